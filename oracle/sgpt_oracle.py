@@ -1,0 +1,390 @@
+"""CPU oracle for the SGPT bi-encoder retrieval hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``sgpt_amd/`` may import this file: only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+use it, and there only as the checker / the reported CPU baseline.
+
+It is a plain numpy (fp32) restatement of the reference algorithm, function by
+function.  Citations are relative to /root/reference; ``HF:`` points into the
+un-vendored dependency that holds the transformer arithmetic
+(huggingface ``transformers``; reference pin ``transformers>=4.6,<5``, setup.py:21
+of the vendored sentence-transformers; 5.15.0 installed in this image), whose
+eager GPT-Neo path is restated here from its published algorithm.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` (run in the build
+container, where /root/reference and HF transformers exist) checks every function
+below against the real reference code (HF ``GPTNeoModel`` eager fp32, the
+reference's own ``Pooling.py`` / ``util.py`` / ``exact_search.py`` loaded from
+their files) and commits the input/output vectors under ``tests/golden``;
+``tests/test_oracle.py`` re-checks the oracle against those vectors and against
+the reference's own offline tests (``tests/test_util.py:9-53,69-76``).
+"""
+from __future__ import annotations
+
+import heapq
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+F32 = np.float32
+FINFO_MIN = np.finfo(np.float32).min
+
+
+# ----------------------------------------------------------------------------
+# Model description + seeded synthetic weights (shared with the GPU tests so the
+# CPU and GPU sides read identical bytes)
+# ----------------------------------------------------------------------------
+class NeoConfig:
+    """Subset of HF GPTNeoConfig that the forward pass reads
+    (HF:gpt_neo/configuration_gpt_neo.py)."""
+
+    def __init__(self, vocab_size=50257, max_position_embeddings=2048, hidden_size=768,
+                 num_layers=12, num_heads=12, intermediate_size=None, window_size=256,
+                 attention_layers=None, layer_norm_epsilon=1e-5):
+        self.vocab_size = vocab_size
+        self.max_position_embeddings = max_position_embeddings
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.num_heads = num_heads
+        self.intermediate_size = intermediate_size or 4 * hidden_size
+        self.window_size = window_size
+        # GPT-Neo default: alternating global/local (HF: attention_types=[[["global","local"], L/2]])
+        self.attention_layers = attention_layers or [
+            "global" if i % 2 == 0 else "local" for i in range(num_layers)]
+        self.layer_norm_epsilon = layer_norm_epsilon
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_heads
+
+
+SGPT_125M = dict(vocab_size=50257, max_position_embeddings=2048, hidden_size=768,
+                 num_layers=12, num_heads=12, window_size=256)
+SGPT_1_3B = dict(vocab_size=50257, max_position_embeddings=2048, hidden_size=2048,
+                 num_layers=24, num_heads=16, window_size=256)
+SGPT_2_7B = dict(vocab_size=50257, max_position_embeddings=2048, hidden_size=2560,
+                 num_layers=32, num_heads=20, window_size=256)
+
+
+def bf16_round(a: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 (the de-quantised weights the
+    oracle uses when the GPU runs bf16 MFMA operands)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    rounded = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return rounded.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def synth_weights(cfg: NeoConfig, seed: int = 0, std: float = 0.02,
+                  bf16_linear: bool = False) -> Dict[str, np.ndarray]:
+    """Seeded random-init weights under HF GPT-Neo state-dict names (no
+    checkpoints exist offline).  Biases/LN get non-trivial values
+    so a dropped bias cannot hide.  ``bf16_linear`` rounds the six matmul weights
+    of every block to bf16 (what the bf16 MFMA path holds)."""
+    rng = np.random.default_rng(seed)
+    d, ffn = cfg.hidden_size, cfg.intermediate_size
+
+    def nrm(*shape, s=std):
+        return (rng.standard_normal(shape, dtype=np.float32) * F32(s)).astype(F32)
+
+    w = {"wte.weight": nrm(cfg.vocab_size, d), "wpe.weight": nrm(cfg.max_position_embeddings, d, s=std / 2)}
+    q = bf16_round if bf16_linear else (lambda x: x)
+    for i in range(cfg.num_layers):
+        p = f"h.{i}."
+        w[p + "ln_1.weight"] = (1.0 + nrm(d, s=0.1)).astype(F32)
+        w[p + "ln_1.bias"] = nrm(d, s=0.05)
+        w[p + "attn.attention.q_proj.weight"] = q(nrm(d, d))
+        w[p + "attn.attention.k_proj.weight"] = q(nrm(d, d))
+        w[p + "attn.attention.v_proj.weight"] = q(nrm(d, d))
+        w[p + "attn.attention.out_proj.weight"] = q(nrm(d, d))
+        w[p + "attn.attention.out_proj.bias"] = nrm(d, s=0.02)
+        w[p + "ln_2.weight"] = (1.0 + nrm(d, s=0.1)).astype(F32)
+        w[p + "ln_2.bias"] = nrm(d, s=0.05)
+        w[p + "mlp.c_fc.weight"] = q(nrm(ffn, d))
+        w[p + "mlp.c_fc.bias"] = nrm(ffn, s=0.02)
+        w[p + "mlp.c_proj.weight"] = q(nrm(d, ffn))
+        w[p + "mlp.c_proj.bias"] = nrm(d, s=0.02)
+    w["ln_f.weight"] = (1.0 + nrm(d, s=0.1)).astype(F32)
+    w["ln_f.bias"] = nrm(d, s=0.05)
+    return w
+
+
+# ----------------------------------------------------------------------------
+# a2: GPT-Neo forward  (HF:gpt_neo/modeling_gpt_neo.py)
+# ----------------------------------------------------------------------------
+def layer_norm(x, g, b, eps):
+    """nn.LayerNorm(eps) over the last dim (HF:gpt_neo:317-319,385)."""
+    x = x.astype(F32)
+    mean = x.mean(axis=-1, keepdims=True, dtype=F32)
+    xc = x - mean
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=F32)
+    return (xc / np.sqrt(var + F32(eps))) * g + b
+
+
+def gelu_new(u):
+    """transformers/activations.py NewGELUActivation:
+    0.5u(1+tanh(sqrt(2/pi)(u+0.044715u^3)))."""
+    u = u.astype(F32)
+    c = F32(np.sqrt(2.0 / np.pi))
+    return F32(0.5) * u * (F32(1.0) + np.tanh(c * (u + F32(0.044715) * u * u * u)))
+
+
+def _softmax_lastdim(a):
+    m = a.max(axis=-1, keepdims=True)
+    e = np.exp(a - m)
+    return e / e.sum(axis=-1, keepdims=True, dtype=F32)
+
+
+def gptneo_forward(w: Dict[str, np.ndarray], cfg: NeoConfig, input_ids, attention_mask=None,
+                   output_hidden_states: bool = False, position_offset=None):
+    """GPTNeoModel.forward (HF:gpt_neo:398-505), eager attention (105-130), fp32.
+
+    input_ids int[B,S]; attention_mask {0,1}[B,S] (None = all ones).
+    Returns last_hidden_state fp32[B,S,d] (post ln_f) and, if asked, the tuple of
+    L+1 hidden states (entry i = input to block i; last = post-ln_f, HF:gpt_neo:478,492-497).
+    Positions are the absolute padded index arange(S) (HF:gpt_neo:451) -- NOT mask-aware.
+    """
+    ids = np.asarray(input_ids)
+    B, S = ids.shape
+    d, H, dh = cfg.hidden_size, cfg.num_heads, cfg.head_dim
+    if attention_mask is None:
+        attention_mask = np.ones((B, S), dtype=np.int64)
+    am = np.asarray(attention_mask)
+    pos = np.arange(S)
+    x = w["wte.weight"][ids] + w["wpe.weight"][pos][None, :, :]          # :444,462-463
+    x = x.astype(F32)
+
+    # causal (+ sliding window) "bias" buffers (HF:gpt_neo:56-66)
+    ii = np.arange(S)[:, None]
+    jj = np.arange(S)[None, :]
+    causal = jj <= ii
+    local = causal & (jj > ii - cfg.window_size)                       # tril xor tril(-window)
+    # 4-D additive mask: 0 where key may be attended, finfo.min where padded
+    # (create_causal_mask(...) for the eager path combines causal & padding; the
+    # causal part is re-applied by torch.where below, :113-119)
+    pad_add = np.where(am[:, None, None, :] != 0, F32(0), F32(FINFO_MIN)).astype(F32)
+
+    hs = []
+    for i in range(cfg.num_layers):
+        if output_hidden_states:
+            hs.append(x)
+        p = f"h.{i}."
+        a = layer_norm(x, w[p + "ln_1.weight"], w[p + "ln_1.bias"], cfg.layer_norm_epsilon)
+        q = a @ w[p + "attn.attention.q_proj.weight"].T                 # no bias :84-86
+        k = a @ w[p + "attn.attention.k_proj.weight"].T
+        v = a @ w[p + "attn.attention.v_proj.weight"].T
+        q = q.reshape(B, S, H, dh).transpose(0, 2, 1, 3)
+        k = k.reshape(B, S, H, dh).transpose(0, 2, 1, 3)
+        v = v.reshape(B, S, H, dh).transpose(0, 2, 1, 3)
+        sc = np.matmul(q, k.transpose(0, 1, 3, 2)).astype(F32)          # UNSCALED :110
+        bias = local if cfg.attention_layers[i] == "local" else causal
+        sc = np.where(bias[None, None], sc, F32(FINFO_MIN))             # :113-117
+        with np.errstate(over="ignore"):
+            sc = sc + pad_add                                           # :119-120
+        pr = _softmax_lastdim(sc)                                       # :122
+        ctx = np.matmul(pr, v)                                          # :126
+        ctx = ctx.transpose(0, 2, 1, 3).reshape(B, S, d)
+        ao = ctx @ w[p + "attn.attention.out_proj.weight"].T + w[p + "attn.attention.out_proj.bias"]
+        x = ao + x                                                      # :342
+        a2 = layer_norm(x, w[p + "ln_2.weight"], w[p + "ln_2.bias"], cfg.layer_norm_epsilon)
+        h = gelu_new(a2 @ w[p + "mlp.c_fc.weight"].T + w[p + "mlp.c_fc.bias"])
+        m = h @ w[p + "mlp.c_proj.weight"].T + w[p + "mlp.c_proj.bias"]
+        x = (x + m).astype(F32)                                         # :348
+    x = layer_norm(x, w["ln_f.weight"], w["ln_f.bias"], cfg.layer_norm_epsilon)  # :492
+    if output_hidden_states:
+        hs.append(x)
+        return x, tuple(hs)
+    return x
+
+
+# ----------------------------------------------------------------------------
+# a4/a5: pooling
+# ----------------------------------------------------------------------------
+def pool(hidden, attention_mask, mode: str = "weightedmean", clamp: bool = True):
+    """Pooling.forward (sentence_transformers/models/Pooling.py:99-125 weightedmean/mean,
+    129-164 lasttoken) and the raw-HF variants (beir_dense_retriever.py:238-242 mean,
+    258-270 weightedmean, 271-282 lasttoken).
+
+    weights w_t = t+1 over the PADDED index (Pooling.py:104-112).  ``clamp`` applies the
+    1e-9 floor on the weight sum that only Pooling.py:122 has.
+    lasttoken follows the raw path's ``len-1`` semantics = index of the last mask==1
+    token (beir_dense_retriever.py:198,271-282), not ST's argmin bug (appendix A.8).
+    """
+    h = np.asarray(hidden, dtype=F32)
+    m = np.asarray(attention_mask).astype(F32)
+    B, S, d = h.shape
+    if mode in ("weightedmean", "mean"):
+        wts = m.copy()
+        if mode == "weightedmean":
+            wts = wts * np.arange(1, S + 1, dtype=F32)[None, :]
+        num = (h * wts[:, :, None]).sum(axis=1, dtype=F32)
+        den = wts.sum(axis=1, dtype=F32)[:, None]
+        if clamp:
+            den = np.maximum(den, F32(1e-9))
+        return (num / den).astype(F32)
+    if mode == "lasttoken":
+        idx = np.array([int(np.nonzero(r)[0][-1]) if r.any() else 0 for r in m])
+        return h[np.arange(B), idx].astype(F32)
+    raise ValueError(f"unknown pooling mode {mode}")
+
+
+def pool_layers(all_hidden: Sequence[np.ndarray], attention_mask, mode: str):
+    """meanmean / lasttokenmean over ALL L+1 hidden states
+    (beir_dense_retriever.py:243-257, 284-301)."""
+    m = np.asarray(attention_mask).astype(F32)
+    hs = np.stack([np.asarray(h, dtype=F32) for h in all_hidden])       # [L+1,B,S,d]
+    if mode == "meanmean":
+        num = (hs * m[None, :, :, None]).sum(axis=2).sum(axis=0)
+        den = (m.sum(axis=1) * hs.shape[0])[:, None]
+        return (num / den).astype(F32)
+    if mode == "lasttokenmean":
+        B = m.shape[0]
+        idx = np.array([int(np.nonzero(r)[0][-1]) for r in m])
+        return hs[:, np.arange(B), idx].mean(axis=0).astype(F32)
+    raise ValueError(mode)
+
+
+# ----------------------------------------------------------------------------
+# a7: scoring
+# ----------------------------------------------------------------------------
+def _as2d(a):
+    a = np.asarray(a, dtype=F32)
+    return a[None, :] if a.ndim == 1 else a
+
+
+def normalize(a, eps: float = 1e-12):
+    """torch.nn.functional.normalize(p=2, dim=1): x / max(||x||, eps) (util.py:41-42,
+    util.normalize_embeddings :66-70)."""
+    a = _as2d(a)
+    n = np.sqrt((a * a).sum(axis=1, keepdims=True, dtype=F32))
+    return (a / np.maximum(n, F32(eps))).astype(F32)
+
+
+def cos_sim(a, b):
+    """util.cos_sim (sentence_transformers/util.py:24-43) == beir.util.cos_sim."""
+    return (normalize(a) @ normalize(b).T).astype(F32)
+
+
+def dot_score(a, b):
+    """util.dot_score (util.py:46-63)."""
+    return (_as2d(a) @ _as2d(b).T).astype(F32)
+
+
+def pairwise_cos_sim(a, b):
+    """util.pairwise_cos_sim (util.py:86-97): row-wise cosine."""
+    return (normalize(a) * normalize(b)).sum(axis=1, dtype=F32)
+
+
+# ----------------------------------------------------------------------------
+# a8: top-k + chunk merge
+# ----------------------------------------------------------------------------
+def topk_rows(scores, k):
+    """torch.topk(scores, k, dim=1, largest=True, sorted=False) as a set per row:
+    returns (values[nq,k], idx[nq,k]) sorted descending for determinism (the
+    reference's order is unspecified, exact_search.py:102-108)."""
+    s = np.asarray(scores, dtype=F32)
+    k = min(k, s.shape[1])
+    idx = np.argsort(-s, axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(s, idx, axis=1), idx
+
+
+def exact_search(query_emb, query_ids: List[str], corpus_emb_chunks, corpus_ids: List[str],
+                 top_k: int, score_function: str = "cos_sim",
+                 chunk_size: int = 50000) -> Dict[str, Dict[str, float]]:
+    """DenseRetrievalExactSearch.search after the encode calls
+    (biencoder/beir/custommodels/exact_search.py:80-132): per corpus chunk score
+    (:96-98), NaN -> -1 (:99), topk(min(k+1,n)) (:102-108), drop corpus_id == query_id
+    (:118), after the first chunk keep heapq.nlargest(min(k+1,len)) (:121-132).
+
+    ``corpus_emb_chunks`` is a callable chunk_index -> fp32[n_chunk,d] or a full array.
+    """
+    if score_function not in ("cos_sim", "dot"):
+        raise ValueError(
+            "score function: {} must be either (cos_sim) for cosine similarity or (dot) for dot product".format(
+                score_function))
+    fn = cos_sim if score_function == "cos_sim" else dot_score
+    results: Dict[str, Dict[str, float]] = {qid: {} for qid in query_ids}
+    n = len(corpus_ids)
+    for batch_num, start in enumerate(range(0, n, chunk_size)):
+        end = min(start + chunk_size, n)
+        sub = corpus_emb_chunks(batch_num) if callable(corpus_emb_chunks) else corpus_emb_chunks[start:end]
+        sc = fn(query_emb, sub)
+        sc[np.isnan(sc)] = -1
+        vals, idx = topk_rows(sc, min(top_k + 1, sc.shape[1]))
+        for qi, qid in enumerate(query_ids):
+            for sub_id, score in zip(idx[qi].tolist(), vals[qi].tolist()):
+                cid = corpus_ids[start + sub_id]
+                if cid != qid:
+                    results[qid][cid] = score
+            if batch_num > 0:
+                keep = heapq.nlargest(min(top_k + 1, len(results[qid])), results[qid], key=results[qid].get)
+                results[qid] = {k_: results[qid][k_] for k_ in keep}
+    return results
+
+
+def semantic_search(query_emb, corpus_emb, query_chunk_size=100, corpus_chunk_size=500000,
+                    top_k=10, score_function=cos_sim):
+    """util.semantic_search (util.py:197-258): chunked top-k with final sort."""
+    q = _as2d(query_emb)
+    c = _as2d(corpus_emb)
+    out = [[] for _ in range(len(q))]
+    for qs in range(0, len(q), query_chunk_size):
+        for cs in range(0, len(c), corpus_chunk_size):
+            sc = score_function(q[qs:qs + query_chunk_size], c[cs:cs + corpus_chunk_size])
+            vals, idx = topk_rows(sc, min(top_k, sc.shape[1]))
+            for r in range(sc.shape[0]):
+                for j, v in zip(idx[r].tolist(), vals[r].tolist()):
+                    out[qs + r].append({"corpus_id": cs + j, "score": v})
+    for i in range(len(out)):
+        out[i] = sorted(out[i], key=lambda x: x["score"], reverse=True)[:top_k]
+    return out
+
+
+# ----------------------------------------------------------------------------
+# a1: the integer part of tokenisation that does not need a vocabulary
+# ----------------------------------------------------------------------------
+SPECB_QUE_BOS, SPECB_QUE_EOS, SPECB_DOC_BOS, SPECB_DOC_EOS = 58, 60, 90, 92   # GPT-2 BPE ids of [ ] { }
+GPT2_PAD = 50256                                                               # pad = eos
+
+
+def specb_wrap(ids: Sequence[int], is_query: bool, max_token_len: Optional[int] = None) -> List[int]:
+    """beir_dense_retriever.py:183-191 / Transformer.py:131-153 restated on ids:
+    truncate to max_token_len (already reduced by 2, :134-136), then bracket."""
+    ids = list(ids)
+    if max_token_len is not None:
+        ids = ids[:max_token_len]
+    if is_query:
+        return [SPECB_QUE_BOS] + ids + [SPECB_QUE_EOS]
+    return [SPECB_DOC_BOS] + ids + [SPECB_DOC_EOS]
+
+
+def pad_batch(seqs: Sequence[Sequence[int]], pad_id: int = GPT2_PAD, side: str = "right"):
+    """tokenizer.pad(padding=True) (beir_dense_retriever.py:201): pad to batch max."""
+    S = max(len(s) for s in seqs)
+    ids = np.full((len(seqs), S), pad_id, dtype=np.int64)
+    mask = np.zeros((len(seqs), S), dtype=np.int64)
+    for i, s in enumerate(seqs):
+        if side == "right":
+            ids[i, :len(s)] = s
+            mask[i, :len(s)] = 1
+        else:
+            ids[i, S - len(s):] = s
+            mask[i, S - len(s):] = 1
+    return ids, mask
+
+
+def encode(w, cfg, seqs: Sequence[Sequence[int]], mode="weightedmean", batch_size=32,
+           normalize_embeddings=False, layer_idx=-1, pad_side="right"):
+    """embed_batcher loop (beir_dense_retriever.py:225-314) on pre-tokenised ids:
+    batch -> pad -> forward -> select layer -> pool."""
+    out = []
+    for i in range(0, len(seqs), batch_size):
+        ids, mask = pad_batch(seqs[i:i + batch_size], pad_id=min(GPT2_PAD, cfg.vocab_size - 1), side=pad_side)
+        last, hs = gptneo_forward(w, cfg, ids, mask, output_hidden_states=True)
+        h = hs[layer_idx]
+        if mode in ("meanmean", "lasttokenmean"):
+            e = pool_layers(hs, mask, mode)
+        else:
+            e = pool(h, mask, mode, clamp=True)
+        out.append(normalize(e) if normalize_embeddings else e)
+    return np.concatenate(out, axis=0)

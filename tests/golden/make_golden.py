@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference and HF transformers):
+  * HF ``GPTNeoModel`` (eager attention, fp32, eval) -- the un-vendored dependency
+    the reference calls at beir_dense_retriever.py:204-205 / Transformer.py:72,
+  * the reference's own ``Pooling.py`` (loaded from its file),
+  * the pure-torch head of the vendored ``util.py`` (cos_sim, dot_score,
+    normalize_embeddings, semantic_search, pairwise_cos_sim),
+  * the reference's ``exact_search.py`` with a stub ``beir`` module.
+
+Weights are NOT stored: they are regenerated from a seed by
+``oracle.sgpt_oracle.synth_weights`` (numpy Generator streams are stable across
+platforms), so fixtures stay small.  While generating, every oracle function is
+checked against the reference output (this is what pins the oracle).
+
+    python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import sgpt_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+ST = f"{REF}/biencoder/nli_msmarco/sentence-transformers/sentence_transformers"
+
+
+def load_file_module(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_ref_util():
+    """exec lines 1-449 of the vendored util.py (everything below needs
+    huggingface_hub symbols that no longer exist)."""
+    src = open(f"{ST}/util.py").read().split("\n")
+    head = "\n".join(src[:449])
+    head = head.replace("import requests\n", "").replace("from tqdm.autonotebook import tqdm", "tqdm = None")
+    mod = types.ModuleType("ref_util")
+    exec(compile(head, f"{ST}/util.py", "exec"), mod.__dict__)
+    return mod
+
+
+def load_ref_exact_search(ref_util):
+    beir = types.ModuleType("beir")
+    beir_util = types.ModuleType("beir.util")
+    import logging
+
+    class LoggingHandler(logging.Handler):
+        def emit(self, record):
+            pass
+
+    beir.LoggingHandler = LoggingHandler
+    beir_util.cos_sim = ref_util.cos_sim
+    beir_util.dot_score = ref_util.dot_score
+    beir.util = beir_util
+    sys.modules["beir"] = beir
+    sys.modules["beir.util"] = beir_util
+    return load_file_module("ref_exact_search", f"{REF}/biencoder/beir/custommodels/exact_search.py")
+
+
+def hf_model(cfg: O.NeoConfig, w):
+    from transformers import GPTNeoConfig, GPTNeoModel
+    types_ = []
+    # HF wants [[pattern, repeat]]: alternate global/local
+    assert cfg.attention_layers == ["global" if i % 2 == 0 else "local" for i in range(cfg.num_layers)]
+    hc = GPTNeoConfig(vocab_size=cfg.vocab_size, max_position_embeddings=cfg.max_position_embeddings,
+                      hidden_size=cfg.hidden_size, num_layers=cfg.num_layers, num_heads=cfg.num_heads,
+                      intermediate_size=cfg.intermediate_size, window_size=cfg.window_size,
+                      attention_types=[[["global", "local"], cfg.num_layers // 2]],
+                      layer_norm_epsilon=cfg.layer_norm_epsilon,
+                      attention_dropout=0.0, resid_dropout=0.0, embed_dropout=0.0)
+    hc._attn_implementation = "eager"
+    m = GPTNeoModel(hc).eval()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in w.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("bias" in k and "attn.attention.bias" in k or "masked_bias" in k for k in missing), missing
+    return m
+
+
+def rand_seqs(rng, n, lo, hi, vocab):
+    return [rng.integers(0, vocab, size=int(rng.integers(lo, hi + 1))).tolist() for _ in range(n)]
+
+
+def check(name, got, want, tol):
+    err = float(np.max(np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64))))
+    print(f"  oracle-vs-reference {name}: max|diff| = {err:.3e} (tol {tol:g})")
+    assert err <= tol, (name, err)
+    return err
+
+
+def encoder_case(tag, cfg_kw, seed, seqs, pad_side="right", std=0.02, store_hidden=False, Pooling=None):
+    cfg = O.NeoConfig(**cfg_kw)
+    w = O.synth_weights(cfg, seed=seed, std=std)
+    model = hf_model(cfg, w)
+    ids, mask = O.pad_batch(seqs, pad_id=min(O.GPT2_PAD, cfg.vocab_size - 1), side=pad_side)
+    with torch.no_grad():
+        out = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                    output_hidden_states=True)
+    last = out.last_hidden_state.numpy()
+    hs = [h.numpy() for h in out.hidden_states]
+    # reference pooling (Pooling.py) on HF hidden states
+    d = cfg.hidden_size
+    emb = {}
+    for mode, kw in (("weightedmean", dict(pooling_mode_weightedmean_tokens=True, pooling_mode_mean_tokens=False)),
+                     ("mean", dict(pooling_mode_mean_tokens=True))):
+        pm = Pooling.Pooling(d, **kw)
+        feats = {"token_embeddings": torch.from_numpy(last.copy()), "attention_mask": torch.from_numpy(mask)}
+        emb[mode] = pm.forward(feats)["sentence_embedding"].numpy()
+    # raw-HF lasttoken (beir_dense_retriever.py:271-282): gather at len-1 of the real tokens
+    gi = np.array([np.nonzero(r)[0][-1] for r in mask])
+    emb["lasttoken"] = last[np.arange(len(seqs)), gi]
+    # raw-HF weightedmean cross-check (beir_dense_retriever.py:258-270)
+    ime = torch.from_numpy(mask).unsqueeze(-1).expand(last.shape).float()
+    wts = torch.arange(1, last.shape[1] + 1).unsqueeze(0).unsqueeze(-1).expand(last.shape).float()
+    raw = (torch.sum(torch.from_numpy(last) * ime * wts, dim=1) / torch.sum(ime * wts, dim=1)).numpy()
+    check(f"{tag} Pooling.py vs raw path weightedmean", emb["weightedmean"], raw, 1e-6)
+    # layeridx variants (hidden_states[i], beir_dense_retriever.py:233) -- store pooled layer -2 (pre-ln_f input of last block)
+    pm = Pooling.Pooling(d, pooling_mode_weightedmean_tokens=True, pooling_mode_mean_tokens=False)
+    emb_l2 = pm.forward({"token_embeddings": torch.from_numpy(hs[-2].copy()),
+                         "attention_mask": torch.from_numpy(mask)})["sentence_embedding"].numpy()
+
+    # ---- pin the oracle ----
+    o_last, o_hs = O.gptneo_forward(w, cfg, ids, mask, output_hidden_states=True)
+    real = mask.astype(bool)
+    check(f"{tag} last_hidden (real tokens)", o_last[real], last[real], 2e-4)
+    for li in (0, 1, len(hs) - 2):
+        check(f"{tag} hidden_states[{li}] (real tokens)", o_hs[li][real], hs[li][real], 2e-4)
+    for mode in ("weightedmean", "mean", "lasttoken"):
+        check(f"{tag} pool {mode}", O.pool(o_last, mask, mode), emb[mode], 2e-4)
+        check(f"{tag} pool-only {mode}", O.pool(last, mask, mode), emb[mode], 5e-6)
+    enc = O.encode(w, cfg, seqs, mode="weightedmean", batch_size=len(seqs), pad_side=pad_side)
+    check(f"{tag} encode()", enc, emb["weightedmean"], 2e-4)
+
+    fx = dict(cfg=np.array(repr(cfg_kw)), seed=seed, std=std, pad_side=np.array(pad_side),
+              seq_lens=np.array([len(s) for s in seqs]), ids=ids.astype(np.int32), mask=mask.astype(np.int8),
+              emb_weightedmean=emb["weightedmean"], emb_mean=emb["mean"], emb_lasttoken=emb["lasttoken"],
+              emb_weightedmean_layer_m2=emb_l2)
+    if store_hidden:
+        fx["last_hidden"] = last
+        fx["hidden_1"] = hs[1]
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **fx)
+    print(f"wrote {tag}.npz")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    Pooling = load_file_module("ref_pooling", f"{ST}/models/Pooling.py")
+    U = load_ref_util()
+    ES = load_ref_exact_search(U)
+
+    # ---------------- encoder + pooling ----------------
+    tiny = dict(vocab_size=211, max_position_embeddings=96, hidden_size=128, num_layers=4,
+                num_heads=2, window_size=8)
+    rng = np.random.default_rng(100)
+    encoder_case("tiny_right", tiny, seed=11, seqs=rand_seqs(rng, 9, 1, 40, 211), std=0.08,
+                 store_hidden=True, Pooling=Pooling)
+    encoder_case("tiny_left", tiny, seed=11, seqs=rand_seqs(rng, 7, 2, 33, 211), pad_side="left",
+                 std=0.08, store_hidden=True, Pooling=Pooling)
+    tiny128 = dict(vocab_size=211, max_position_embeddings=96, hidden_size=256, num_layers=2,
+                   num_heads=2, window_size=16)          # head_dim 128 (the 1.3B/2.7B head size)
+    encoder_case("tiny_dh128", tiny128, seed=12, seqs=rand_seqs(rng, 6, 3, 50, 211), std=0.06,
+                 store_hidden=True, Pooling=Pooling)
+    # BASELINE config 1: SGPT-125M shape, 32 sentences, seq_len<=64
+    rng = np.random.default_rng(0)
+    seqs = rand_seqs(rng, 32, 8, 64, 50256)
+    seqs[0] = rng.integers(0, 50256, size=64).tolist()
+    encoder_case("cfg1_125m_32x64", O.SGPT_125M, seed=0, seqs=seqs, Pooling=Pooling)
+    # config-3 style: specb brackets, docs up to 300 tokens -> exercises the 256 local window
+    rng = np.random.default_rng(2)
+    docs = [O.specb_wrap(rng.integers(0, 50256, size=n).tolist(), is_query=False) for n in (298, 280, 150, 17)]
+    qs = [O.specb_wrap(rng.integers(0, 50256, size=n).tolist(), is_query=True) for n in (30, 7)]
+    encoder_case("cfg3_125m_specb_s300", O.SGPT_125M, seed=2, seqs=docs + qs, Pooling=Pooling)
+
+    # ---------------- scoring / top-k (reference util.py + exact_search.py) ----------------
+    rng = np.random.default_rng(7)
+    a = rng.standard_normal((50, 100)).astype(np.float32)
+    b = rng.standard_normal((37, 100)).astype(np.float32)
+    b[3] = 0.0                                     # zero-norm row (eps path of F.normalize)
+    cos = U.cos_sim(torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    dot = U.dot_score(torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    nrm = U.normalize_embeddings(torch.from_numpy(a)).numpy()
+    pcs = U.pairwise_cos_sim(torch.from_numpy(a[:37]), torch.from_numpy(b)).numpy()
+    check("cos_sim", O.cos_sim(a, b), cos, 1e-6)
+    check("dot_score", O.dot_score(a, b), dot, 1e-5)
+    check("normalize", O.normalize(a), nrm, 1e-6)
+    check("pairwise_cos_sim", O.pairwise_cos_sim(a[:37], b), pcs, 1e-6)
+    # semantic_search, the shapes of tests/test_util.py:33-53
+    docs_e = rng.standard_normal((1000, 100)).astype(np.float32)
+    q_e = rng.standard_normal((20, 100)).astype(np.float32)
+    hits = U.semantic_search(torch.from_numpy(q_e), torch.from_numpy(docs_e), top_k=10,
+                             query_chunk_size=5, corpus_chunk_size=17)
+    ss_idx = np.array([[h["corpus_id"] for h in row] for row in hits], dtype=np.int64)
+    ss_val = np.array([[h["score"] for h in row] for row in hits], dtype=np.float32)
+    ohits = O.semantic_search(q_e, docs_e, top_k=10, query_chunk_size=5, corpus_chunk_size=17)
+    assert (np.array([[h["corpus_id"] for h in row] for row in ohits]) == ss_idx).all()
+    check("semantic_search scores", np.array([[h["score"] for h in row] for row in ohits]), ss_val, 1e-6)
+
+    # exact_search.search with a fake encoder (embeddings looked up by id), 3 chunks, anisotropic embeddings
+    nd, nq, dd, topk = 700, 13, 96, 10
+    ce = rng.standard_normal((nd, dd)).astype(np.float32)
+    qe = rng.standard_normal((nq, dd)).astype(np.float32)
+    ce[:, :3] *= 30.0
+    qe[:, :3] *= 30.0                              # SGPT-like anisotropy
+    corpus = {f"d{i}": {"title": "t" * int(rng.integers(0, 5)), "text": "x" * int(rng.integers(1, 50))} for i in range(nd)}
+    queries = {f"q{i}": "q" for i in range(nq)}
+    # make query ids collide with corpus ids for two queries (the self-match rule :118)
+    queries = {("d5" if i == 2 else "d9" if i == 4 else k): v for i, (k, v) in enumerate(queries.items())}
+    cvec = {f"d{i}": ce[i] for i in range(nd)}
+    qvec = {k: qe[i] for i, k in enumerate(queries)}
+
+    class FakeModel:
+        def encode_queries(self, qs, batch_size, **kw):
+            return torch.from_numpy(np.stack([qvec[qid] for qid, _ in qs]))
+
+        def encode_corpus(self, cs, batch_size, **kw):
+            return torch.from_numpy(np.stack([cvec[cid] for cid, _ in cs]))
+
+    es_out = {}
+    for fn in ("cos_sim", "dot"):
+        s = ES.DenseRetrievalExactSearch(FakeModel(), batch_size=8, corpus_chunk_size=256)
+        res = s.search(corpus, queries, topk, fn)
+        # oracle restatement on the same sorted corpus order (:66-71)
+        cids = sorted(corpus, key=lambda k: len(corpus[k].get("title", "") + corpus[k].get("text", "")), reverse=True)
+        cemb = np.stack([cvec[c] for c in cids])
+        ores = O.exact_search(np.stack([qvec[q] for q in queries]), list(queries), cemb, cids, topk, fn, chunk_size=256)
+        for qid in queries:
+            assert set(res[qid]) == set(ores[qid]), (fn, qid)
+            check(f"exact_search[{fn}] {qid}", [ores[qid][c] for c in res[qid]], [res[qid][c] for c in res[qid]], 1e-4)
+        es_out[fn] = res
+    try:
+        ES.DenseRetrievalExactSearch(FakeModel()).search(corpus, queries, topk, "euclid")
+        raise AssertionError("expected ValueError")
+    except ValueError as e:
+        bad_fn_msg = str(e)
+
+    import json
+    np.savez_compressed(
+        os.path.join(HERE, "scoring.npz"), a=a, b=b, cos=cos, dot=dot, nrm=nrm, pcs=pcs,
+        ss_docs=docs_e, ss_q=q_e, ss_idx=ss_idx, ss_val=ss_val,
+        es_corpus_emb=ce, es_query_emb=qe,
+        es_json=np.array(json.dumps(dict(corpus=corpus, queries=list(queries.keys()), top_k=topk, chunk=256,
+                                         results=es_out, bad_fn_msg=bad_fn_msg))))
+    print("wrote scoring.npz")
+
+
+if __name__ == "__main__":
+    main()

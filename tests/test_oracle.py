@@ -1,0 +1,134 @@
+"""The oracle against (1) the committed golden vectors produced by the real reference
+(tests/golden/make_golden.py: HF GPTNeoModel + reference Pooling.py / util.py /
+exact_search.py) and (2) the reference's own offline tests, restated:
+sentence-transformers/tests/test_util.py:9-18, 21-30, 33-53, 69-76."""
+import ast
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sgpt_oracle as O
+
+
+def load_case(golden_dir, tag):
+    fx = np.load(os.path.join(golden_dir, f"{tag}.npz"))
+    cfg = O.NeoConfig(**ast.literal_eval(str(fx["cfg"])))
+    lens = fx["seq_lens"].tolist()
+    ids, mask = fx["ids"].astype(np.int64), fx["mask"].astype(np.int64)
+    side = str(fx["pad_side"])
+    seqs = [ids[i, :n].tolist() if side == "right" else ids[i, ids.shape[1] - n:].tolist() for i, n in enumerate(lens)]
+    return fx, cfg, seqs, ids, mask, side
+
+
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128"])
+def test_oracle_encoder_matches_hf_golden(golden_dir, tag):
+    fx, cfg, seqs, ids, mask, side = load_case(golden_dir, tag)
+    w = O.synth_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    last, hs = O.gptneo_forward(w, cfg, ids, mask, output_hidden_states=True)
+    real = mask.astype(bool)
+    assert np.abs(last[real] - fx["last_hidden"][real]).max() < 2e-4
+    assert np.abs(hs[1][real] - fx["hidden_1"][real]).max() < 2e-4
+    for mode in ("weightedmean", "mean", "lasttoken"):
+        assert np.abs(O.pool(last, mask, mode) - fx[f"emb_{mode}"]).max() < 2e-4
+        # pooling alone, fed the reference's own hidden states
+        assert np.abs(O.pool(fx["last_hidden"], mask, mode) - fx[f"emb_{mode}"]).max() < 5e-6
+    assert np.abs(O.pool(hs[-2], mask, "weightedmean") - fx["emb_weightedmean_layer_m2"]).max() < 2e-4
+    enc = O.encode(w, cfg, seqs, batch_size=len(seqs), pad_side=side)
+    assert np.abs(enc - fx["emb_weightedmean"]).max() < 2e-4
+
+
+def test_oracle_cfg3_specb_window(golden_dir):
+    """125M shape, specb brackets, S=300 (GPT-Neo local window 256 active)."""
+    fx, cfg, seqs, ids, mask, side = load_case(golden_dir, "cfg3_125m_specb_s300")
+    assert seqs[0][0] == O.SPECB_DOC_BOS and seqs[0][-1] == O.SPECB_DOC_EOS and len(seqs[0]) == 300
+    assert seqs[-1][0] == O.SPECB_QUE_BOS and seqs[-1][-1] == O.SPECB_QUE_EOS
+    w = O.synth_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    enc = O.encode(w, cfg, seqs[:2] + seqs[-1:], batch_size=3)
+    want = np.concatenate([fx["emb_weightedmean"][:2], fx["emb_weightedmean"][-1:]])
+    # right padding => embeddings do not depend on the batch's max length
+    assert np.abs(enc - want).max() < 2e-4
+
+
+def test_right_padding_is_batch_invariant_left_is_not(golden_dir):
+    fx, cfg, seqs, ids, mask, side = load_case(golden_dir, "tiny_right")
+    w = O.synth_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    one = O.encode(w, cfg, [seqs[3]], batch_size=1)
+    assert np.abs(one[0] - fx["emb_weightedmean"][3]).max() < 2e-4
+    both_l = O.encode(w, cfg, seqs, batch_size=len(seqs), pad_side="left")
+    one_l = O.encode(w, cfg, [seqs[3]], batch_size=1, pad_side="left")
+    assert np.abs(one_l[0] - both_l[3]).max() > 1e-3
+
+
+def test_scoring_golden(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "scoring.npz"))
+    assert np.abs(O.cos_sim(fx["a"], fx["b"]) - fx["cos"]).max() < 1e-6
+    assert np.abs(O.dot_score(fx["a"], fx["b"]) - fx["dot"]).max() < 1e-5
+    assert np.abs(O.normalize(fx["a"]) - fx["nrm"]).max() < 1e-6
+    assert np.abs(O.pairwise_cos_sim(fx["a"][:37], fx["b"]) - fx["pcs"]).max() < 1e-6
+    # 1-D inputs promoted (util.py:35-39)
+    assert O.cos_sim(fx["a"][0], fx["b"]).shape == (1, 37)
+    hits = O.semantic_search(fx["ss_q"], fx["ss_docs"], top_k=10, query_chunk_size=5, corpus_chunk_size=17)
+    assert (np.array([[h["corpus_id"] for h in r] for r in hits]) == fx["ss_idx"]).all()
+    assert np.abs(np.array([[h["score"] for h in r] for r in hits]) - fx["ss_val"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("fn", ["cos_sim", "dot"])
+def test_exact_search_golden(golden_dir, fn):
+    fx = np.load(os.path.join(golden_dir, "scoring.npz"))
+    meta = json.loads(str(fx["es_json"]))
+    corpus, qids, topk = meta["corpus"], meta["queries"], meta["top_k"]
+    cvec = {f"d{i}": fx["es_corpus_emb"][i] for i in range(len(corpus))}
+    cids = sorted(corpus, key=lambda k: len(corpus[k].get("title", "") + corpus[k].get("text", "")), reverse=True)
+    res = O.exact_search(fx["es_query_emb"], qids, np.stack([cvec[c] for c in cids]), cids, topk, fn,
+                         chunk_size=meta["chunk"])
+    want = meta["results"][fn]
+    for qid in qids:
+        assert set(res[qid]) == set(want[qid])
+        assert len(res[qid]) <= topk + 1 and qid not in res[qid]
+        for c, v in want[qid].items():
+            assert abs(res[qid][c] - v) < 1e-4
+    with pytest.raises(ValueError) as e:
+        O.exact_search(fx["es_query_emb"], qids, fx["es_corpus_emb"], cids, topk, "euclid")
+    assert str(e.value) == meta["bad_fn_msg"]
+
+
+# ---- the reference's own offline tests, restated (sentence-transformers/tests/test_util.py) ----
+def test_ref_normalize_embeddings():                       # test_util.py:9-18
+    a = np.random.default_rng(0).standard_normal((50, 100))
+    for e in O.normalize(a):
+        assert len(e) == 100 and abs(np.linalg.norm(e) - 1) < 1e-4
+
+
+def test_ref_cos_sim_vs_sklearn():                         # test_util.py:21-30
+    from sklearn.metrics.pairwise import cosine_similarity
+    rng = np.random.default_rng(1)
+    a, b = rng.standard_normal((50, 100)), rng.standard_normal((50, 100))
+    assert np.abs(cosine_similarity(a, b) - O.cos_sim(a, b)).max() < 1e-3
+
+
+def test_ref_semantic_search():                            # test_util.py:33-53
+    rng = np.random.default_rng(2)
+    doc, q = rng.standard_normal((1000, 100)), rng.standard_normal((20, 100))
+    hits = O.semantic_search(q, doc, top_k=10, query_chunk_size=5, corpus_chunk_size=17)
+    assert len(hits) == 20 and len(hits[0]) == 10
+    vals, idx = O.topk_rows(O.cos_sim(q, doc), 10)
+    for qi in range(20):
+        for h in range(10):
+            assert hits[qi][h]["corpus_id"] == idx[qi][h]
+            assert abs(hits[qi][h]["score"] - vals[qi][h]) < 1e-3
+
+
+def test_ref_pairwise_scores():                            # test_util.py:69-76
+    from sklearn.metrics.pairwise import paired_cosine_distances
+    rng = np.random.default_rng(3)
+    a, b = rng.standard_normal((50, 100)), rng.standard_normal((50, 100))
+    assert np.allclose(1 - paired_cosine_distances(a, b), O.pairwise_cos_sim(a, b), atol=1e-6)
+
+
+def test_bf16_round_matches_torch():
+    import torch
+    a = np.random.default_rng(4).standard_normal(10000).astype(np.float32) * 3
+    want = torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    assert (O.bf16_round(a) == want).all()
