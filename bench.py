@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: encoded sentences/sec (+ queries/sec @ corpus)
+for SGPT-125M, seq_len 128, bf16, cosine top-10, synthetic corpus (BASELINE configs[1]).
+
+One "step" = one pass of the reference's corpus-chunk loop (custommodels/exact_search.py:80-132)
+over a chunk of `--chunk` synthetic documents already resident in HBM as packed token ids:
+    encode (GPT-Neo forward + weighted-mean pool + L2 normalise)  ->  bf16 corpus rows
+    score nq pre-encoded queries against the chunk, running top-(k+1) merge.
+N > 1 (torchrun, one rank per GPU): every rank owns its own corpus shard (weak scaling: work per
+GPU fixed); queries are encoded sharded and all-gathered once over RCCL; at the end the per-rank
+top-k lists are all-gathered and merged.  No data-path collective inside a step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+SGPT_125M = dict(vocab_size=50257, max_position_embeddings=2048, hidden_size=768, num_layers=12, num_heads=12,
+                 window_size=256)
+
+
+def flops_per_sentence(S, L=12, d=768):
+    """F(S) = L*24*S*d^2 + 2*L*d*S*(S+1) (causal-minimal attention, ffn = 4d)."""
+    return L * 24 * S * d * d + 2 * L * d * S * (S + 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chunk", type=int, default=4096, help="documents per step (per GPU)")
+    ap.add_argument("--call", type=int, default=1024, help="documents per sgpt_encode call")
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--nq", type=int, default=1000)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-1m", action="store_true", help="skip the queries/sec @ 1M-doc scoring leg")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="sentences in the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)    # RCCL over xGMI
+
+    from sgpt_amd import SGPTConfig, SGPTModel, get_context, synthetic_weights
+    ctx = get_context(dev)
+    cfg = SGPTConfig(**SGPT_125M)
+    model = SGPTModel(cfg, synthetic_weights(cfg, seed=1), device=dev, dtype=args.dtype,
+                      max_tokens_per_call=args.call * args.seq)
+    d, S, k1 = cfg.hidden_size, args.seq, args.topk + 1      # the reference keeps top_k+1 (exact_search.py:104)
+    score_dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    # ---- synthetic inputs, resident in HBM before the clock starts (ids ~ U{0..50255}) ----
+    rng = np.random.default_rng(1000 + rank)
+    n_steps = args.steps + args.warmup
+    calls_per_step = (args.chunk + args.call - 1) // args.call
+    packed = []
+    for _ in range(n_steps):
+        row = []
+        left = args.chunk
+        for _ in range(calls_per_step):
+            nb = min(args.call, left)
+            left -= nb
+            ids = rng.integers(0, 50256, size=(nb, S), dtype=np.int64)
+            row.append(model.pack([r for r in ids.tolist()]))
+        packed.append(row)
+    # queries: lengths U{4..32}; encoded sharded by rank, then ONE all-gather
+    qrng = np.random.default_rng(7)
+    queries = [qrng.integers(0, 50256, size=int(qrng.integers(4, 33))).tolist() for _ in range(args.nq)]
+    per = (args.nq + world - 1) // world
+    mine = queries[rank * per: (rank + 1) * per]
+
+    corpus = torch.empty((n_steps * args.chunk, d), dtype=score_dt, device=dev)   # this rank's shard, stays in HBM
+    emb32 = torch.empty((args.chunk, d), dtype=torch.float32, device=dev)
+
+    def encode_queries():
+        local_q = model.encode_ids(mine, normalize=True) if mine else torch.empty((0, d), device=dev)
+        if not dist_on:
+            return local_q
+        pad = torch.zeros((per, d), dtype=torch.float32, device=dev)
+        pad[: local_q.shape[0]] = local_q
+        allq = torch.empty((world * per, d), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allq, pad)
+        return allq[: args.nq]
+
+    def step(i, q, run):
+        base = i * args.chunk
+        o = 0
+        for pb in packed[i]:
+            model.encode_packed(pb, mode="weightedmean", normalize=True, out=emb32[o: o + pb.B])
+            o += pb.B
+        rows = corpus[base: base + args.chunk]
+        if score_dt == torch.bfloat16:
+            ctx._chk(ctx.lib.sgpt_f32_to_bf16(ctx.handle, emb32.data_ptr(), emb32.numel(), rows.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream), "sgpt_f32_to_bf16")
+        else:
+            rows.copy_(emb32)
+        return ctx.score_topk(q, rows, k1, idx_base=rank * n_steps * args.chunk + base, run=run, dtype=score_dt)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    q = encode_queries()
+    q = ctx._operand(q, score_dt)
+    run = None
+    for i in range(args.warmup):
+        run = step(i, q, run)
+    sync()
+    ctx.prof_read(reset=True)
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        run = step(i, q, run)
+    if dist_on:   # exchange step: per-rank top-(k+1) lists -> every rank, merge
+        gv = torch.empty((world,) + tuple(run[0].shape), dtype=torch.float32, device=dev)
+        gi = torch.empty((world,) + tuple(run[1].shape), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gv, run[0])
+        dist.all_gather_into_tensor(gi, run[1])
+        fv, fi = ctx.topk_merge(gv.permute(1, 0, 2).reshape(args.nq, -1), gi.permute(1, 0, 2).reshape(args.nq, -1), k1)
+    else:
+        fv, fi = run[0], run[1]
+    sync()
+    dt = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    n_launch, gemm_ms, gemm_flops = ctx.prof_read(reset=True)
+    if dist_on:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(fv[:, : args.topk]).all() and (fi[:, : args.topk] >= 0).all()
+
+    sentences = world * args.steps * args.chunk
+    sent_per_s = sentences / dt
+
+    # ---- queries/sec: scoring + top-k only, against this job's encoded corpus and a 1M-doc synthetic shard ----
+    def time_search(cmat, reps=5):
+        ctx.score_topk(q, cmat, k1, dtype=score_dt)
+        sync()
+        t = time.perf_counter()
+        for _ in range(reps):
+            ctx.score_topk(q, cmat, k1, dtype=score_dt)
+        sync()
+        return args.nq * reps / (time.perf_counter() - t)
+
+    qps_job = time_search(corpus[args.warmup * args.chunk:])
+    qps_1m = None
+    if not args.no_1m:
+        n1m = 1_000_000 // world                           # 1M-doc corpus sharded over the ranks
+        big = torch.empty((n1m, d), dtype=score_dt, device=dev)
+        blk = corpus[args.warmup * args.chunk:]
+        for s0 in range(0, n1m, blk.shape[0]):             # tile the encoded (anisotropic) embeddings
+            e0 = min(n1m, s0 + blk.shape[0])
+            big[s0:e0] = blk[: e0 - s0]
+        qps_1m = time_search(big, reps=3)
+        if dist_on:
+            tq = torch.tensor([qps_1m], dtype=torch.float64, device=dev)
+            dist.all_reduce(tq, op=dist.ReduceOp.MIN)
+            qps_1m = float(tq.item())
+        del big
+
+    if rank != 0:
+        if dist_on:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (the MFMA GEMM) from live hipEvent timings ----
+    gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "gemm_kernel<bf16,128x128x64>", "achieved": round(gemm_tflops, 2),
+                "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
+                "frac": round(gemm_tflops / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
+                "traffic": None, "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(n_launch, 1), 5),
+                "gemm_share_of_step": round(gemm_ms * 1e-3 / dt, 4),
+                "end_to_end_frac_of_mfma_roofline": round(
+                    sent_per_s / world * flops_per_sentence(S) / (PEAK_BF16_TFLOPS * 1e12), 4)}
+
+    # ---- CPU baseline: the numpy oracle (a port of the reference CPU path) on a bounded sample ----
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import sgpt_oracle as O      # checker / reported baseline only, never the measured path
+        ocfg = O.NeoConfig(**SGPT_125M)
+        ow = O.synth_weights(ocfg, seed=1)
+        sample = [r for r in np.random.default_rng(5).integers(0, 50256, size=(args.cpu_sample, S)).tolist()]
+        O.encode(ow, ocfg, sample[:4], batch_size=4)                    # warm-up
+        t = time.perf_counter()
+        ce = O.encode(ow, ocfg, sample, batch_size=16, normalize_embeddings=True)
+        cdt = time.perf_counter() - t
+        got = model.encode_ids(sample, normalize=True).cpu().numpy()
+        cpu = {"value": round(args.cpu_sample / cdt, 2), "unit": "sentences/s", "cores": os.cpu_count(),
+               "kind": "port", "sample": f"{args.cpu_sample} sentences x {S} tokens, numpy fp32 oracle "
+                                         f"(oracle/sgpt_oracle.py), encode+pool+normalise, {cdt:.1f}s",
+               "gpu_vs_cpu_max_abs_emb_diff": float(np.abs(got - ce).max())}
+
+    out = {"metric": "encoded sentences/sec (SGPT-125M, seq_len 128, encode + weighted-mean pool + cosine top-10 "
+                     "chunk loop)",
+           "value": round(sent_per_s, 1), "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "BASELINE configs[1]: SGPT-125M-shape random-init weights, bf16 MFMA, "
+                                  f"{args.steps * args.chunk} docs/GPU x seq_len {S}, nq={args.nq}, cosine top-{args.topk} "
+                                  "(top_k+1 kept), corpus rows bf16 in HBM",
+                      "docs_per_step": args.chunk, "docs_per_encode_call": args.call, "seq_len": S, "nq": args.nq,
+                      "top_k": args.topk, "parallelism": f"corpus-shard x{world}"},
+           "queries_per_sec_at_job_corpus": round(qps_job, 1),
+           "job_corpus_docs_per_gpu": args.steps * args.chunk,
+           "queries_per_sec_at_1M_corpus": None if qps_1m is None else round(qps_1m, 1),
+           "roofline": roofline, "cpu_baseline": cpu}
+    print(json.dumps(out))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

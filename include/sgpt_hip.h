@@ -1,0 +1,189 @@
+/*
+ * sgpt_hip.h -- C ABI of the MI355X (gfx950) SGPT bi-encoder retrieval hot path.
+ *
+ * The reference (Muennighoff/sgpt) has NO native layer: the hot path is Python that
+ * reaches implicit PyTorch/cuBLAS kernels through HuggingFace `AutoModel`, `torch.mm`
+ * and `torch.topk`.  Each entry point below names the reference call site whose device
+ * work it replaces (paths relative to /root/reference; HF: = huggingface transformers,
+ * the un-vendored dependency that holds the transformer arithmetic).  The Python side
+ * (sgpt_amd/_lib.py) binds these with ctypes; INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer marked "device" is a HIP device pointer owned by the caller
+ *     (e.g. torch.Tensor.data_ptr()); the library allocates only its own workspace and
+ *     its packed copy of the weights, both tied to the ctx / model handle;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     legacy default stream) and performs no hidden device synchronisation, except
+ *     sgpt_ctx_create / sgpt_model_load / *_destroy / *_free and workspace growth;
+ *   - no C++ exception crosses the ABI: functions return SGPT_OK (0) or a negative
+ *     sgpt_status; sgpt_last_error(ctx) returns a message for the last failure on ctx;
+ *   - a ctx is bound to one HIP device and is re-entrant per ctx, not thread-safe
+ *     (the reference runs one single-threaded Python process per GPU,
+ *     sentence_transformers/SentenceTransformer.py:275-283).
+ */
+#ifndef SGPT_HIP_H
+#define SGPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGPT_ABI_VERSION 1
+
+typedef int sgpt_status;
+#define SGPT_OK 0
+#define SGPT_ERR_INVALID (-1)     /* bad argument / unsupported shape */
+#define SGPT_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define SGPT_ERR_MISSING (-3)     /* a required weight tensor was not supplied */
+#define SGPT_ERR_OOM (-4)
+
+typedef struct sgpt_ctx sgpt_ctx;
+typedef struct sgpt_model sgpt_model;
+
+enum { SGPT_F32 = 0, SGPT_BF16 = 1 };                      /* element types */
+enum { SGPT_ARCH_GPTNEO = 0 };                             /* GPT-J / BLOOM: later rounds */
+enum { SGPT_POOL_WEIGHTEDMEAN = 0, SGPT_POOL_MEAN = 1, SGPT_POOL_LASTTOKEN = 2 };
+enum { SGPT_COS = 0, SGPT_DOT = 1 };
+
+/* Model hyper-parameters = the fields of HF GPTNeoConfig the forward pass reads
+ * (HF:gpt_neo/configuration_gpt_neo.py; values of the SGPT checkpoints in SURVEY.md 8). */
+typedef struct {
+    int32_t arch;            /* SGPT_ARCH_GPTNEO */
+    int32_t n_layers;
+    int32_t d_model;         /* multiple of 128 */
+    int32_t n_heads;         /* d_model / n_heads in {64, 128} */
+    int32_t d_ffn;           /* multiple of 128 */
+    int32_t vocab;
+    int32_t max_pos;
+    int32_t window;          /* GPT-Neo local-attention window (256) */
+    float ln_eps;            /* 1e-5 */
+    float attn_scale;        /* 1.0 for GPT-Neo (no 1/sqrt(dh), HF:gpt_neo:110) */
+    int32_t compute_dtype;   /* SGPT_BF16: bf16 MFMA operands, fp32 accumulate/residual/LN/softmax;
+                                SGPT_F32 : exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the parity gate */
+    const uint8_t* layer_is_local;  /* host, [n_layers]: 1 = sliding-window layer (HF:gpt_neo:66) */
+} sgpt_model_desc;
+
+/* One named fp32 weight tensor under its HF state-dict name
+ * ("wte.weight", "h.0.attn.attention.q_proj.weight", ..., "ln_f.bias"). */
+typedef struct {
+    const char* name;
+    const float* ptr;        /* device, contiguous fp32 */
+    int64_t numel;
+} sgpt_tensor_view;
+
+/* -- lifetime ------------------------------------------------------------------------- */
+int sgpt_abi_version(void);
+sgpt_status sgpt_ctx_create(int hip_device, sgpt_ctx** out);
+void sgpt_ctx_destroy(sgpt_ctx* ctx);
+const char* sgpt_last_error(const sgpt_ctx* ctx);
+
+/* Replaces AutoModel.from_pretrained(...).to(device) (biencoder/beir/beir_dense_retriever.py:123;
+ * sentence_transformers/models/Transformer.py:38).  Copies / packs the weights into
+ * library-owned device memory (fused [3d,d] QKV; bf16 rounding (RNE) of the six matmul
+ * weights per block when compute_dtype == SGPT_BF16); the caller may free its tensors after
+ * return. */
+sgpt_status sgpt_model_load(sgpt_ctx* ctx, const sgpt_model_desc* desc,
+                            const sgpt_tensor_view* tensors, size_t n_tensors, sgpt_model** out);
+void sgpt_model_free(sgpt_model* model);
+
+/* -- a2+a3+a4: forward + pool --------------------------------------------------------- */
+/* Replaces, in ONE call and with no hidden-state D2H:
+ *   AutoModel(**tokens, output_hidden_states=True)   beir_dense_retriever.py:204-205 / Transformer.py:72
+ *     = HF GPTNeoModel.forward                       HF:gpt_neo/modeling_gpt_neo.py:398-505
+ *   hidden_state = all_hidden_states[layeridx]       beir_dense_retriever.py:233
+ *   weightedmean / mean / lasttoken pooling          beir_dense_retriever.py:238-282; Pooling.py:99-125
+ *   optional F.normalize                             SentenceTransformer.py:248-249
+ *
+ * Token layout (varlen, no FLOPs on padding): sequence b owns rows
+ * [seq_off[b], seq_off[b+1]) of the packed token axis; its seq_len[b] real tokens come
+ * first.  seq_off[] are multiples of 16, seq_off[B] <= T_pad, T_pad is a multiple of 128
+ * (rows past seq_off[B] are filler: computed by the row-wise kernels, never attended to).
+ *   ids      device int32[T_pad]  token ids (filler rows: any valid id)
+ *   pos      device int32[T_pad]  absolute position id = pad_left[b] + t  (HF:gpt_neo:451 uses
+ *                                 the PADDED index arange(S); filler rows: 0)
+ *   pad_left device int32[B]      left-padding of the reference batch (0 for right-padded
+ *                                 GPT-2 tokenizers); the pooling weight of token t is
+ *                                 pad_left[b] + t + 1 (Pooling.py:104-112, padded index)
+ *   n_layers_run  number of blocks to run (n_layers for layeridx=-1)
+ *   apply_final_ln  1 = ln_f (hidden_states[-1]); 0 = raw residual (hidden_states[i<L])
+ *   out      device fp32[B, d_model]
+ *   hidden_out  optional device fp32[T_pad, d_model]: the selected hidden state per token
+ */
+sgpt_status sgpt_encode(sgpt_model* model, const int32_t* ids, const int32_t* pos,
+                        const int32_t* seq_off, const int32_t* seq_len, const int32_t* pad_left,
+                        int32_t B, int32_t T_pad, int32_t max_alloc_len,
+                        int32_t pool_mode, int32_t n_layers_run, int32_t apply_final_ln,
+                        int32_t normalize, float* out, float* hidden_out, void* stream);
+
+/* Stand-alone pooling over caller-supplied hidden states (USEB layer sweeps, parity tests).
+ * Replaces Pooling.forward (sentence_transformers/models/Pooling.py:99-125,129-164) and
+ * CustomEmbedder.embed_batcher's pooling branch (beir_dense_retriever.py:238-282).
+ *   hidden device [B,S,d] (fp32 or bf16), mask device int32[B,S] (0/1, any padding side);
+ *   weights follow the padded index t+1; weight sum clamped at 1e-9 (Pooling.py:122). */
+sgpt_status sgpt_pool(sgpt_ctx* ctx, const void* hidden, int32_t hidden_dtype, const int32_t* mask,
+                      int32_t B, int32_t S, int32_t d, int32_t pool_mode, float* out, void* stream);
+
+/* Row-wise x / max(||x||_2, 1e-12): torch.nn.functional.normalize(p=2, dim=1)
+ * (sentence_transformers/util.py:41-42, 66-70).  out may alias in when out_dtype == SGPT_F32. */
+sgpt_status sgpt_l2_normalize(sgpt_ctx* ctx, const float* in, int64_t n, int32_t d,
+                              void* out, int32_t out_dtype, void* stream);
+
+/* fp32 -> bf16 (RNE) element-wise; used to keep a corpus shard in HBM as bf16. */
+sgpt_status sgpt_f32_to_bf16(sgpt_ctx* ctx, const float* in, int64_t numel, void* out, void* stream);
+
+/* -- a7: scoring ---------------------------------------------------------------------- */
+/* Replaces cos_sim / dot_score = torch.mm(a, b.T) (sentence_transformers/util.py:24-63;
+ * beir.util, imported at custommodels/exact_search.py:9): out[i][j] = <a_i, b_j>, NaN kept.
+ * For cosine the caller normalises first (sgpt_l2_normalize), exactly as util.py:41-43.
+ *   a device [na,d], b device [nb,d], both of `dtype` (fp32: exact fp32 MFMA; bf16: bf16 MFMA,
+ *   fp32 accumulate); d multiple of 4 (fp32) / 8 (bf16); out device fp32[na, ldo], ldo >= nb, ldo%4==0. */
+sgpt_status sgpt_scores(sgpt_ctx* ctx, const void* a, const void* b, int32_t dtype,
+                        int64_t na, int64_t nb, int32_t d, float* out, int64_t ldo, void* stream);
+
+/* -- a7+a8: fused chunked score + top-k ------------------------------------------------ */
+/* Replaces the body of the corpus-chunk loop of DenseRetrievalExactSearch.search
+ * (custommodels/exact_search.py:96-108): scores = q . corpus^T ; scores[isnan] = -1 ;
+ * topk(min(k, n)) -- and, when run_val/run_idx already hold `n_run` entries per query from
+ * earlier chunks, the heapq.nlargest merge of :121-132 (the set of the k best of old+new).
+ *   q       device [nq,d] of `dtype`;  corpus device [N,d] of `dtype`
+ *   idx_base  global index of corpus row 0 (rank offset when the corpus is sharded)
+ *   run_val device fp32[nq,k], run_idx device int64[nq,k]: in = running best (first n_run
+ *           columns valid), out = new running best, sorted by descending score
+ *           (ties: ascending index); unused tail = (-inf, -1).
+ *   returns through *n_out (host) the number of valid columns = min(k, n_run + N). */
+sgpt_status sgpt_score_topk(sgpt_ctx* ctx, const void* q, const void* corpus, int32_t dtype,
+                            int32_t nq, int64_t N, int32_t d, int32_t k, int64_t idx_base,
+                            float* run_val, int64_t* run_idx, int32_t n_run, int32_t* n_out,
+                            void* stream);
+
+/* k best of m candidate (score, index) pairs per query: the cross-rank / cross-chunk merge
+ * (exact_search.py:121-132 heapq.nlargest).  Candidates with idx < 0 are ignored, and so is
+ * the candidate whose idx == exclude_idx[q] (the `corpus_id != query_id` rule of :118;
+ * exclude_idx may be NULL).
+ *   val device fp32[nq,m], idx device int64[nq,m] -> out_val fp32[nq,k], out_idx int64[nq,k]
+ *   (sorted descending; tail (-inf,-1)). */
+sgpt_status sgpt_topk_merge(sgpt_ctx* ctx, const float* val, const int64_t* idx, int32_t nq,
+                            int32_t m, int32_t k, const int64_t* exclude_idx,
+                            float* out_val, int64_t* out_idx, void* stream);
+
+/* Plain top-k over a materialised score matrix: torch.topk(scores, k, dim=1)
+ * (exact_search.py:102-108; util.semantic_search util.py:241).  NaN -> -1 first (:99). */
+sgpt_status sgpt_topk(sgpt_ctx* ctx, const float* scores, int32_t nq, int64_t n, int64_t ld,
+                      int32_t k, int64_t idx_base, float* out_val, int64_t* out_idx, void* stream);
+
+/* -- measurement ----------------------------------------------------------------------- */
+/* bench.py's live roofline: when enabled, every GEMM launched by sgpt_encode /
+ * sgpt_scores / sgpt_score_topk is bracketed by hipEvents on the launch stream;
+ * sgpt_prof_read synchronises and returns launches, summed milliseconds and summed
+ * algorithmic FLOPs (2*M*N*K of the un-padded problem) since the last reset. */
+sgpt_status sgpt_prof_enable(sgpt_ctx* ctx, int32_t on);
+sgpt_status sgpt_prof_read(sgpt_ctx* ctx, int64_t* launches, double* ms, double* flops, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGPT_HIP_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI in include/sgpt_hip.h (libsgpt_hip.so, built in-tree by
+sgpt_amd/build.py).  There is NO fallback: if the library is missing or fails to load,
+every product entry point raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsgpt_hip.so")
+
+SGPT_F32, SGPT_BF16 = 0, 1
+SGPT_ARCH_GPTNEO = 0
+POOL_MODES = {"weightedmean": 0, "mean": 1, "lasttoken": 2}
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("arch", C.c_int32), ("n_layers", C.c_int32), ("d_model", C.c_int32), ("n_heads", C.c_int32),
+                ("d_ffn", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("window", C.c_int32),
+                ("ln_eps", C.c_float), ("attn_scale", C.c_float), ("compute_dtype", C.c_int32),
+                ("layer_is_local", C.POINTER(C.c_uint8))]
+
+
+class TensorView(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p), ("numel", C.c_int64)]
+
+
+# name -> (restype, argtypes); mirrors include/sgpt_hip.h one to one
+SIGNATURES = {
+    "sgpt_abi_version": (C.c_int, []),
+    "sgpt_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "sgpt_ctx_destroy": (None, [C.c_void_p]),
+    "sgpt_last_error": (C.c_char_p, [C.c_void_p]),
+    "sgpt_model_load": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.POINTER(TensorView), C.c_size_t,
+                                  C.POINTER(C.c_void_p)]),
+    "sgpt_model_free": (None, [C.c_void_p]),
+    "sgpt_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgpt_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                            C.c_int32, C.c_void_p, C.c_void_p]),
+    "sgpt_l2_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sgpt_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sgpt_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+                              C.c_void_p, C.c_int64, C.c_void_p]),
+    "sgpt_score_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                                  C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                                  C.c_void_p]),
+    "sgpt_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgpt_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64,
+                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgpt_prof_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "sgpt_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.c_int32]),
+}
+
+_lib = None
+
+
+class SgptHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libsgpt_hip.so and declare every prototype.  Raises (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SgptHipError(f"{LIB_PATH} is missing: build it with `python -m sgpt_amd.build` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sgpt_abi_version() != 1:
+        raise SgptHipError("libsgpt_hip.so ABI version mismatch: rebuild with `python -m sgpt_amd.build --force`")
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, status, what=""):
+    if status == 0:
+        return
+    msg = load().sgpt_last_error(ctx_handle)
+    msg = msg.decode() if msg else ""
+    if status == -1:
+        raise ValueError(f"{what}: {msg}")
+    raise SgptHipError(f"{what}: status {status}: {msg}")

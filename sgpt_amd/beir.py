@@ -1,0 +1,244 @@
+"""Drop-in adapters for biencoder/beir of the reference.
+
+  CustomEmbedder              <- biencoder/beir/beir_dense_retriever.py:106-348
+  DenseRetrievalExactSearch   <- biencoder/beir/custommodels/exact_search.py:21-134
+  SentenceBERTBOSEOS          <- biencoder/beir/custommodels/sentence_bert_asym.py:21-79
+
+Same constructor arguments, method names, input conventions, return types and error
+behaviour; the device work goes through the HIP layer (sgpt_amd.model / sgpt_amd.runtime)
+and embeddings never leave the GPU between encode and top-k."""
+import logging
+import os
+import pathlib
+import pickle
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .model import SGPTModel
+from .runtime import get_context
+from .tokenization import TextPipeline, load_tokenizer
+
+logger = logging.getLogger(__name__)
+
+SINGLE_LAYER_METHODS = ("mean", "weightedmean", "lasttoken")
+ALL_LAYER_METHODS = {"meanmean": "mean", "lasttokenmean": "lasttoken"}
+
+
+class CustomEmbedder:
+    """Raw-HF-path embedder of the reference (beir_dense_retriever.py:106-348): per-text
+    tokenise/truncate/specb brackets on the host, then forward + pooling on the GPU in one C call
+    (the reference copies all L+1 hidden states to the CPU and pools there, :221-304)."""
+
+    def __init__(self, model_name="EleutherAI/gpt-neo-1.3B", batch_size=250, device="cuda:0", save_emb=False,
+                 reinit=False, layeridx=-1, method="mean", dataset="scifact", specb=False, maxseqlen=None,
+                 model: Optional[SGPTModel] = None, tokenizer=None, dtype="bf16", **kwargs):
+        if reinit:
+            raise NotImplementedError("reinit (random re-initialisation ablation) is not part of the hot path")
+        self.device = torch.device(device)
+        self.model = model if model is not None else SGPTModel.from_pretrained(model_name, device=device, dtype=dtype)
+        self.tokenizer = tokenizer if tokenizer is not None else load_tokenizer(model_name)
+        self.max_token_len = maxseqlen if maxseqlen else self.model.cfg.max_position_embeddings   # :128
+        self.pipe = TextPipeline(self.tokenizer, self.max_token_len, specb=specb)
+        self.max_token_len = self.pipe.max_token_len
+        self.batch_size = batch_size
+        self.save_emb = save_emb
+        self.layeridx = layeridx
+        self.method = method
+        self.specb = specb
+        if method not in SINGLE_LAYER_METHODS and method not in ALL_LAYER_METHODS:
+            raise ValueError(f"unknown method {method}")   # 'poolout' needs a pooler GPT models do not have
+        self.base_path = f"embeddings/{model_name.split('/')[-1]}/{self.method}/{dataset}"     # :155
+        if save_emb:
+            pathlib.Path(self.base_path).parent.mkdir(parents=True, exist_ok=True)
+
+    # -- device leg --------------------------------------------------------------------------
+    def embed_device(self, sentences: List[str], is_query: bool, normalize: bool = False) -> torch.Tensor:
+        before = (self.pipe.docs_truncated, self.pipe.toks_truncated)
+        seqs = self.pipe.batch(sentences, is_query)
+        if self.pipe.docs_truncated > before[0]:
+            logging.warning(f"Truncated {self.pipe.docs_truncated - before[0]} out of {len(sentences)} documents "
+                            f"by {self.pipe.toks_truncated - before[1]} tokens.")                # :216-219
+        L = self.model.cfg.num_layers
+        if abs(self.layeridx) > L + 1:
+            raise ValueError(f"Layer Idx {self.layeridx} is larger than the {L + 1} hidden states")   # :234-235
+        if self.method in SINGLE_LAYER_METHODS:
+            return self.model.encode_ids(seqs, mode=self.method, normalize=normalize, layer_idx=self.layeridx)
+        # meanmean / lasttokenmean (:243-257, 284-301): average of the per-layer pooled vectors over all
+        # L+1 hidden states (equal token counts per layer make the two formulations identical)
+        acc = None
+        for li in range(L + 1):
+            e = self.model.encode_ids(seqs, mode=ALL_LAYER_METHODS[self.method], layer_idx=li)
+            acc = e if acc is None else acc.add_(e)
+        acc.div_(L + 1)
+        return get_context(self.model.device).l2_normalize(acc) if normalize else acc
+
+    # -- reference surface -------------------------------------------------------------------
+    def embed_batcher(self, texts: List[Tuple[int, str]], is_query, out_name=None, **kwargs) -> Dict:
+        ids, sentences = zip(*texts)
+        emb = self.embed_device(list(sentences), is_query).cpu().numpy()
+        all_embeddings = {i: e for i, e in zip(ids, emb)}
+        assert len(texts) == len(all_embeddings)
+        if self.save_emb:
+            pickle.dump(all_embeddings, open(out_name, "wb"))                                   # :311-312
+        return all_embeddings
+
+    def encode_queries(self, queries: List[Tuple[str, str]], batch_size: int = None, **kwargs) -> np.ndarray:
+        path = f"{self.base_path}_queries.pickle"
+        if os.path.exists(path):
+            embeddings = pickle.load(open(path, "rb"))                                          # :319-321
+        else:
+            embeddings = self.embed_batcher(texts=queries, out_name=path, is_query=True, **kwargs)
+        embeddings = np.array([embeddings[i] for (i, _) in queries])
+        logger.info(f"Produced embeddings of shape {embeddings.shape}")
+        return embeddings
+
+    @staticmethod
+    def _corpus_texts(corpus):
+        # (title + " " + text).strip() (:341); docs without a title keep their text (appendix A.1 latent bug not copied)
+        return [(i, (d["title"] + " " + d["text"]).strip() if "title" in d else d["text"].strip()) for (i, d) in corpus]
+
+    def encode_corpus(self, corpus: List[Tuple[str, Dict[str, str]]], batch_size: int = None, batch_num="",
+                      **kwargs) -> np.ndarray:
+        path = f"{self.base_path}_corpus{batch_num}.pickle"
+        if os.path.exists(path):
+            embeddings = pickle.load(open(path, "rb"))                                          # :336-338
+        else:
+            embeddings = self.embed_batcher(texts=self._corpus_texts(corpus), out_name=path, is_query=False, **kwargs)
+        embeddings = np.array([embeddings[i] for (i, _) in corpus])
+        logger.info(f"Produced embeddings of shape {embeddings.shape}")
+        return embeddings
+
+    # device-resident variants used by DenseRetrievalExactSearch below (no D2H of embeddings)
+    def encode_queries_device(self, queries, normalize=False):
+        if os.path.exists(f"{self.base_path}_queries.pickle") or self.save_emb:
+            return torch.from_numpy(self.encode_queries(queries)).to(self.model.device)
+        return self.embed_device([q for (_, q) in queries], True, normalize=False)
+
+    def encode_corpus_device(self, corpus, batch_num="", normalize=False):
+        if os.path.exists(f"{self.base_path}_corpus{batch_num}.pickle") or self.save_emb:
+            return torch.from_numpy(self.encode_corpus(corpus, batch_num=batch_num)).to(self.model.device)
+        return self.embed_device([t for (_, t) in self._corpus_texts(corpus)], False, normalize=False)
+
+
+class DenseRetrievalExactSearch:
+    """custommodels/exact_search.py:21-134 with the scoring / top-k / chunk merge on the GPU.
+
+    Result contract kept bit-for-bit in structure: Dict[qid, Dict[doc_id, float]] holding, per
+    query, the (k+1) best of {per-chunk top-(k+1) minus corpus_id == query_id} (:102-132)."""
+
+    def __init__(self, model, batch_size: int = 128, corpus_chunk_size: int = 50000, score_dtype=torch.float32,
+                 **kwargs):
+        self.model = model
+        self.batch_size = batch_size
+        self.score_function_desc = {"cos_sim": "Cosine Similarity", "dot": "Dot Product"}
+        self.corpus_chunk_size = corpus_chunk_size
+        self.show_progress_bar = True
+        self.convert_to_tensor = True
+        self.score_dtype = score_dtype          # torch.float32: exact-fp32 MFMA; torch.bfloat16: bf16 corpus in HBM
+        self.results = {}
+
+    def _to_dev(self, ctx, x):
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x))
+        return x.to(device=ctx.device, dtype=torch.float32)
+
+    def search(self, corpus: Dict[str, Dict[str, str]], queries: Dict[str, str], top_k: int, score_function: str,
+               return_sorted: bool = False, **kwargs) -> Dict[str, Dict[str, float]]:
+        if score_function not in self.score_function_desc:
+            raise ValueError(
+                "score function: {} must be either (cos_sim) for cosine similarity or (dot) for dot product".format(
+                    score_function))
+        ctx = get_context(getattr(getattr(self.model, "model", None), "device", None))
+        logger.info("Encoding Queries...")
+        query_ids = list(queries.keys())
+        self.results = {qid: {} for qid in query_ids}
+        qlist = [(qid, queries[qid]) for qid in queries]
+        if hasattr(self.model, "encode_queries_device"):
+            q_emb = self.model.encode_queries_device(qlist)
+        else:
+            q_emb = self.model.encode_queries(qlist, batch_size=self.batch_size,
+                                              show_progress_bar=self.show_progress_bar,
+                                              convert_to_tensor=self.convert_to_tensor)
+        q_emb = self._to_dev(ctx, q_emb)
+        if score_function == "cos_sim":
+            q_emb = ctx.l2_normalize(q_emb)                                       # util.py:41 (once, not per chunk)
+
+        logger.info("Sorting Corpus by document length (Longest first)...")
+        corpus_ids = sorted(corpus, key=lambda k: len(corpus[k].get("title", "") + corpus[k].get("text", "")),
+                            reverse=True)                                         # :66-70
+        clist = [(cid, corpus[cid]) for cid in corpus_ids]
+        pos_of = {cid: i for i, cid in enumerate(corpus_ids)}
+        # corpus_id != query_id (:118) as an index: position of the doc carrying the query's id, or -1
+        self_idx = torch.tensor([pos_of.get(qid, -1) for qid in query_ids], dtype=torch.int64, device=ctx.device)
+
+        nq = len(query_ids)
+        run_val = run_idx = None
+        itr = range(0, len(clist), self.corpus_chunk_size)
+        for batch_num, start in enumerate(itr):
+            logger.info("Encoding Batch {}/{}...".format(batch_num + 1, len(itr)))
+            end = min(start + self.corpus_chunk_size, len(clist))
+            if hasattr(self.model, "encode_corpus_device"):
+                sub = self.model.encode_corpus_device(clist[start:end], batch_num=batch_num)
+            else:
+                sub = self.model.encode_corpus(clist[start:end], batch_size=self.batch_size,
+                                               show_progress_bar=self.show_progress_bar,
+                                               convert_to_tensor=self.convert_to_tensor, batch_num=batch_num)
+            sub = self._to_dev(ctx, sub)
+            if score_function == "cos_sim":
+                sub = ctx.l2_normalize(sub, out_dtype=self.score_dtype)           # util.py:42
+            kk = min(top_k + 1, end - start)                                      # :104
+            val, idx, _ = ctx.score_topk(q_emb, sub, kk, idx_base=start, dtype=self.score_dtype)   # :96-108 (NaN -> -1)
+            if run_val is None:
+                cand_v, cand_i = val, idx
+            else:
+                cand_v, cand_i = torch.cat([run_val, val], dim=1), torch.cat([run_idx, idx], dim=1)
+            keep = min(top_k + 1, cand_v.shape[1])                                # :126
+            run_val, run_idx = ctx.topk_merge(cand_v, cand_i, keep, exclude_idx=self_idx)          # :118,121-132
+
+        if run_val is not None:
+            vals, idxs = run_val.cpu().numpy(), run_idx.cpu().numpy()
+            for qi, qid in enumerate(query_ids):
+                row_i, row_v = idxs[qi], vals[qi]
+                ok = row_i >= 0
+                self.results[qid] = {corpus_ids[j]: float(s) for j, s in zip(row_i[ok].tolist(), row_v[ok].tolist())}
+        return self.results
+
+
+class SentenceBERTBOSEOS:
+    """custommodels/sentence_bert_asym.py:21-79: the `--usest --specb` adapter.  The reference
+    prefixes "[SOS]" / "{SOS}" marker tokens that Transformer.tokenize_bos_eos then swaps for
+    the bracket ids and closes with the EOS bracket (Transformer.py:131-153); here the brackets
+    are added directly on the id lists (same ids, no marker round trip).  Inputs follow upstream
+    BEIR's DRES: List[str] queries, List[{"title","text"}] corpus."""
+
+    def __init__(self, model_path=None, sep: str = " ", speca=False, specb=False, model: Optional[SGPTModel] = None,
+                 tokenizer=None, max_seq_length: int = 300, method: str = "weightedmean", dtype="bf16",
+                 device="cuda:0", **kwargs):
+        if speca:
+            raise NotImplementedError("speca adds new vocabulary rows ([SOS]/[EOS]); only specb is on the hot path")
+        self.sep = sep
+        self.specb = specb
+        if not specb:
+            raise NameError("name 'sentences' is not defined")   # the reference fails the same way (appendix A.2)
+        self.model = model if model is not None else SGPTModel.from_pretrained(model_path, device=device, dtype=dtype)
+        tok = tokenizer if tokenizer is not None else load_tokenizer(model_path)
+        self.pipe = TextPipeline(tok, max_seq_length, specb=True)      # max_length = max_seq_length - 2 (Transformer.py:135)
+        self.method = method
+
+    def _encode(self, texts, is_query, convert_to_tensor=False, normalize_embeddings=False, **kwargs):
+        seqs = self.pipe.batch([str(t).strip() for t in texts], is_query)
+        emb = self.model.encode_ids(seqs, mode=self.method, normalize=normalize_embeddings)
+        return emb if convert_to_tensor else emb.cpu().numpy()
+
+    def encode_queries(self, queries: List[str], batch_size: int = 16, **kwargs):
+        queries = [q[1] if isinstance(q, tuple) else q for q in queries]   # custom DRES passes (id, text)
+        return self._encode(queries, True, **kwargs)
+
+    def encode_corpus(self, corpus: List[Dict[str, str]], batch_size: int = 8, **kwargs):
+        corpus = [c[1] if isinstance(c, tuple) else c for c in corpus]
+        kwargs.pop("batch_num", None)
+        sentences = [(doc["title"] + self.sep + doc["text"]).strip() if "title" in doc else doc["text"].strip()
+                     for doc in corpus]
+        return self._encode(sentences, False, **kwargs)

@@ -1,0 +1,456 @@
+// C ABI (include/sgpt_hip.h): context, packed weights, forward orchestration, scorer.
+// Host-side C++ only -- every device op is one of the hand-written kernels in this directory.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/sgpt_hip.h"
+#include "common.h"
+
+struct sgpt_ctx {
+    int device = 0;
+    std::string err;
+    // grow-only workspaces
+    void* ws = nullptr; size_t ws_bytes = 0;        // encoder activations
+    void* ws2 = nullptr; size_t ws2_bytes = 0;      // scorer: score chunk + ping-pong top-k
+    // GEMM profiling (bench.py roofline)
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    std::vector<double> ev_flops;
+    int64_t prof_launches = 0; double prof_ms = 0, prof_flops = 0;
+};
+
+struct LayerW {
+    void* w_qkv = nullptr;   // [3d, d]  (q rows, k rows, v rows)
+    void* w_o = nullptr;     // [d, d]
+    void* w_fc = nullptr;    // [ffn, d]
+    void* w_proj = nullptr;  // [d, ffn]
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *b_o, *b_fc, *b_proj;
+    int is_local = 0;
+};
+
+struct sgpt_model {
+    sgpt_ctx* ctx;
+    sgpt_model_desc d;
+    std::vector<LayerW> L;
+    float *wte = nullptr, *wpe = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+#define HIPC(ctx, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return SGPT_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+sgpt_status fail(sgpt_ctx* c, sgpt_status st, const std::string& m) {
+    if (c) c->err = m;
+    return st;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+sgpt_status ensure(sgpt_ctx* c, void** p, size_t* have, size_t need) {
+    if (*have >= need) return SGPT_OK;
+    if (*p) { HIPC(c, hipDeviceSynchronize()); HIPC(c, hipFree(*p)); *p = nullptr; *have = 0; }
+    need = align_up(need + (need >> 3), 1 << 20);
+    if (hipMalloc(p, need) != hipSuccess) { *p = nullptr; return fail(c, SGPT_ERR_OOM, "hipMalloc workspace failed"); }
+    HIPC(c, hipMemset(*p, 0, need));
+    *have = need;
+    return SGPT_OK;
+}
+
+struct Prof {  // brackets one GEMM launch with events when profiling is on
+    sgpt_ctx* c; hipStream_t s; bool on; size_t slot = 0;
+    Prof(sgpt_ctx* c_, hipStream_t s_, double flops) : c(c_), s(s_), on(c_->prof) {
+        if (!on) return;
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            c->ev_pool.emplace_back(a, b);
+            c->ev_flops.push_back(0);
+        }
+        slot = c->ev_used++;
+        c->ev_flops[slot] = flops;
+        hipEventRecord(c->ev_pool[slot].first, s);
+    }
+    ~Prof() { if (on) hipEventRecord(c->ev_pool[slot].second, s); }
+};
+
+void gemm(sgpt_ctx* c, int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
+    Prof p(c, s, 2.0 * (double)a.m_valid * a.N * a.K);
+    launch_gemm(dtype, epi, out_dtype, a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgpt_abi_version(void) { return SGPT_ABI_VERSION; }
+
+sgpt_status sgpt_ctx_create(int hip_device, sgpt_ctx** out) {
+    if (!out) return SGPT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || hip_device < 0 || hip_device >= n) return SGPT_ERR_HIP;
+    if (hipSetDevice(hip_device) != hipSuccess) return SGPT_ERR_HIP;
+    sgpt_ctx* c = new sgpt_ctx();
+    c->device = hip_device;
+    *out = c;
+    return SGPT_OK;
+}
+
+void sgpt_ctx_destroy(sgpt_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    if (c->ws) hipFree(c->ws);
+    if (c->ws2) hipFree(c->ws2);
+    for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete c;
+}
+
+const char* sgpt_last_error(const sgpt_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+sgpt_status sgpt_prof_enable(sgpt_ctx* c, int32_t on) {
+    if (!c) return SGPT_ERR_INVALID;
+    c->prof = on != 0;
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_prof_read(sgpt_ctx* c, int64_t* launches, double* ms, double* flops, int32_t reset) {
+    if (!c) return SGPT_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float t = 0;
+        HIPC(c, hipEventElapsedTime(&t, c->ev_pool[i].first, c->ev_pool[i].second));
+        c->prof_ms += t;
+        c->prof_flops += c->ev_flops[i];
+        c->prof_launches++;
+    }
+    c->ev_used = 0;
+    if (launches) *launches = c->prof_launches;
+    if (ms) *ms = c->prof_ms;
+    if (flops) *flops = c->prof_flops;
+    if (reset) { c->prof_launches = 0; c->prof_ms = 0; c->prof_flops = 0; }
+    return SGPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_tensor_view* tv, size_t nt,
+                            sgpt_model** out) {
+    if (!c || !d || !tv || !out) return SGPT_ERR_INVALID;
+    *out = nullptr;
+    HIPC(c, hipSetDevice(c->device));
+    if (d->arch != SGPT_ARCH_GPTNEO) return fail(c, SGPT_ERR_INVALID, "only SGPT_ARCH_GPTNEO is built in this round");
+    const int dm = d->d_model, ffn = d->d_ffn, H = d->n_heads;
+    if (dm % 128 || ffn % 128 || H <= 0 || dm % H) return fail(c, SGPT_ERR_INVALID, "d_model and d_ffn must be multiples of 128");
+    const int dh = dm / H;
+    if (d->compute_dtype == SGPT_BF16 && dh != 64 && dh != 128)
+        return fail(c, SGPT_ERR_INVALID, "bf16 attention supports head_dim 64 or 128");
+    if (dh > 256 || dh % 4) return fail(c, SGPT_ERR_INVALID, "head_dim must be <= 256 and a multiple of 4");
+    if (dm > 4096) return fail(c, SGPT_ERR_INVALID, "d_model > 4096 not supported");
+    if (d->compute_dtype != SGPT_BF16 && d->compute_dtype != SGPT_F32) return fail(c, SGPT_ERR_INVALID, "bad compute_dtype");
+
+    std::unordered_map<std::string, const sgpt_tensor_view*> byname;
+    for (size_t i = 0; i < nt; ++i) byname[tv[i].name] = &tv[i];
+    sgpt_model* m = new sgpt_model();
+    m->ctx = c;
+    m->d = *d;
+    m->d.layer_is_local = nullptr;
+    const bool bf = d->compute_dtype == SGPT_BF16;
+    const size_t esz = bf ? 2 : 4;
+    sgpt_status st = SGPT_OK;
+
+    auto find = [&](const std::string& name, int64_t numel) -> const float* {
+        auto it = byname.find(name);
+        if (it == byname.end()) { st = fail(c, SGPT_ERR_MISSING, "missing weight tensor: " + name); return nullptr; }
+        if (it->second->numel != numel) { st = fail(c, SGPT_ERR_INVALID, "wrong numel for " + name); return nullptr; }
+        return it->second->ptr;
+    };
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { st = fail(c, SGPT_ERR_OOM, "hipMalloc weights failed"); return nullptr; }
+        m->allocs.push_back(p);
+        return p;
+    };
+    auto copy_f32 = [&](const std::string& name, int64_t numel) -> float* {
+        const float* src = find(name, numel);
+        if (!src) return nullptr;
+        float* dst = (float*)dalloc(numel * 4);
+        if (!dst) return nullptr;
+        if (hipMemcpyAsync(dst, src, numel * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memcpy " + name);
+        return dst;
+    };
+    // matmul weight -> packed dtype at dst (element offset)
+    auto pack_w = [&](const std::string& name, int64_t numel, void* dst, int64_t off) {
+        const float* src = find(name, numel);
+        if (!src) return;
+        if (bf) launch_f32_to_bf16(src, numel, (bf16_t*)dst + off, 0);
+        else if (hipMemcpyAsync((float*)dst + off, src, numel * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess)
+            st = fail(c, SGPT_ERR_HIP, "memcpy " + name);
+    };
+
+    m->wte = copy_f32("wte.weight", (int64_t)d->vocab * dm);
+    m->wpe = copy_f32("wpe.weight", (int64_t)d->max_pos * dm);
+    m->lnf_g = copy_f32("ln_f.weight", dm);
+    m->lnf_b = copy_f32("ln_f.bias", dm);
+    m->L.resize(d->n_layers);
+    for (int i = 0; i < d->n_layers && st == SGPT_OK; ++i) {
+        const std::string p = "h." + std::to_string(i) + ".";
+        LayerW& l = m->L[i];
+        l.is_local = d->layer_is_local ? d->layer_is_local[i] : (i & 1);
+        l.ln1_g = copy_f32(p + "ln_1.weight", dm); l.ln1_b = copy_f32(p + "ln_1.bias", dm);
+        l.ln2_g = copy_f32(p + "ln_2.weight", dm); l.ln2_b = copy_f32(p + "ln_2.bias", dm);
+        l.b_o = copy_f32(p + "attn.attention.out_proj.bias", dm);
+        l.b_fc = copy_f32(p + "mlp.c_fc.bias", ffn);
+        l.b_proj = copy_f32(p + "mlp.c_proj.bias", dm);
+        l.w_qkv = dalloc((size_t)3 * dm * dm * esz);
+        l.w_o = dalloc((size_t)dm * dm * esz);
+        l.w_fc = dalloc((size_t)ffn * dm * esz);
+        l.w_proj = dalloc((size_t)dm * ffn * esz);
+        if (st != SGPT_OK) break;
+        pack_w(p + "attn.attention.q_proj.weight", (int64_t)dm * dm, l.w_qkv, 0);
+        pack_w(p + "attn.attention.k_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)dm * dm);
+        pack_w(p + "attn.attention.v_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)2 * dm * dm);
+        pack_w(p + "attn.attention.out_proj.weight", (int64_t)dm * dm, l.w_o, 0);
+        pack_w(p + "mlp.c_fc.weight", (int64_t)ffn * dm, l.w_fc, 0);
+        pack_w(p + "mlp.c_proj.weight", (int64_t)dm * ffn, l.w_proj, 0);
+    }
+    if (st == SGPT_OK && hipDeviceSynchronize() != hipSuccess) st = fail(c, SGPT_ERR_HIP, "sync after weight pack");
+    if (st != SGPT_OK) { sgpt_model_free(m); return st; }
+    *out = m;
+    return SGPT_OK;
+}
+
+void sgpt_model_free(sgpt_model* m) {
+    if (!m) return;
+    hipSetDevice(m->ctx->device);
+    hipDeviceSynchronize();
+    for (void* p : m->allocs) hipFree(p);
+    delete m;
+}
+
+// ------------------------------------------------------------------------------------------
+sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, const int32_t* seq_off,
+                        const int32_t* seq_len, const int32_t* pad_left, int32_t B, int32_t T, int32_t max_alloc,
+                        int32_t pool_mode, int32_t n_layers_run, int32_t apply_final_ln, int32_t normalize,
+                        float* out, float* hidden_out, void* stream) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (!ids || !pos || !seq_off || !seq_len || B <= 0 || T <= 0 || T % 128 || max_alloc <= 0 || max_alloc % 16)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad token layout (T_pad % 128, max_alloc_len % 16)");
+    if (n_layers_run < 0 || n_layers_run > m->d.n_layers) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: n_layers_run out of range");
+    if (pool_mode < 0 || pool_mode > 2) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad pool_mode");
+    if (max_alloc > 2048) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: sequence longer than 2048 tokens");
+    if (!out && !hidden_out) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: no output requested");
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int dm = m->d.d_model, ffn = m->d.d_ffn, H = m->d.n_heads, dh = dm / H;
+    const bool bf = m->d.compute_dtype == SGPT_BF16;
+    const int dt = bf ? SGPT_BF16 : SGPT_F32;
+    const size_t esz = bf ? 2 : 4;
+    const size_t SLACK = 64;  // rows of zeroed slack behind buffers the attention key tiles may over-read
+
+    // workspace carve (all offsets 256-B aligned)
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_x = carve((size_t)T * dm * 4);                        // residual stream fp32
+    const size_t o_a = carve((size_t)T * dm * esz);                      // LN output / attention ctx
+    const size_t o_qkv = carve(((size_t)T + SLACK) * 3 * dm * esz);      // bf16: [T][2d] qk + V^T [d][T]; fp32: [T][3d]
+    const size_t o_h = carve((size_t)T * ffn * esz);                     // MLP hidden
+    sgpt_status st = ensure(c, &c->ws, &c->ws_bytes, off);
+    if (st != SGPT_OK) return st;
+    char* base = (char*)c->ws;
+    float* x = (float*)(base + o_x);
+    void* a = base + o_a;
+    void* qkv = base + o_qkv;
+    void* h = base + o_h;
+    void* vt = bf ? (void*)((bf16_t*)qkv + ((size_t)T + SLACK) * 2 * dm) : nullptr;
+
+    launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, s);
+    for (int li = 0; li < n_layers_run; ++li) {
+        const LayerW& l = m->L[li];
+        launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
+        GemmArgs g{};
+        g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
+        AttnArgs at{};
+        at.seq_off = seq_off; at.B = B; at.H = H; at.dh = dh; at.window = l.is_local ? m->d.window : 0;
+        at.scale = m->d.attn_scale; at.max_alloc_len = max_alloc; at.ctx = a; at.ldo = dm;
+        if (bf) {
+            // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]
+            g.W = l.w_qkv; g.N = 2 * dm; g.out = qkv; g.ldo = 2 * dm;
+            gemm(c, dt, EPI_STORE, SGPT_BF16, g, s);
+            g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; g.N = dm; g.out = vt; g.ldo = T;
+            gemm(c, dt, EPI_VT, SGPT_BF16, g, s);
+            at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
+            launch_attn_bf16(at, s);
+        } else {
+            g.W = l.w_qkv; g.N = 3 * dm; g.out = qkv; g.ldo = 3 * dm;
+            gemm(c, dt, EPI_STORE, SGPT_F32, g, s);
+            at.q = qkv; at.k = (float*)qkv + dm; at.v = (float*)qkv + 2 * dm; at.ldq = 3 * dm;
+            launch_attn_f32(at, s);
+        }
+        // x += ctx . Wo^T + bo
+        g.W = l.w_o; g.N = dm; g.K = dm; g.ldw = dm; g.out = x; g.ldo = dm; g.bias = l.b_o; g.resid = x;
+        gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
+        // x += gelu_new(LN2(x) . W1^T + b1) . W2^T + b2
+        launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s);
+        g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
+        gemm(c, dt, EPI_BIAS_GELU, dt, g, s);
+        g.A = h; g.lda = ffn; g.W = l.w_proj; g.N = dm; g.K = ffn; g.ldw = ffn; g.out = x; g.ldo = dm;
+        g.bias = l.b_proj; g.resid = x;
+        gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
+    }
+    if (hidden_out) {
+        if (apply_final_ln) launch_layernorm(x, m->lnf_g, m->lnf_b, hidden_out, SGPT_F32, T, dm, m->d.ln_eps, s);
+        else HIPC(c, hipMemcpyAsync(hidden_out, x, (size_t)T * dm * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (out)
+        launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, apply_final_ln,
+                        pool_mode, normalize, out, s);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_pool(sgpt_ctx* c, const void* hidden, int32_t dtype, const int32_t* mask, int32_t B, int32_t S,
+                      int32_t d, int32_t mode, float* out, void* stream) {
+    if (!c || !hidden || !mask || !out || B <= 0 || S <= 0 || d <= 0 || d % 4 || mode < 0 || mode > 2)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_pool: bad arguments (d % 4 == 0 required)");
+    HIPC(c, hipSetDevice(c->device));
+    launch_pool(hidden, dtype, mask, B, S, d, mode, out, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_l2_normalize(sgpt_ctx* c, const float* in, int64_t n, int32_t d, void* out, int32_t out_dtype,
+                              void* stream) {
+    if (!c || !in || !out || n <= 0 || d <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_l2_normalize: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    launch_l2norm(in, n, d, out, out_dtype, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_f32_to_bf16(sgpt_ctx* c, const float* in, int64_t numel, void* out, void* stream) {
+    if (!c || !in || !out || numel <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_f32_to_bf16: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    launch_f32_to_bf16(in, numel, out, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+static sgpt_status check_score_dims(sgpt_ctx* c, int dtype, int d) {
+    if (dtype != SGPT_F32 && dtype != SGPT_BF16) return fail(c, SGPT_ERR_INVALID, "score: bad dtype");
+    const int mult = dtype == SGPT_BF16 ? 8 : 4;
+    if (d <= 0 || d % mult) return fail(c, SGPT_ERR_INVALID, "score: d must be a multiple of 4 (fp32) / 8 (bf16)");
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_scores(sgpt_ctx* c, const void* a, const void* b, int32_t dtype, int64_t na, int64_t nb, int32_t d,
+                        float* out, int64_t ldo, void* stream) {
+    if (!c || !a || !b || !out || na <= 0 || nb <= 0 || ldo < nb || ldo % 4 || na > INT32_MAX || nb > INT32_MAX)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_scores: bad arguments");
+    sgpt_status st = check_score_dims(c, dtype, d);
+    if (st != SGPT_OK) return st;
+    HIPC(c, hipSetDevice(c->device));
+    GemmArgs g{};
+    g.A = a; g.lda = d; g.W = b; g.ldw = d; g.M = (int)na; g.m_valid = (int)na; g.N = (int)nb; g.K = d;
+    g.out = out; g.ldo = ldo;
+    gemm(c, dtype, EPI_STORE, SGPT_F32, g, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int32_t dtype, int32_t nq, int64_t N,
+                            int32_t d, int32_t k, int64_t idx_base, float* run_val, int64_t* run_idx, int32_t n_run,
+                            int32_t* n_out, void* stream) {
+    if (!c || !q || !corpus || !run_val || !run_idx || nq <= 0 || N <= 0 || k <= 0 || n_run < 0 || n_run > k)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_score_topk: bad arguments");
+    sgpt_status st = check_score_dims(c, dtype, d);
+    if (st != SGPT_OK) return st;
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // chunk the corpus so the fp32 score tile [nq, chunk] stays resident in the 256 MiB Infinity Cache
+    const size_t budget = (size_t)96 << 20;
+    long chunk = (long)(budget / ((size_t)nq * 4));
+    chunk = chunk / 128 * 128;
+    if (chunk < 128) chunk = 128;
+    if (chunk > 65536) chunk = 65536;
+    if (chunk > N) chunk = (long)align_up((size_t)N, 4);
+    const size_t sc_bytes = align_up((size_t)nq * chunk * 4, 256);
+    const size_t tv_bytes = align_up((size_t)nq * k * 4, 256), ti_bytes = align_up((size_t)nq * k * 8, 256);
+    st = ensure(c, &c->ws2, &c->ws2_bytes, sc_bytes + 2 * (tv_bytes + ti_bytes));
+    if (st != SGPT_OK) return st;
+    char* base = (char*)c->ws2;
+    float* sc = (float*)base;
+    float* tv[2] = {(float*)(base + sc_bytes), (float*)(base + sc_bytes + tv_bytes)};
+    int64_t* ti[2] = {(int64_t*)(base + sc_bytes + 2 * tv_bytes), (int64_t*)(base + sc_bytes + 2 * tv_bytes + ti_bytes)};
+    const size_t esz = dtype == SGPT_BF16 ? 2 : 4;
+
+    const float* pv = n_run > 0 ? run_val : nullptr;
+    const int64_t* pi = n_run > 0 ? run_idx : nullptr;
+    int have = n_run;
+    int cur = 0;
+    for (long c0 = 0; c0 < N; c0 += chunk) {
+        const long nc = (N - c0) < chunk ? (N - c0) : chunk;
+        GemmArgs g{};
+        g.A = q; g.lda = d; g.M = nq; g.m_valid = nq; g.K = d;
+        g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = d; g.N = (int)nc;
+        g.out = sc; g.ldo = chunk;
+        gemm(c, dtype, EPI_SCORE, SGPT_F32, g, s);
+        const bool last = c0 + nc >= N;
+        float* ov = last ? run_val : tv[cur];
+        int64_t* oi = last ? run_idx : ti[cur];
+        if (last && pv == run_val) {  // in/out alias on a single-chunk call: stage through the ping-pong buffer
+            launch_topk_select(sc, chunk, nc, idx_base + c0, pv, pi, have, k, nq, k, 0, nullptr, tv[cur], ti[cur], s);
+            HIPC(c, hipMemcpyAsync(run_val, tv[cur], (size_t)nq * k * 4, hipMemcpyDeviceToDevice, s));
+            HIPC(c, hipMemcpyAsync(run_idx, ti[cur], (size_t)nq * k * 8, hipMemcpyDeviceToDevice, s));
+        } else {
+            launch_topk_select(sc, chunk, nc, idx_base + c0, pv, pi, have, k, nq, k, 0, nullptr, ov, oi, s);
+        }
+        pv = tv[cur]; pi = ti[cur];
+        have = k;  // unused tail slots carry idx = -1 and are ignored by the next merge
+        cur ^= 1;
+    }
+    if (n_out) { const int64_t tot = (int64_t)n_run + N; *n_out = (int32_t)(tot < k ? tot : k); }
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_topk_merge(sgpt_ctx* c, const float* val, const int64_t* idx, int32_t nq, int32_t mcand, int32_t k,
+                            const int64_t* exclude_idx, float* out_val, int64_t* out_idx, void* stream) {
+    if (!c || !val || !idx || !out_val || !out_idx || nq <= 0 || mcand <= 0 || k <= 0)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_topk_merge: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    // all candidates ride in the "previous best" leg of the virtual row (n = 0 fresh scores)
+    launch_topk_select(val, mcand, 0, 0, val, idx, mcand, mcand, nq, k, 0, exclude_idx, out_val, out_idx,
+                       (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_topk(sgpt_ctx* c, const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t k, int64_t idx_base,
+                      float* out_val, int64_t* out_idx, void* stream) {
+    if (!c || !scores || !out_val || !out_idx || nq <= 0 || n <= 0 || ld < n || k <= 0)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_topk: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    launch_topk_select(scores, ld, n, idx_base, nullptr, nullptr, 0, 0, nq, k, 1, nullptr, out_val, out_idx,
+                       (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// Causal (+ sliding-window) self-attention over packed variable-length sequences:
+// GPTNeoSelfAttention._attn (HF:gpt_neo/modeling_gpt_neo.py:105-130): scores = q.k^T (NO
+// 1/sqrt(dh) for GPT-Neo; `scale` carries it for other families), causal / local-window mask,
+// fp32 softmax, P.V.  Right/left padding never reaches a real token (pad keys are masked,
+// :119-120), so only the rows of each sequence's own span are touched.
+//
+// bf16 path (attn_bf16_kernel): one wave per 16 query rows, no LDS, no barriers.
+//   S^T = K.Q^T via v_mfma_f32_16x16x32_bf16 with K rows as the A-operand: a lane then owns ONE
+//   query (column lane&15) and keys {4g+r} of each 16-key tile, so
+//     - the row max / row sum are in-lane reductions + 2 shuffles (xor 16, 32),
+//     - the 8 probabilities a lane holds for a 32-key step ARE the B-operand fragment of
+//       O^T = V^T.P^T under the k-slot permutation  slot(g,j) <-> key 16*(j>>2) + 4g + (j&3);
+//       the A-operand (V^T rows, written transposed by the QKV GEMM epilogue) applies the same
+//       permutation with two 8-byte loads along the token axis.  No P round trip through LDS.
+//   Online softmax (running max m, running sum l) over 32-key steps; masked scores are -inf and
+//   m starts at -1e30 so a fully masked step contributes exp(-inf) = 0 without NaN.
+//
+// fp32 path (attn_f32_kernel): exact-fp32 VALU kernel for the parity gate, one wave per query row.
+#include "common.h"
+
+namespace {
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs p) {
+    constexpr int KS = DH / 32;  // k-slices of the QK^T contraction
+    constexpr int DT = DH / 16;  // 16-wide output tiles over the head dim
+    const int sq = blockIdx.z, head = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s0 = p.seq_off[sq];
+    const int alloc = p.seq_off[sq + 1] - s0;  // multiple of 16; rows >= seq_len are filler queries
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    if (q0 >= alloc) return;
+    const int fr = lane & 15, g = lane >> 4;
+
+    const bf16_t* __restrict__ qb = static_cast<const bf16_t*>(p.q) + (long)head * DH;
+    const bf16_t* __restrict__ kb = static_cast<const bf16_t*>(p.k) + (long)head * DH;
+    const bf16_t* __restrict__ vt = static_cast<const bf16_t*>(p.v) + (long)head * DH * p.ldvt;
+
+    // Q as the B-operand: lane (query fr, k-group g) holds 8 contiguous head-dim elements
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (long)(s0 + q0 + fr) * p.ldq + ks * 32 + 8 * g);
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+    const int qi = q0 + fr;  // this lane's query (sequence-relative)
+
+    int j_lo = 0;
+    if (p.window > 0) { j_lo = q0 - p.window + 1; j_lo = j_lo < 0 ? 0 : (j_lo & ~31); }
+    const int j_hi = q0 + 15;  // last key any of the 16 queries may see
+    for (int j0 = j_lo; j0 <= j_hi; j0 += 32) {
+        // ---- S^T tiles: [16 keys][16 queries] x 2 ----
+        f32x4 s[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16_t* kr = kb + (long)(s0 + j0 + nt * 16 + fr) * p.ldq + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + ks * 32);
+                s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[nt], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (lane: query qi, keys j0 + nt*16 + 4g + r) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kj = j0 + nt * 16 + 4 * g + r;
+                const bool vis = (kj <= qi) && (p.window <= 0 || kj > qi - p.window);
+                const float v = vis ? s[nt][r] * p.scale : -INFINITY;
+                s[nt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float ps = 0.f;
+        float pv[8];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[nt][r] - m_new);
+                pv[nt * 4 + r] = e;
+                ps += e;
+            }
+        l_run = l_run * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
+        }
+        // P^T fragment (B-operand): slot j <-> key j0 + 16*(j>>2) + 4g + (j&3)
+        uint4 pu;
+        pu.x = pack_bf16x2(pv[0], pv[1]); pu.y = pack_bf16x2(pv[2], pv[3]);
+        pu.z = pack_bf16x2(pv[4], pv[5]); pu.w = pack_bf16x2(pv[6], pv[7]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pu);
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16_t* vr = vt + (long)(dt * 16 + fr) * p.ldvt + s0 + j0 + 4 * g;
+            uint4 vu;
+            const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+            const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 16);
+            vu.x = v0.x; vu.y = v0.y; vu.z = v1.x; vu.w = v1.y;
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vu), pf, o[dt], 0, 0, 0);
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_run;
+    // O^T tile dt: lane holds head-dim rows dt*16 + 4g + r for query column fr
+    bf16_t* orow = static_cast<bf16_t*>(p.ctx) + (long)(s0 + qi) * p.ldo + (long)head * DH + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+        *reinterpret_cast<uint2*>(orow + dt * 16) =
+            make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+}
+
+// Exact fp32: one wave per query row.  Scores in LDS (max 2048 keys per wave).
+constexpr int F32_MAXKEYS = 2048;
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
+    __shared__ float sc[4][F32_MAXKEYS];
+    __shared__ float qs[4][256];
+    const int sq = blockIdx.z, head = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s0 = p.seq_off[sq];
+    const int alloc = p.seq_off[sq + 1] - s0;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= alloc) return;
+    const int dh = p.dh;
+    const float* __restrict__ qb = static_cast<const float*>(p.q) + (long)head * dh;
+    const float* __restrict__ kb = static_cast<const float*>(p.k) + (long)head * dh;
+    const float* __restrict__ vb = static_cast<const float*>(p.v) + (long)head * dh;
+    for (int c = lane; c < dh; c += 64) qs[wave][c] = qb[(long)(s0 + qi) * p.ldq + c];
+    int lo = 0;
+    if (p.window > 0) { lo = qi - p.window + 1; lo = lo < 0 ? 0 : lo; }
+    const int nkeys = qi - lo + 1;
+    float mx = -INFINITY;
+    for (int jj = lane; jj < nkeys; jj += 64) {
+        const float* kr = kb + (long)(s0 + lo + jj) * p.ldq;
+        float a = 0.f;
+        for (int c = 0; c < dh; c += 4) {
+            const float4 kv = *reinterpret_cast<const float4*>(kr + c);
+            a = fmaf(qs[wave][c], kv.x, a); a = fmaf(qs[wave][c + 1], kv.y, a);
+            a = fmaf(qs[wave][c + 2], kv.z, a); a = fmaf(qs[wave][c + 3], kv.w, a);
+        }
+        a *= p.scale;
+        sc[wave][jj] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int jj = lane; jj < nkeys; jj += 64) {
+        const float e = expf(sc[wave][jj] - mx);
+        sc[wave][jj] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float* orow = static_cast<float*>(p.ctx) + (long)(s0 + qi) * p.ldo + (long)head * dh;
+    for (int c = lane; c < dh; c += 64) {
+        float a = 0.f;
+        for (int jj = 0; jj < nkeys; ++jj) a = fmaf(sc[wave][jj], vb[(long)(s0 + lo + jj) * p.ldq + c], a);
+        orow[c] = a * inv;
+    }
+}
+
+}  // namespace
+
+void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
+    dim3 grid((a.max_alloc_len + 63) / 64, a.H, a.B);
+    if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_kernel<64>, grid, dim3(256), 0, s, a);
+    else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_kernel<128>, grid, dim3(256), 0, s, a);
+    else abort();
+}
+
+void launch_attn_f32(const AttnArgs& a, hipStream_t s) {
+    dim3 grid((a.max_alloc_len + 3) / 4, a.H, a.B);
+    hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, s, a);
+}

@@ -1,0 +1,96 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA 16x16 fragments).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN kept quiet (same as torch.Tensor.to(bfloat16))
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// transformers.activations.NewGELUActivation (HF gelu_new)
+__device__ __forceinline__ float gelu_new(float u) {
+    const float c = 0.7978845608028654f;  // sqrt(2/pi)
+    float t = c * (u + 0.044715f * u * u * u);
+    return 0.5f * u * (1.0f + tanhf(t));
+}
+
+// ---- launch descriptors shared between the .hip translation units and api.cpp ----
+enum GemmEpi {
+    EPI_STORE = 0,        // out[m][n] = acc                          (row-major, OutT)
+    EPI_BIAS_GELU = 1,    // out[m][n] = gelu_new(acc + bias[n])      (row-major, OutT)
+    EPI_BIAS_RESID = 2,   // out[m][n] = resid[m][n] + acc + bias[n]  (fp32, may alias)
+    EPI_SCORE = 3,        // out[m][n] = isnan(acc) ? -1 : acc        (fp32)
+    EPI_VT = 4,           // out[n][m] = acc  (transposed store, bf16: V^T for the attention B-operand)
+};
+
+struct GemmArgs {
+    const void* A;      // [M][K] row-major, leading dim lda (elements)
+    const void* W;      // [N][K] row-major, leading dim ldw (elements)  -> C = A * W^T
+    void* out;
+    const float* bias;  // [N] or null
+    const float* resid; // [M][ldo] fp32 or null
+    int M, N, K;
+    long lda, ldw, ldo;
+    int m_valid;        // rows >= m_valid are computed from clamped reads and not stored
+};
+
+void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
+
+struct AttnArgs {
+    const void* q;       // [T][ldq]  (bf16 path: qk buffer; fp32 path: qkv buffer)
+    const void* k;       // same buffer, column offset applied by the caller
+    const void* v;       // bf16 path: V^T [d][ldvt]; fp32 path: [T][ldq]
+    void* ctx;           // [T][d]
+    const int* seq_off;  // [B+1]
+    int B, H, dh;
+    long ldq, ldvt, ldo;
+    int window;          // 0 = global causal
+    float scale;
+    int max_alloc_len;
+};
+void launch_attn_bf16(const AttnArgs& a, hipStream_t s);
+void launch_attn_f32(const AttnArgs& a, hipStream_t s);
+
+void launch_embed(const int* ids, const int* pos, const float* wte, const float* wpe, float* x, int T, int d,
+                  hipStream_t s);
+void launch_layernorm(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
+                      float eps, hipStream_t s);
+void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,
+                     const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize, float* out,
+                     hipStream_t s);
+void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, int d, int mode, float* out,
+                 hipStream_t s);
+void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s);
+void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s);
+void launch_fill_f32(float* p, long n, float v, hipStream_t s);
+
+// top-k: one block per query row over a virtual row = [scores(n) | prev(n_prev)]
+void launch_topk_select(const float* scores, long ld, long n, long idx_base, const float* prev_val,
+                        const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
+                        const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s);

@@ -1,0 +1,280 @@
+// HBM-bound streaming kernels of the encoder: embedding gather-add, LayerNorm, the fused
+// final-LayerNorm + position-weighted mean pool, stand-alone pooling, L2 normalise.
+// All are one-wave-per-row (64 lanes x float4 = 1 KiB per instruction, coalesced) with
+// wavefront-shuffle reductions; no LDS except the cross-wave combine of the pool.
+#include "common.h"
+
+namespace {
+
+// ---- wte[ids] + wpe[pos]  (HF:gpt_neo/modeling_gpt_neo.py:444,462-463) ----
+__global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ ids, const int* __restrict__ pos,
+                                                    const float* __restrict__ wte, const float* __restrict__ wpe,
+                                                    float* __restrict__ x, int T, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const int lane = threadIdx.x & 63;
+    const float4* a = reinterpret_cast<const float4*>(wte + (long)ids[row] * d);
+    const float4* b = reinterpret_cast<const float4*>(wpe + (long)pos[row] * d);
+    float4* o = reinterpret_cast<float4*>(x + (long)row * d);
+    for (int c = lane; c < d / 4; c += 64) {
+        const float4 u = a[c], v = b[c];
+        o[c] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+}
+
+// row statistics + normalise in registers: nn.LayerNorm(eps) (HF:gpt_neo:317-319,385,492)
+template <int NV>
+struct RowLN {
+    float4 v[NV];
+    __device__ __forceinline__ void load(const float* __restrict__ xr, int d, int lane) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            v[i] = c < d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void normalize(const float* __restrict__ g, const float* __restrict__ b, int d,
+                                              float eps, int lane) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < d) {
+                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < d) {
+                const float4 gg = *reinterpret_cast<const float4*>(g + c);
+                const float4 bb = *reinterpret_cast<const float4*>(b + c);
+                v[i].x = (v[i].x - mean) * rstd * gg.x + bb.x;
+                v[i].y = (v[i].y - mean) * rstd * gg.y + bb.y;
+                v[i].z = (v[i].z - mean) * rstd * gg.z + bb.z;
+                v[i].w = (v[i].w - mean) * rstd * gg.w + bb.w;
+            }
+        }
+    }
+};
+
+template <typename OutT, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, OutT* __restrict__ out, int T,
+                                                        int d, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const int lane = threadIdx.x & 63;
+    RowLN<NV> r;
+    r.load(x + (long)row * d, d, lane);
+    r.normalize(g, b, d, eps, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            if constexpr (sizeof(OutT) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)row * d + c) = r.v[i];
+            } else {
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)row * d + c) =
+                    make_uint2(pack_bf16x2(r.v[i].x, r.v[i].y), pack_bf16x2(r.v[i].z, r.v[i].w));
+            }
+        }
+    }
+}
+
+// ---- ln_f + pooling + optional L2 normalise, one workgroup (4 waves) per sequence ----
+// weightedmean: sum_t (P+t+1) * h_t / clamp(sum_t (P+t+1), 1e-9), P = pad_left
+//   (Pooling.py:99-125; beir_dense_retriever.py:258-270; weights follow the PADDED index)
+// mean: Pooling.py:117-125 / beir_dense_retriever.py:238-242;  lasttoken: :271-282 (index len-1)
+template <int NV>
+__global__ __launch_bounds__(256) void lnf_pool_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                       const float* __restrict__ b, const int* __restrict__ seq_off,
+                                                       const int* __restrict__ seq_len,
+                                                       const int* __restrict__ pad_left, int d, float eps,
+                                                       int apply_ln, int mode, int normalize,
+                                                       float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][d] + 8
+    const int sq = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s0 = seq_off[sq], len = seq_len[sq], P = pad_left ? pad_left[sq] : 0;
+
+    float4 acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float den = 0.f;
+    const int t_lo = mode == 2 ? (len > 0 ? len - 1 : 0) : 0;
+    for (int t = t_lo + wave; t < len; t += 4) {
+        RowLN<NV> r;
+        r.load(x + (long)(s0 + t) * d, d, lane);
+        if (apply_ln) r.normalize(g, b, d, eps, lane);
+        const float w = mode == 0 ? (float)(P + t + 1) : 1.0f;
+        den += w;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            acc[i].x += w * r.v[i].x; acc[i].y += w * r.v[i].y;
+            acc[i].z += w * r.v[i].z; acc[i].w += w * r.v[i].w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) *reinterpret_cast<float4*>(sm + wave * d + c) = acc[i];
+    }
+    float* red = sm + 4 * d;
+    if (lane == 0) red[wave] = den;
+    __syncthreads();
+    float dsum = (red[0] + red[1]) + (red[2] + red[3]);
+    if (mode != 2) dsum = fmaxf(dsum, 1e-9f);  // Pooling.py:122
+    else dsum = 1.0f;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        const float e = ((sm[c] + sm[d + c]) + (sm[2 * d + c] + sm[3 * d + c])) / dsum;
+        sm[c] = e;
+        ss += e * e;
+    }
+    if (normalize) {  // F.normalize(p=2, dim=1), SentenceTransformer.py:248-249
+        ss = wave_sum(ss);
+        __syncthreads();
+        if (lane == 0) red[4 + wave] = ss;
+        __syncthreads();
+        const float nrm = fmaxf(sqrtf((red[4] + red[5]) + (red[6] + red[7])), 1e-12f);
+        for (int c = threadIdx.x; c < d; c += 256) out[(long)sq * d + c] = sm[c] / nrm;
+    } else {
+        for (int c = threadIdx.x; c < d; c += 256) out[(long)sq * d + c] = sm[c];
+    }
+}
+
+// ---- stand-alone pooling over [B,S,d] hidden states + {0,1} mask (any padding side) ----
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_kernel(const T* __restrict__ h, const int* __restrict__ mask, int S, int d,
+                                                   int mode, float* __restrict__ out) {
+    const int bq = blockIdx.x;
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (c >= d) return;
+    const T* hb = h + (long)bq * S * d + c;
+    const int* mb = mask + (long)bq * S;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == 2) {
+        int last = 0;
+        for (int t = 0; t < S; ++t) if (mb[t] != 0) last = t;
+        acc = load4<T>(hb + (long)last * d);
+    } else {
+        float den = 0.f;
+#pragma unroll 4
+        for (int t = 0; t < S; ++t) {
+            const float w = mb[t] != 0 ? (mode == 0 ? (float)(t + 1) : 1.0f) : 0.0f;
+            const float4 v = load4<T>(hb + (long)t * d);
+            den += w;
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+        den = fmaxf(den, 1e-9f);
+        acc.x /= den; acc.y /= den; acc.z /= den; acc.w /= den;
+    }
+    *reinterpret_cast<float4*>(out + (long)bq * d + c) = acc;
+}
+
+// ---- x / max(||x||, 1e-12) per row; fp32 or bf16 output ----
+template <typename OutT>
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ in, long n, int d,
+                                                     OutT* __restrict__ out) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = in + row * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) { const float v = xr[c]; s += v * v; }
+    const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int c = lane; c < d; c += 64) {
+        const float v = xr[c] / nrm;
+        if constexpr (sizeof(OutT) == 4) reinterpret_cast<float*>(out)[row * d + c] = v;
+        else reinterpret_cast<bf16_t*>(out)[row * d + c] = f32_to_bf16(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, long numel,
+                                                       bf16_t* __restrict__ out) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += stride) out[i] = f32_to_bf16(in[i]);
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n, float v) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+inline int cap_grid(long blocks) { return (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks)); }
+
+}  // namespace
+
+void launch_embed(const int* ids, const int* pos, const float* wte, const float* wpe, float* x, int T, int d,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, pos, wte, wpe, x, T, d);
+}
+
+void launch_layernorm(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
+                      float eps, hipStream_t s) {
+#define LN_CASE(NV)                                                                                              \
+    if (out_dtype == 1)                                                                                          \
+        hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,          \
+                           (bf16_t*)out, T, d, eps);                                                             \
+    else                                                                                                         \
+        hipLaunchKernelGGL((layernorm_kernel<float, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,           \
+                           (float*)out, T, d, eps);
+    const int nv = (d + 255) / 256;
+    if (nv <= 1) { LN_CASE(1) } else if (nv <= 2) { LN_CASE(2) } else if (nv <= 3) { LN_CASE(3) }
+    else if (nv <= 4) { LN_CASE(4) } else if (nv <= 8) { LN_CASE(8) } else if (nv <= 10) { LN_CASE(10) }
+    else { LN_CASE(16) }
+#undef LN_CASE
+}
+
+void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,
+                     const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize, float* out,
+                     hipStream_t s) {
+    const size_t sm = (size_t)(4 * d + 8) * sizeof(float);
+#define LP_CASE(NV)                                                                                              \
+    hipLaunchKernelGGL((lnf_pool_kernel<NV>), dim3(B), dim3(256), sm, s, x, g, b, seq_off, seq_len, pad_left, d, \
+                       eps, apply_ln, mode, normalize, out);
+    const int nv = (d + 255) / 256;
+    if (nv <= 1) { LP_CASE(1) } else if (nv <= 2) { LP_CASE(2) } else if (nv <= 3) { LP_CASE(3) }
+    else if (nv <= 4) { LP_CASE(4) } else if (nv <= 8) { LP_CASE(8) } else if (nv <= 10) { LP_CASE(10) }
+    else { LP_CASE(16) }
+#undef LP_CASE
+}
+
+void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, int d, int mode, float* out,
+                 hipStream_t s) {
+    dim3 grid(B, (d / 4 + 255) / 256);
+    if (dtype == 1)
+        hipLaunchKernelGGL(pool_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)hidden, mask, S, d, mode, out);
+    else
+        hipLaunchKernelGGL(pool_kernel<float>, grid, dim3(256), 0, s, (const float*)hidden, mask, S, d, mode, out);
+}
+
+void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s) {
+    const int grid = (int)((n + 3) / 4);
+    if (out_dtype == 1) hipLaunchKernelGGL(l2norm_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, in, n, d, (bf16_t*)out);
+    else hipLaunchKernelGGL(l2norm_kernel<float>, dim3(grid), dim3(256), 0, s, in, n, d, (float*)out);
+}
+
+void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3(cap_grid((numel + 255) / 256)), dim3(256), 0, s, in, numel, (bf16_t*)out);
+}
+
+void launch_fill_f32(float* p, long n, float v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_kernel, dim3(cap_grid((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+}

@@ -1,0 +1,249 @@
+// C[M,N] = A[M,K] * W[N,K]^T with fused epilogues -- the MFMA hot loop of the encoder
+// (QKV / out-proj / MLP projections: HF:gpt_neo/modeling_gpt_neo.py:141-143,155,304-309)
+// and of the scorer (torch.mm(a, b.T): sentence_transformers/util.py:43,63).
+//
+// gfx950 design
+//   * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
+//     4x4 MFMA 16x16 fragments, fp32 accumulators in 64 VGPRs);
+//   * both operands are K-contiguous ("B^T input"), so A- and B-fragments are the same
+//     16-byte-per-lane read: lane (r = lane&15, g = lane>>4) holds 16 B of row r at
+//     K-chunk g.  One k-step = 128 B of K per row (64 bf16 / 32 fp32);
+//       bf16: one v_mfma_f32_16x16x32_bf16 per fragment pair per 32-wide k slice,
+//       fp32: four v_mfma_f32_16x16x4_f32 (element e of the 16-B chunk <-> k = 4*chunk+e,
+//             the same k permutation on both operands, so the contraction is exact);
+//   * LDS: 2 (double buffer) x 2 (A,W) x 128 rows x 128 B = 64 KiB, rows XOR-swizzled at
+//     16-B granularity (chunk ^= row&7) -> conflict-free ds_write_b128 / ds_read_b128;
+//   * register-staged software pipeline: global loads of tile k+1 are issued before the
+//     MFMAs of tile k and written to the other LDS buffer after them (one barrier / k-step);
+//   * XCD-aware block order: the 8 XCDs own interleaved M-tiles, and the N-tiles of one
+//     M-tile run back-to-back on the same XCD, so the activation panel is fetched into one
+//     L2 only (weights are small and live in every L2);
+//   * SWAP=true feeds the weight fragment as the MFMA A-operand, so a lane ends up with
+//     4 consecutive n for one m: row-major stores are 8 B (bf16) / 16 B (fp32) per lane.
+//     SWAP=false gives 4 consecutive m for one n: used for the transposed V^T store.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, CH = 8;  // CH = 16-byte chunks per row per k-step
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<bf16_t> { static constexpr int EPC = 8; };
+template <> struct ElemTraits<float> { static constexpr int EPC = 4; };
+
+template <typename T, bool SWAP>
+__device__ __forceinline__ void mma(f32x4& acc, const uint4& act, const uint4& wgt) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 a = __builtin_bit_cast(bf16x8, act);
+        bf16x8 w = __builtin_bit_cast(bf16x8, wgt);
+        if constexpr (SWAP) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc, 0, 0, 0);
+    } else {
+        const float a[4] = {__uint_as_float(act.x), __uint_as_float(act.y), __uint_as_float(act.z),
+                            __uint_as_float(act.w)};
+        const float w[4] = {__uint_as_float(wgt.x), __uint_as_float(wgt.y), __uint_as_float(wgt.z),
+                            __uint_as_float(wgt.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (SWAP) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], a[e], acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w[e], acc, 0, 0, 0);
+        }
+    }
+}
+
+template <typename OutT> __device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+template <typename OutT> __device__ __forceinline__ void store1(OutT* p, float a);
+template <> __device__ __forceinline__ void store1<float>(float* p, float a) { *p = a; }
+template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float a) { *p = f32_to_bf16(a); }
+
+template <typename T, int EPI, typename OutT, bool SWAP>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = CH * EPC;
+    __shared__ __attribute__((aligned(16))) uint4 lds[2][2][BM * CH];  // 64 KiB
+
+    const int M = p.M, N = p.N, K = p.K;
+    const int MT = (M + BM - 1) / BM, NT = (N + BN - 1) / BN;
+    // XCD-aware order (block b runs on XCD b%8): XCD x owns M-tiles x, x+8, ...
+    const int b = blockIdx.x;
+    const int xcd = b & 7, local = b >> 3;
+    const int mt = xcd + 8 * (local / NT), nt = local % NT;
+    if (mt >= MT) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int t = threadIdx.x;
+    const int lr = t >> 3, lc = t & 7;
+    const T* __restrict__ Ag = static_cast<const T*>(p.A);
+    const T* __restrict__ Wg = static_cast<const T*>(p.W);
+
+    long arow[4], wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ra = m0 + lr + 32 * i; ra = ra < M ? ra : M - 1;
+        int rw = n0 + lr + 32 * i; rw = rw < N ? rw : N - 1;
+        arow[i] = (long)ra * p.lda;
+        wrow[i] = (long)rw * p.ldw;
+    }
+
+    uint4 ra_[4], rw_[4];
+    auto gload = [&](int kt) {
+        const int kc = kt * BK + lc * EPC;
+        if (kt * BK + BK <= K) {  // block-uniform: full k-step (every encoder GEMM)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra_[i] = *reinterpret_cast<const uint4*>(Ag + arow[i] + kc);
+                rw_[i] = *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc);
+            }
+        } else {  // K tail (scoring with d not a multiple of the k-step): zero-fill chunks past K
+            const bool ok = kc < K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra_[i] = ok ? *reinterpret_cast<const uint4*>(Ag + arow[i] + kc) : make_uint4(0, 0, 0, 0);
+                rw_[i] = ok ? *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lr + 32 * i;
+            const int off = row * CH + (lc ^ (row & 7));
+            lds[buf][0][off] = ra_[i];
+            lds[buf][1][off] = rw_[i];
+        }
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, g = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + fr;
+                af[i] = lds[buf][0][row * CH + ((4 * ks + g) ^ (row & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + fr;
+                wf[j] = lds[buf][1][row * CH + ((4 * ks + g) ^ (row & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma<T, SWAP>(acc[i][j], af[i], wf[j]);
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        compute(kt & 1);
+        if (more) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    OutT* __restrict__ out = static_cast<OutT*>(p.out);
+    const int mv = p.m_valid;
+    if constexpr (SWAP) {
+        // lane: m = .. + fr ; n = .. + 4g + r  -> 4 consecutive n, row-major vector store
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + fr;
+            if (m >= mv) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + 4 * g;
+                if (n >= N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const bool full = n + 3 < N;
+                if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
+                    // N is a multiple of 4 for every biased projection
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_new(v[r]);
+                }
+                if constexpr (EPI == EPI_BIAS_RESID) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
+                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                }
+                if constexpr (EPI == EPI_SCORE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (v[r] != v[r]) ? -1.0f : v[r];  // exact_search.py:99
+                }
+                OutT* dst = out + (long)m * p.ldo + n;
+                if (full) {
+                    store4<OutT>(dst, v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < N) store1<OutT>(dst + r, v[r]);
+                }
+            }
+        }
+    } else {
+        // lane: m = .. + 4g + r ; n = .. + fr  -> 4 consecutive m: transposed store out[n][m..m+3]
+        static_assert(SWAP || EPI == EPI_VT, "non-swapped orientation is only used for the V^T store");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fr;
+            if (n >= N) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + 4 * g;
+                if (m >= M) continue;  // M (token axis) is padded to a multiple of 128 by the caller
+                store4<OutT>(out + (long)n * p.ldo + m, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+    }
+}
+
+template <typename T, int EPI, typename OutT, bool SWAP>
+void launch(const GemmArgs& a, hipStream_t s) {
+    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
+    const int grid = ((MT + 7) / 8) * 8 * NT;
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP>), dim3(grid), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
+    const bool bf = dtype == 1, obf = out_dtype == 1;
+    if (bf) {
+        if (epi == EPI_STORE && obf) return launch<bf16_t, EPI_STORE, bf16_t, true>(a, s);
+        if (epi == EPI_STORE && !obf) return launch<bf16_t, EPI_STORE, float, true>(a, s);
+        if (epi == EPI_VT) return launch<bf16_t, EPI_VT, bf16_t, false>(a, s);
+        if (epi == EPI_BIAS_GELU) return launch<bf16_t, EPI_BIAS_GELU, bf16_t, true>(a, s);
+        if (epi == EPI_BIAS_RESID) return launch<bf16_t, EPI_BIAS_RESID, float, true>(a, s);
+        if (epi == EPI_SCORE) return launch<bf16_t, EPI_SCORE, float, true>(a, s);
+    } else {
+        if (epi == EPI_STORE) return launch<float, EPI_STORE, float, true>(a, s);
+        if (epi == EPI_BIAS_GELU) return launch<float, EPI_BIAS_GELU, float, true>(a, s);
+        if (epi == EPI_BIAS_RESID) return launch<float, EPI_BIAS_RESID, float, true>(a, s);
+        if (epi == EPI_SCORE) return launch<float, EPI_SCORE, float, true>(a, s);
+    }
+    abort();
+}

@@ -1,0 +1,262 @@
+"""SGPT encoder on the HIP layer: weights -> sgpt_model_load, token lists -> packed varlen
+batches -> sgpt_encode (GPT-Neo forward + pool + optional normalise in one C call).
+
+Replaces the device leg of CustomEmbedder.embed / embed_batcher
+(biencoder/beir/beir_dense_retriever.py:158-314) and of SentenceTransformer._encode
+(sentence_transformers/SentenceTransformer.py:217-255)."""
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F32
+from .runtime import Context, get_context, _p, _stream_ptr
+
+ALIGN = 16         # sequence starts on the packed token axis (MFMA 16-row tiles; V^T 8-byte loads)
+TOKEN_TILE = 128   # GEMM M tile
+
+
+@dataclass
+class SGPTConfig:
+    """The fields of HF GPTNeoConfig the forward reads (HF:gpt_neo/configuration_gpt_neo.py)."""
+    vocab_size: int = 50257
+    max_position_embeddings: int = 2048
+    hidden_size: int = 768
+    num_layers: int = 12
+    num_heads: int = 12
+    intermediate_size: Optional[int] = None
+    window_size: int = 256
+    attention_layers: Optional[List[str]] = None
+    layer_norm_epsilon: float = 1e-5
+
+    def __post_init__(self):
+        if self.intermediate_size is None:
+            self.intermediate_size = 4 * self.hidden_size
+        if self.attention_layers is None:
+            self.attention_layers = ["global" if i % 2 == 0 else "local" for i in range(self.num_layers)]
+
+    @classmethod
+    def from_hf_dict(cls, c: dict) -> "SGPTConfig":
+        mt = c.get("model_type", "gpt_neo")
+        if mt != "gpt_neo":
+            raise NotImplementedError(f"model_type {mt!r}: only GPT-Neo (SGPT-125M/1.3B/2.7B) is built in this round")
+        layers = c.get("attention_layers")
+        if layers is None and c.get("attention_types"):
+            layers = []
+            for pattern, rep in c["attention_types"]:
+                for _ in range(rep):
+                    layers.extend(pattern)
+        return cls(vocab_size=c["vocab_size"], max_position_embeddings=c["max_position_embeddings"],
+                   hidden_size=c["hidden_size"], num_layers=c["num_layers"], num_heads=c["num_heads"],
+                   intermediate_size=c.get("intermediate_size"), window_size=c.get("window_size", 256),
+                   attention_layers=layers, layer_norm_epsilon=c.get("layer_norm_epsilon", 1e-5))
+
+
+@dataclass
+class PackedBatch:
+    """Device-resident packed token layout of include/sgpt_hip.h::sgpt_encode."""
+    ids: torch.Tensor
+    pos: torch.Tensor
+    seq_off: torch.Tensor
+    seq_len: torch.Tensor
+    pad_left: torch.Tensor
+    B: int
+    T_pad: int
+    max_alloc: int
+    n_tokens: int  # real tokens (for throughput accounting)
+
+
+def pack_host(seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None):
+    """Token lists -> numpy arrays of the packed layout (pure index arithmetic, host side)."""
+    B = len(seqs)
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=B)
+    if B == 0 or (lens <= 0).any():
+        raise ValueError("Empty items should be cleaned prior to running")  # beir_dense_retriever.py:180-181
+    alloc = (lens + ALIGN - 1) // ALIGN * ALIGN
+    off = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(alloc, out=off[1:])
+    T_used = int(off[-1])
+    T_pad = (T_used + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE
+    ids = np.zeros(T_pad, dtype=np.int32)
+    pos = np.zeros(T_pad, dtype=np.int32)
+    pl = np.zeros(B, dtype=np.int32) if pad_left is None else np.asarray(pad_left, dtype=np.int32)
+    flat = np.fromiter((t for s in seqs for t in s), dtype=np.int32, count=int(lens.sum()))
+    # destination row of every real token: seq_off[b] + t
+    rep_off = np.repeat(off[:-1], lens)
+    within = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+    rows = rep_off + within
+    ids[rows] = flat
+    pos[rows] = (within + np.repeat(pl.astype(np.int64), lens)).astype(np.int32)
+    return dict(ids=ids, pos=pos, seq_off=off.astype(np.int32), seq_len=lens.astype(np.int32), pad_left=pl,
+                B=B, T_pad=T_pad, max_alloc=int(alloc.max()), n_tokens=int(lens.sum()))
+
+
+class SGPTModel:
+    """GPT-Neo weights resident on one GPU behind an `sgpt_model*` handle."""
+
+    def __init__(self, cfg: SGPTConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device=None,
+                 dtype: str = "bf16", ctx: Optional[Context] = None, max_tokens_per_call: int = 32768):
+        if dtype not in ("bf16", "fp32"):
+            raise ValueError("dtype must be 'bf16' (MFMA bf16 operands) or 'fp32' (exact fp32 MFMA)")
+        self.cfg = cfg
+        self.ctx = ctx or get_context(device)
+        self.device = self.ctx.device
+        self.dtype = dtype
+        self.max_tokens_per_call = max_tokens_per_call
+        lib = self.ctx.lib
+        local = (C.c_uint8 * cfg.num_layers)(*[1 if a == "local" else 0 for a in cfg.attention_layers])
+        desc = ModelDesc(arch=_lib.SGPT_ARCH_GPTNEO, n_layers=cfg.num_layers, d_model=cfg.hidden_size,
+                         n_heads=cfg.num_heads, d_ffn=cfg.intermediate_size, vocab=cfg.vocab_size,
+                         max_pos=cfg.max_position_embeddings, window=cfg.window_size,
+                         ln_eps=cfg.layer_norm_epsilon, attn_scale=1.0,
+                         compute_dtype=SGPT_BF16 if dtype == "bf16" else SGPT_F32,
+                         layer_is_local=C.cast(local, C.POINTER(C.c_uint8)))
+        names, keep = [], []
+        for k, v in weights.items():
+            k2 = k[len("transformer."):] if k.startswith("transformer.") else k
+            if k2.endswith("attn.attention.bias") or k2.endswith("masked_bias") or k2.startswith("lm_head"):
+                continue
+            t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()   # H2D staging only
+            names.append(k2.encode())
+            keep.append(t)
+        views = (TensorView * len(keep))(*[TensorView(n, t.data_ptr(), t.numel()) for n, t in zip(names, keep)])
+        h = C.c_void_p()
+        torch.cuda.synchronize(self.device)
+        _lib.check(self.ctx.handle, lib.sgpt_model_load(self.ctx.handle, C.byref(desc), views, len(keep), C.byref(h)),
+                   "sgpt_model_load")
+        self.handle = h
+        del keep  # the library now owns packed copies
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.sgpt_model_free(self.handle)
+            self.handle = None
+
+    # ---- loading real checkpoints (HF folder / sentence-transformers folder layout) ----
+    @classmethod
+    def from_pretrained(cls, path: str, **kw) -> "SGPTModel":
+        """Reads config.json + model.safetensors / pytorch_model.bin of an SGPT checkpoint folder
+        (AutoModel.from_pretrained at beir_dense_retriever.py:123; ST folder layout
+        SentenceTransformer.py:903-936 keeps the transformer either at the root or in 0_Transformer/)."""
+        root = path
+        if not os.path.exists(os.path.join(root, "config.json")) and os.path.exists(os.path.join(root, "0_Transformer")):
+            root = os.path.join(root, "0_Transformer")
+        with open(os.path.join(root, "config.json")) as f:
+            cfg = SGPTConfig.from_hf_dict(json.load(f))
+        st = os.path.join(root, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(root, "pytorch_model.bin"), map_location="cpu")
+        return cls(cfg, sd, **kw)
+
+    # ---- packing ----
+    def pack(self, seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None) -> PackedBatch:
+        h = pack_host(seqs, pad_left)
+        if h["max_alloc"] > 2048 or int(h["seq_len"].max()) + int(h["pad_left"].max()) > self.cfg.max_position_embeddings:
+            raise ValueError("sequence longer than max_position_embeddings")
+        dev = lambda a: torch.from_numpy(a).to(self.device, non_blocking=False)  # noqa: E731
+        return PackedBatch(dev(h["ids"]), dev(h["pos"]), dev(h["seq_off"]), dev(h["seq_len"]), dev(h["pad_left"]),
+                           h["B"], h["T_pad"], h["max_alloc"], h["n_tokens"])
+
+    # ---- one C call: forward + pool ----
+    def encode_packed(self, pb: PackedBatch, mode: str = "weightedmean", normalize: bool = False,
+                      layer_idx: int = -1, out: Optional[torch.Tensor] = None,
+                      return_hidden: bool = False):
+        if mode not in POOL_MODES:
+            raise ValueError(f"unknown pooling mode {mode}")
+        L = self.cfg.num_layers
+        # hidden_states has L+1 entries: i<L = input of block i (no ln_f); L (== -1) = post ln_f
+        li = layer_idx if layer_idx >= 0 else L + 1 + layer_idx
+        if not 0 <= li <= L:
+            raise ValueError(f"Layer Idx {layer_idx} is larger than the {L + 1} hidden states")
+        n_run, final_ln = (L, 1) if li == L else (li, 0)
+        d = self.cfg.hidden_size
+        if out is None:
+            out = torch.empty((pb.B, d), dtype=torch.float32, device=self.device)
+        hidden = torch.empty((pb.T_pad, d), dtype=torch.float32, device=self.device) if return_hidden else None
+        st = self.ctx.lib.sgpt_encode(self.handle, _p(pb.ids), _p(pb.pos), _p(pb.seq_off), _p(pb.seq_len),
+                                      _p(pb.pad_left), pb.B, pb.T_pad, pb.max_alloc, POOL_MODES[mode], n_run,
+                                      final_ln, 1 if normalize else 0, _p(out), _p(hidden),
+                                      _stream_ptr(self.device))
+        _lib.check(self.ctx.handle, st, "sgpt_encode")
+        return (out, hidden) if return_hidden else out
+
+    def plan_batches(self, lens: np.ndarray, max_sentences: Optional[int] = None) -> List[np.ndarray]:
+        """Length-sorted (longest first, SentenceTransformer.py:148-149 / exact_search.py:66-71)
+        contiguous slices bounded by a token budget instead of a padded [B,S] rectangle."""
+        order = np.argsort(-lens, kind="stable")
+        alloc = (lens[order] + ALIGN - 1) // ALIGN * ALIGN
+        out, start, tok = [], 0, 0
+        for i, a in enumerate(alloc):
+            full = tok + a > self.max_tokens_per_call or (max_sentences and i - start >= max_sentences)
+            if full and i > start:
+                out.append(order[start:i])
+                start, tok = i, 0
+            tok += int(a)
+        out.append(order[start:])
+        return out
+
+    def encode_ids(self, seqs: Sequence[Sequence[int]], mode: str = "weightedmean", normalize: bool = False,
+                   layer_idx: int = -1, pad_left: Optional[Sequence[int]] = None,
+                   out_dtype=torch.float32) -> torch.Tensor:
+        """n token lists -> fp32[n,d] embeddings on the GPU, row-aligned with the input order."""
+        n = len(seqs)
+        if n == 0:
+            return torch.empty((0, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
+        lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
+        if (lens <= 0).any():
+            raise ValueError("Empty items should be cleaned prior to running")
+        res = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
+        for sel in self.plan_batches(lens):
+            pb = self.pack([seqs[i] for i in sel], None if pad_left is None else [pad_left[i] for i in sel])
+            emb = self.encode_packed(pb, mode, normalize, layer_idx)
+            res[torch.from_numpy(sel).to(self.device)] = emb          # un-sort (SentenceTransformer.py:205)
+        return res
+
+    def token_embeddings(self, seqs: Sequence[Sequence[int]], layer_idx: int = -1,
+                         pad_left: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+        """output_value='token_embeddings' (SentenceTransformer.py:233-241): per-sentence [len,d]."""
+        pb = self.pack(seqs, pad_left)
+        _, hid = self.encode_packed(pb, layer_idx=layer_idx, return_hidden=True)
+        off = pb.seq_off.cpu().tolist()
+        return [hid[off[i]: off[i] + len(s)] for i, s in enumerate(seqs)]
+
+
+def synthetic_weights(cfg: SGPTConfig, seed: int = 0, std: float = 0.02) -> Dict[str, np.ndarray]:
+    """Seeded random-init weights under HF GPT-Neo state-dict names (no checkpoints exist offline).
+    Same generator stream as oracle/sgpt_oracle.py::synth_weights so the CPU oracle and the GPU read
+    identical bytes; duplicated here because product code must not import the oracle."""
+    rng = np.random.default_rng(seed)
+    d, ffn = cfg.hidden_size, cfg.intermediate_size
+    f32 = np.float32
+
+    def nrm(*shape, s=std):
+        return (rng.standard_normal(shape, dtype=np.float32) * f32(s)).astype(f32)
+
+    w = {"wte.weight": nrm(cfg.vocab_size, d), "wpe.weight": nrm(cfg.max_position_embeddings, d, s=std / 2)}
+    for i in range(cfg.num_layers):
+        p = f"h.{i}."
+        w[p + "ln_1.weight"] = (1.0 + nrm(d, s=0.1)).astype(f32)
+        w[p + "ln_1.bias"] = nrm(d, s=0.05)
+        w[p + "attn.attention.q_proj.weight"] = nrm(d, d)
+        w[p + "attn.attention.k_proj.weight"] = nrm(d, d)
+        w[p + "attn.attention.v_proj.weight"] = nrm(d, d)
+        w[p + "attn.attention.out_proj.weight"] = nrm(d, d)
+        w[p + "attn.attention.out_proj.bias"] = nrm(d, s=0.02)
+        w[p + "ln_2.weight"] = (1.0 + nrm(d, s=0.1)).astype(f32)
+        w[p + "ln_2.bias"] = nrm(d, s=0.05)
+        w[p + "mlp.c_fc.weight"] = nrm(ffn, d)
+        w[p + "mlp.c_fc.bias"] = nrm(ffn, s=0.02)
+        w[p + "mlp.c_proj.weight"] = nrm(d, ffn)
+        w[p + "mlp.c_proj.bias"] = nrm(d, s=0.02)
+    w["ln_f.weight"] = (1.0 + nrm(d, s=0.1)).astype(f32)
+    w["ln_f.bias"] = nrm(d, s=0.05)
+    return w

@@ -1,0 +1,177 @@
+"""Thin Python host over the C ABI: a `Context` per GPU.  PyTorch is used only to own device
+memory (torch.empty / .data_ptr()) and to name the current HIP stream -- every computation is
+a call into libsgpt_hip.so.  No torch compute op stands in for a kernel here."""
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SGPT_BF16, SGPT_F32, POOL_MODES
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+_contexts = {}
+
+
+def get_context(device=None) -> "Context":
+    """One Context per HIP device per process (one process per GPU in multi-GPU runs)."""
+    if not torch.cuda.is_available():
+        raise _lib.SgptHipError("no HIP device visible: sgpt_amd runs its hot path only as gfx950 kernels "
+                                "(there is no CPU path)")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.SgptHipError(f"sgpt_amd needs a HIP device, got {dev}")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _contexts:
+        _contexts[idx] = Context(idx)
+    return _contexts[idx]
+
+
+class Context:
+    def __init__(self, device_index: int):
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device_index)
+        h = C.c_void_p()
+        st = self.lib.sgpt_ctx_create(device_index, C.byref(h))
+        if st != 0:
+            raise _lib.SgptHipError(f"sgpt_ctx_create(device={device_index}) failed with status {st}")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sgpt_ctx_destroy(self.handle)
+            self.handle = None
+
+    def _chk(self, st, what):
+        _lib.check(self.handle, st, what)
+
+    # ---- helpers ----
+    def _dev_f32(self, a) -> torch.Tensor:
+        """Tensor / ndarray / list -> contiguous fp32 tensor on this device (the coercions of
+        util.cos_sim, sentence_transformers/util.py:29-39)."""
+        if not isinstance(a, torch.Tensor):
+            a = torch.as_tensor(np.asarray(a))
+        if a.dim() == 1:
+            a = a.unsqueeze(0)
+        return a.to(device=self.device, dtype=torch.float32).contiguous()
+
+    # ---- a4: stand-alone pooling ----
+    def pool(self, hidden: torch.Tensor, mask: torch.Tensor, mode: str = "weightedmean") -> torch.Tensor:
+        if mode not in POOL_MODES:
+            raise ValueError(f"unknown pooling mode {mode}")
+        hidden = hidden.to(self.device)
+        if hidden.dtype not in (torch.float32, torch.bfloat16):
+            hidden = hidden.float()
+        hidden = hidden.contiguous()
+        B, S, d = hidden.shape
+        m = mask.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty((B, d), dtype=torch.float32, device=self.device)
+        dt = SGPT_BF16 if hidden.dtype == torch.bfloat16 else SGPT_F32
+        self._chk(self.lib.sgpt_pool(self.handle, _p(hidden), dt, _p(m), B, S, d, POOL_MODES[mode], _p(out),
+                                     _stream_ptr(self.device)), "sgpt_pool")
+        return out
+
+    # ---- normalise / convert ----
+    def l2_normalize(self, x: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+        x = self._dev_f32(x)
+        n, d = x.shape
+        out = torch.empty((n, d), dtype=out_dtype, device=self.device)
+        self._chk(self.lib.sgpt_l2_normalize(self.handle, _p(x), n, d, _p(out),
+                                             SGPT_BF16 if out_dtype == torch.bfloat16 else SGPT_F32,
+                                             _stream_ptr(self.device)), "sgpt_l2_normalize")
+        return out
+
+    def to_bf16(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=self.device)
+        self._chk(self.lib.sgpt_f32_to_bf16(self.handle, _p(x), x.numel(), _p(out), _stream_ptr(self.device)),
+                  "sgpt_f32_to_bf16")
+        return out
+
+    def _operand(self, x: torch.Tensor, dtype) -> torch.Tensor:
+        if x.dtype == dtype and x.device == self.device and x.is_contiguous():
+            return x
+        if dtype == torch.bfloat16:
+            return x if (x.dtype == torch.bfloat16 and x.is_contiguous()) else self.to_bf16(x)
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    # ---- a7: dense score matrix (cos_sim / dot_score) ----
+    def scores(self, a: torch.Tensor, b: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+        a, b = self._operand(a, dtype), self._operand(b, dtype)
+        na, d = a.shape
+        nb, d2 = b.shape
+        if d != d2:
+            raise ValueError(f"embedding dims differ: {d} vs {d2}")
+        ldo = (nb + 3) // 4 * 4
+        out = torch.empty((na, ldo), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.sgpt_scores(self.handle, _p(a), _p(b), SGPT_BF16 if dtype == torch.bfloat16 else SGPT_F32,
+                                       na, nb, d, _p(out), ldo, _stream_ptr(self.device)), "sgpt_scores")
+        return out[:, :nb]
+
+    # ---- a7+a8: fused chunked score + running top-k ----
+    def score_topk(self, q: torch.Tensor, corpus: torch.Tensor, k: int, idx_base: int = 0,
+                   run: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
+                   dtype=None) -> Tuple[torch.Tensor, torch.Tensor, int]:
+        """-> (values fp32[nq,k], indices int64[nq,k], n_valid); rows sorted by descending score."""
+        if dtype is None:
+            dtype = corpus.dtype if corpus.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        q, corpus = self._operand(q, dtype), self._operand(corpus, dtype)
+        nq, d = q.shape
+        N, d2 = corpus.shape
+        if d != d2:
+            raise ValueError(f"embedding dims differ: {d} vs {d2}")
+        if run is None:
+            val = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            idx = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+            n_run = 0
+        else:
+            val, idx, n_run = run
+        n_out = C.c_int32(0)
+        self._chk(self.lib.sgpt_score_topk(self.handle, _p(q), _p(corpus),
+                                           SGPT_BF16 if dtype == torch.bfloat16 else SGPT_F32, nq, N, d, k,
+                                           idx_base, _p(val), _p(idx), n_run, C.byref(n_out),
+                                           _stream_ptr(self.device)), "sgpt_score_topk")
+        return val, idx, int(n_out.value)
+
+    def topk_merge(self, val: torch.Tensor, idx: torch.Tensor, k: int,
+                   exclude_idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        val = val.to(device=self.device, dtype=torch.float32).contiguous()
+        idx = idx.to(device=self.device, dtype=torch.int64).contiguous()
+        nq, m = val.shape
+        ov = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        oi = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        ex = None if exclude_idx is None else exclude_idx.to(device=self.device, dtype=torch.int64).contiguous()
+        self._chk(self.lib.sgpt_topk_merge(self.handle, _p(val), _p(idx), nq, m, k, _p(ex), _p(ov), _p(oi),
+                                           _stream_ptr(self.device)), "sgpt_topk_merge")
+        return ov, oi
+
+    def topk(self, scores: torch.Tensor, k: int, idx_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        """torch.topk(scores, k, dim=1) with NaN -> -1 first (exact_search.py:99-108); sorted descending."""
+        scores = scores.to(device=self.device, dtype=torch.float32)
+        if scores.stride(1) != 1:
+            scores = scores.contiguous()
+        nq, n = scores.shape
+        ov = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        oi = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        self._chk(self.lib.sgpt_topk(self.handle, _p(scores), nq, n, scores.stride(0), k, idx_base, _p(ov), _p(oi),
+                                     _stream_ptr(self.device)), "sgpt_topk")
+        return ov, oi
+
+    # ---- measurement hooks (bench.py) ----
+    def prof_enable(self, on: bool):
+        self._chk(self.lib.sgpt_prof_enable(self.handle, 1 if on else 0), "sgpt_prof_enable")
+
+    def prof_read(self, reset=True):
+        n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
+        self._chk(self.lib.sgpt_prof_read(self.handle, C.byref(n), C.byref(ms), C.byref(fl), 1 if reset else 0),
+                  "sgpt_prof_read")
+        return int(n.value), float(ms.value), float(fl.value)

@@ -1,0 +1,89 @@
+"""SentenceTransformer-style surface (sentence_transformers/SentenceTransformer.py:107-255) over
+the HIP encoder: `encode(sentences, batch_size, ..., normalize_embeddings)` with the reference's
+return-type rules, plus its torch.distributed data-parallel branch (:153-175) re-done with ONE
+equal-size RCCL all-gather instead of the two-step pad-to-max gather of
+util.mismatched_sizes_all_gather (util.py:326-347)."""
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from .model import SGPTModel
+from .runtime import get_context
+from .tokenization import TextPipeline
+
+
+def shard_sizes(n: int, world_size: int) -> List[int]:
+    """Contiguous shard sizes of SentenceTransformer.encode (:159-160)."""
+    return [n // world_size + (1 if r < n % world_size else 0) for r in range(world_size)]
+
+
+def all_gather_rows(local: torch.Tensor, sizes: List[int], group=None) -> torch.Tensor:
+    """All-gather of per-rank row blocks with known sizes: pad to max(sizes) (the sizes are a pure
+    function of (n, world) so no size exchange is needed), one all_gather_into_tensor, trim."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
+
+
+class SentenceTransformerSGPT:
+    """Transformer + Pooling(weightedmean) [+ Normalize] as one module
+    (the assembly of training_nli_v2.py:85-123 / modules.json)."""
+
+    def __init__(self, model: SGPTModel, tokenizer, max_seq_length: int = 300, pooling_mode: str = "weightedmean",
+                 specb: bool = False):
+        self.model = model
+        self.tokenizer = tokenizer
+        self.max_seq_length = max_seq_length
+        self.pooling_mode = pooling_mode
+        self.specb = specb
+        self.pipe = TextPipeline(tokenizer, max_seq_length, specb=specb)
+
+    def get_sentence_embedding_dimension(self) -> int:
+        return self.model.cfg.hidden_size
+
+    def encode(self, sentences: Union[str, List[str]], batch_size: int = 32, show_progress_bar: bool = None,
+               output_value: str = "sentence_embedding", convert_to_numpy: bool = True,
+               convert_to_tensor: bool = False, device: str = None, normalize_embeddings: bool = False,
+               num_proc=None, is_query: bool = True):
+        if convert_to_tensor:
+            convert_to_numpy = False
+        input_was_string = False
+        if isinstance(sentences, str) or not hasattr(sentences, "__len__"):     # :143-146
+            sentences = [sentences]
+            input_was_string = True
+        seqs = self.pipe.batch([str(s).strip() for s in sentences], is_query)
+
+        if output_value == "token_embeddings":                                  # :233-241
+            embs = self.model.token_embeddings(seqs)
+            return embs[0] if input_was_string else embs
+        if output_value != "sentence_embedding":
+            raise ValueError("output_value must be 'sentence_embedding' or 'token_embeddings'")
+
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # data-parallel branch (:153-175): contiguous shards of the length-sorted list
+            order = np.argsort([-len(s) for s in seqs], kind="stable")
+            sizes = shard_sizes(len(seqs), dist.get_world_size())
+            lim = np.cumsum([0] + sizes)
+            r = dist.get_rank()
+            mine = [seqs[i] for i in order[lim[r]: lim[r + 1]]]
+            local = self.model.encode_ids(mine, mode=self.pooling_mode, normalize=normalize_embeddings)
+            gathered = all_gather_rows(local, sizes)
+            emb = torch.empty_like(gathered)
+            emb[torch.from_numpy(order).to(gathered.device)] = gathered          # un-sort (:205)
+        else:
+            emb = self.model.encode_ids(seqs, mode=self.pooling_mode, normalize=normalize_embeddings)
+
+        if convert_to_numpy:
+            emb = emb.cpu().numpy()
+        elif not convert_to_tensor:
+            emb = [e for e in emb]                                               # list of tensors (:207-210)
+        if input_was_string:
+            emb = emb[0]
+        return emb

@@ -1,0 +1,43 @@
+"""Shared helpers for the GPU parity tests (test infrastructure: may import the oracle)."""
+import ast
+import os
+
+import numpy as np
+
+from oracle import sgpt_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(tag):
+    fx = np.load(os.path.join(GOLDEN, f"{tag}.npz"))
+    cfg_kw = ast.literal_eval(str(fx["cfg"]))
+    lens = fx["seq_lens"].tolist()
+    ids, mask = fx["ids"].astype(np.int64), fx["mask"].astype(np.int64)
+    side = str(fx["pad_side"])
+    S = ids.shape[1]
+    seqs = [ids[i, :n].tolist() if side == "right" else ids[i, S - n:].tolist() for i, n in enumerate(lens)]
+    pad_left = [0] * len(lens) if side == "right" else [S - n for n in lens]
+    return fx, cfg_kw, seqs, pad_left, ids, mask
+
+
+_models = {}
+
+
+def build_model(cfg_kw, seed, std, dtype):
+    """SGPTModel on cuda:0 with the oracle's seeded synthetic weights (cached per test session)."""
+    from sgpt_amd import SGPTConfig, SGPTModel
+    key = (repr(sorted(cfg_kw.items())), seed, std, dtype)
+    if key not in _models:
+        w = O.synth_weights(O.NeoConfig(**cfg_kw), seed=seed, std=std)
+        _models[key] = SGPTModel(SGPTConfig(**cfg_kw), w, device="cuda:0", dtype=dtype)
+    return _models[key]
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+def row_cos(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))

@@ -1,0 +1,215 @@
+"""-m gpu: each HIP kernel through the C ABI against the numpy oracle (small sizes) and against a
+plain PyTorch fp32 reference of the same op on the GPU (large sizes)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sgpt_oracle as O
+from helpers import GOLDEN, load_case, maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sgpt_amd import get_context
+    return get_context("cuda:0")
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0").to(dtype)
+
+
+# ---------------------------------------------------------------- GEMM (scores) ----------
+@pytest.mark.parametrize("na,nb,d", [(16, 16, 32), (50, 37, 100), (130, 257, 768), (1, 5, 4), (300, 1000, 2048)])
+def test_scores_fp32_vs_numpy(ctx, na, nb, d):
+    rng = np.random.default_rng(na * 7 + nb)
+    a = rng.standard_normal((na, d)).astype(np.float32)
+    b = rng.standard_normal((nb, d)).astype(np.float32)
+    b[:, 0] += 3.0                                       # asymmetric: catches an output transpose
+    got = ctx.scores(dev(a), dev(b)).cpu().numpy()
+    want = a.astype(np.float64) @ b.astype(np.float64).T
+    assert got.shape == (na, nb)
+    assert maxabs(got, want) < 2e-4 * np.sqrt(d / 100)  # fp32 fma chain vs fp64
+
+
+@pytest.mark.parametrize("na,nb,d", [(16, 16, 64), (130, 257, 768), (77, 1001, 1024)])
+def test_scores_bf16_vs_torch(ctx, na, nb, d):
+    g = torch.Generator(device="cpu").manual_seed(na + nb)
+    a = torch.randn(na, d, generator=g).to(torch.bfloat16).cuda()
+    b = torch.randn(nb, d, generator=g).to(torch.bfloat16).cuda()
+    got = ctx.scores(a, b, dtype=torch.bfloat16)
+    want = a.float() @ b.float().T                       # exact products of bf16 inputs, fp32 accumulate
+    assert torch.max(torch.abs(got - want)).item() < 1e-3 * np.sqrt(d / 64)
+
+
+def test_scores_identity_layout(ctx):
+    """A = I against an asymmetric B (cdna guide: transpose-detecting check)."""
+    n = 128
+    b = (torch.arange(n * 64, dtype=torch.float32).reshape(n, 64) % 97).cuda()
+    eye = torch.eye(64, dtype=torch.float32).cuda()
+    got = ctx.scores(eye, b)                             # [64, n] = B^T
+    assert torch.equal(got, b.T.contiguous())
+    gotb = ctx.scores(eye.to(torch.bfloat16), b.to(torch.bfloat16), dtype=torch.bfloat16)
+    assert torch.equal(gotb, b.T.contiguous())           # small integers are exact in bf16
+
+
+def test_cos_sim_dot_score_golden(ctx):
+    """Reference outputs of util.cos_sim / dot_score / normalize_embeddings (scoring.npz)."""
+    from sgpt_amd import util
+    fx = np.load(f"{GOLDEN}/scoring.npz")
+    assert maxabs(util.cos_sim(fx["a"], fx["b"]).numpy(), fx["cos"]) < 1e-5
+    assert maxabs(util.dot_score(fx["a"], fx["b"]).numpy(), fx["dot"]) < 1e-4
+    assert maxabs(util.normalize_embeddings(torch.from_numpy(fx["a"])).numpy(), fx["nrm"]) < 1e-6
+    assert util.cos_sim(fx["a"][0], fx["b"]).shape == (1, 37)          # 1-D promoted (util.py:35-39)
+    out = util.cos_sim(torch.from_numpy(fx["a"]).cuda(), torch.from_numpy(fx["b"]).cuda())
+    assert out.is_cuda
+
+
+def test_ref_test_util_cos_sim_vs_sklearn(ctx):
+    """sentence-transformers/tests/test_util.py:21-30 on the HIP scorer."""
+    from sklearn.metrics.pairwise import cosine_similarity
+    from sgpt_amd import util
+    rng = np.random.default_rng(1)
+    a, b = rng.standard_normal((50, 100)), rng.standard_normal((50, 100))
+    assert np.abs(cosine_similarity(a, b) - util.pytorch_cos_sim(a, b).numpy()).max() < 1e-3
+
+
+def test_ref_test_util_normalize(ctx):
+    """tests/test_util.py:9-18."""
+    from sgpt_amd import util
+    a = torch.tensor(np.random.default_rng(0).standard_normal((50, 100)))
+    for e in util.normalize_embeddings(a):
+        assert len(e) == 100 and abs(torch.norm(e).item() - 1) < 1e-4
+
+
+# ---------------------------------------------------------------- pooling -----------------
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128"])
+@pytest.mark.parametrize("mode", ["weightedmean", "mean", "lasttoken"])
+def test_pool_golden(ctx, tag, mode):
+    """Reference Pooling.py outputs on HF hidden states (golden), through sgpt_pool."""
+    fx, _, _, _, _, mask = load_case(tag)
+    got = ctx.pool(dev(fx["last_hidden"]), dev(mask, torch.int32), mode).cpu().numpy()
+    assert maxabs(got, fx[f"emb_{mode}"]) < 2e-6
+    assert maxabs(got, O.pool(fx["last_hidden"], mask, mode)) < 2e-6
+
+
+def test_pool_edge_cases(ctx):
+    rng = np.random.default_rng(3)
+    h = rng.standard_normal((5, 33, 772)).astype(np.float32)       # d % 256 != 0, ragged masks
+    mask = np.zeros((5, 33), np.int64)
+    mask[0, :33] = 1; mask[1, :1] = 1; mask[2, 10:20] = 1; mask[3, 32:] = 1       # row 4: all padding
+    for mode in ("weightedmean", "mean"):
+        got = ctx.pool(dev(h), dev(mask, torch.int32), mode).cpu().numpy()
+        assert maxabs(got, O.pool(h, mask, mode)) < 5e-6
+        assert np.all(got[4] == 0)                                   # clamp(1e-9): 0/1e-9 = 0 (Pooling.py:122)
+    hb = torch.from_numpy(h).to(torch.bfloat16)
+    got = ctx.pool(hb.cuda(), dev(mask, torch.int32), "weightedmean").cpu().numpy()
+    assert maxabs(got, O.pool(hb.float().numpy(), mask, "weightedmean")) < 5e-6
+
+
+def test_pool_large_vs_torch(ctx):
+    B, S, d = 256, 128, 768
+    h = torch.randn(B, S, d, device="cuda")
+    lens = torch.randint(1, S + 1, (B,), device="cuda")
+    mask = (torch.arange(S, device="cuda")[None, :] < lens[:, None]).to(torch.int32)
+    w = mask.float() * torch.arange(1, S + 1, device="cuda").float()[None, :]
+    want = (h * w[:, :, None]).sum(1) / w.sum(1, keepdim=True)
+    got = ctx.pool(h, mask, "weightedmean")
+    assert torch.max(torch.abs(got - want)).item() < 1e-5
+
+
+def test_l2_normalize(ctx):
+    x = torch.randn(1000, 768, device="cuda") * 5
+    x[7] = 0
+    got = ctx.l2_normalize(x)
+    want = torch.nn.functional.normalize(x, p=2, dim=1)
+    assert torch.max(torch.abs(got - want)).item() < 1e-6
+    gb = ctx.l2_normalize(x, out_dtype=torch.bfloat16)
+    assert torch.equal(gb, want.to(torch.bfloat16)) or torch.max(torch.abs(gb.float() - want)).item() < 4e-3
+    assert torch.equal(ctx.to_bf16(x), x.to(torch.bfloat16))         # RNE identical to torch
+
+
+# ---------------------------------------------------------------- top-k -------------------
+def _check_topk(val, idx, scores, k, idx_base=0):
+    n = scores.shape[1]
+    kk = min(k, n)
+    order = np.argsort(-scores, axis=1, kind="stable")[:, :kk]
+    want_v = np.take_along_axis(scores, order, axis=1)
+    assert np.array_equal(val[:, :kk], want_v)                       # values bit-exact, sorted descending
+    got_scores = np.take_along_axis(scores, idx[:, :kk] - idx_base, axis=1)
+    assert np.array_equal(got_scores, want_v)                        # indices point at those values
+    assert np.all(val[:, kk:] == -np.inf) and np.all(idx[:, kk:] == -1)
+    for r in range(scores.shape[0]):
+        assert len(set(idx[r, :kk].tolist())) == kk                  # no duplicates
+
+
+@pytest.mark.parametrize("nq,n,k", [(7, 5000, 10), (3, 50000, 1001), (5, 17, 10), (4, 11, 11), (2, 9, 20), (1, 1, 1),
+                                    (9, 4096, 2048)])
+def test_topk_vs_numpy(ctx, nq, n, k):
+    scores = np.random.default_rng(n + k).standard_normal((nq, n)).astype(np.float32)
+    val, idx = ctx.topk(dev(scores), k, idx_base=100)
+    _check_topk(val.cpu().numpy(), idx.cpu().numpy(), scores, k, idx_base=100)
+
+
+def test_topk_ties_and_nan(ctx):
+    scores = np.zeros((3, 300), np.float32)                          # all tied: lowest indices win
+    scores[1, 5] = np.nan                                            # NaN -> -1 (exact_search.py:99)
+    scores[2, ::2] = 1.0
+    val, idx = ctx.topk(dev(scores), 10)
+    val, idx = val.cpu().numpy(), idx.cpu().numpy()
+    assert idx[0].tolist() == list(range(10)) and np.all(val[0] == 0)
+    assert 5 not in idx[1].tolist() and np.all(val[1] == 0)
+    assert idx[2].tolist() == list(range(0, 20, 2)) and np.all(val[2] == 1)
+    s2 = np.full((1, 50), np.nan, np.float32)
+    v2, _ = ctx.topk(dev(s2), 5)
+    assert np.all(v2.cpu().numpy() == -1)
+
+
+def test_topk_merge_and_exclude(ctx):
+    rng = np.random.default_rng(5)
+    val = rng.standard_normal((6, 40)).astype(np.float32)
+    idx = np.stack([rng.permutation(1000)[:40] for _ in range(6)]).astype(np.int64)
+    idx[0, :5] = -1                                                  # empty slots are ignored
+    ex = np.array([-1, idx[1, np.argmax(val[1])], -1, 12345, -1, idx[5, 3]], np.int64)
+    ov, oi = ctx.topk_merge(dev(val), dev(idx, torch.int64), 11, exclude_idx=dev(ex, torch.int64))
+    ov, oi = ov.cpu().numpy(), oi.cpu().numpy()
+    for r in range(6):
+        ok = (idx[r] >= 0) & (idx[r] != ex[r])
+        order = np.argsort(-val[r][ok], kind="stable")[:11]
+        assert np.array_equal(ov[r], val[r][ok][order])
+        assert np.array_equal(oi[r], idx[r][ok][order])
+
+
+# ---------------------------------------------------------------- fused score + top-k -----
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_score_topk_vs_torch(ctx, dtype):
+    nq, N, d, k = 33, 70001, 768, 11                                 # several internal chunks, ragged tail
+    g = torch.Generator(device="cpu").manual_seed(0)
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).cuda()
+    c = torch.nn.functional.normalize(torch.randn(N, d, generator=g), dim=1).cuda()
+    if dtype == torch.bfloat16:
+        q, c = q.to(dtype), c.to(dtype)
+    val, idx, n = ctx.score_topk(q, c, k, idx_base=5, dtype=dtype)
+    assert n == k
+    full = q.float() @ c.float().T
+    wv, wi = torch.topk(full, k, dim=1)
+    tol = 2e-6 if dtype == torch.float32 else 2e-5
+    assert torch.max(torch.abs(val - wv)).item() < tol
+    picked = torch.gather(full, 1, idx - 5)
+    assert torch.max(torch.abs(picked - wv)).item() < tol            # same docs up to fp ties
+    assert (idx[:, 0] - 5 == wi[:, 0]).all()
+
+
+def test_score_topk_running_merge_equals_single_pass(ctx):
+    nq, N, d, k = 8, 3000, 128, 16
+    q = torch.randn(nq, d, device="cuda")
+    c = torch.randn(N, d, device="cuda")
+    v1, i1, _ = ctx.score_topk(q, c, k)
+    run = None
+    for s in range(0, N, 700):
+        v, i, n = ctx.score_topk(q, c[s:s + 700].contiguous(), k, idx_base=s, run=run)
+        run = (v, i, n)
+    assert torch.equal(run[0], v1) and torch.equal(run[1], i1)
+    v3, i3, n3 = ctx.score_topk(q, c[:5].contiguous(), k)           # fewer docs than k
+    assert n3 == 5 and (i3[:, 5:] == -1).all() and torch.isinf(v3[:, 5:]).all()

@@ -1,0 +1,175 @@
+"""-m gpu: the drop-in adapters (DenseRetrievalExactSearch.search, CustomEmbedder, semantic_search,
+SentenceTransformer-style encode, USEB semb_fn) against the reference's golden outputs and the oracle."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sgpt_oracle as O
+from helpers import GOLDEN, build_model, load_case, maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeModel:
+    """The fake encoder make_golden.py fed to the reference's exact_search.py: embeddings by id."""
+
+    def __init__(self, qvec, cvec):
+        self.qvec, self.cvec = qvec, cvec
+
+    def encode_queries(self, qs, batch_size, **kw):
+        return torch.from_numpy(np.stack([self.qvec[qid] for qid, _ in qs]))
+
+    def encode_corpus(self, cs, batch_size, **kw):
+        return np.stack([self.cvec[cid] for cid, _ in cs])           # ndarray: the CustomEmbedder return type
+
+
+@pytest.mark.parametrize("fn", ["cos_sim", "dot"])
+def test_exact_search_matches_reference_golden(fn):
+    """Golden = the reference's DenseRetrievalExactSearch.search output (3 chunks of 256, top_k=10,
+    two queries whose id collides with a corpus id, anisotropic embeddings)."""
+    from sgpt_amd.beir import DenseRetrievalExactSearch
+    fx = np.load(f"{GOLDEN}/scoring.npz")
+    meta = json.loads(str(fx["es_json"]))
+    corpus, qids, topk = meta["corpus"], meta["queries"], meta["top_k"]
+    cvec = {f"d{i}": fx["es_corpus_emb"][i] for i in range(len(corpus))}
+    qvec = {q: fx["es_query_emb"][i] for i, q in enumerate(qids)}
+    s = DenseRetrievalExactSearch(FakeModel(qvec, cvec), batch_size=8, corpus_chunk_size=meta["chunk"])
+    res = s.search(corpus, {q: "q" for q in qids}, topk, fn)
+    want = meta["results"][fn]
+    for qid in qids:
+        assert set(res[qid]) == set(want[qid]), (fn, qid)
+        assert qid not in res[qid] and len(res[qid]) <= topk + 1
+        scale = max(1.0, max(abs(v) for v in want[qid].values()))
+        for c, v in want[qid].items():
+            assert abs(res[qid][c] - v) < 1e-3 * scale
+    with pytest.raises(ValueError) as e:
+        s.search(corpus, {q: "q" for q in qids}, topk, "euclid")
+    assert str(e.value) == meta["bad_fn_msg"]
+
+
+def test_semantic_search_golden_and_ref_test():
+    """util.semantic_search golden (tests/test_util.py:33-53 shapes)."""
+    from sgpt_amd import util
+    fx = np.load(f"{GOLDEN}/scoring.npz")
+    hits = util.semantic_search(torch.from_numpy(fx["ss_q"]), torch.from_numpy(fx["ss_docs"]), top_k=10,
+                                query_chunk_size=5, corpus_chunk_size=17)
+    assert len(hits) == 20 and len(hits[0]) == 10
+    got_idx = np.array([[h["corpus_id"] for h in r] for r in hits])
+    got_val = np.array([[h["score"] for h in r] for r in hits])
+    assert np.array_equal(got_idx, fx["ss_idx"])
+    assert maxabs(got_val, fx["ss_val"]) < 1e-3
+    # custom score function path
+    hits2 = util.semantic_search(fx["ss_q"], fx["ss_docs"], top_k=3, corpus_chunk_size=400,
+                                 score_function=lambda a, b: -util.dot_score(a, b))
+    want = O.semantic_search(fx["ss_q"], fx["ss_docs"], top_k=3, corpus_chunk_size=400,
+                             score_function=lambda a, b: -O.dot_score(a, b))
+    assert [[h["corpus_id"] for h in r] for r in hits2] == [[h["corpus_id"] for h in r] for r in want]
+
+
+def _texts(rng, n, lo, hi):
+    words = ["alpha", "beta", "gamma", "delta", "query", "doc", "paris", "atom", "cell", "gene", "?", "the", "of"]
+    return [" ".join(rng.choice(words, size=int(rng.integers(lo, hi))).tolist()) for _ in range(n)]
+
+
+def test_custom_embedder_and_search_end_to_end_vs_oracle(tmp_path, monkeypatch):
+    """text -> SyntheticTokenizer -> specb brackets -> encode -> cosine top-k through the reference API
+    names, against the oracle run on the identical ids/weights (fp32 mode, tolerance 1e-3)."""
+    from sgpt_amd.beir import CustomEmbedder, DenseRetrievalExactSearch
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    monkeypatch.chdir(tmp_path)
+    fx, cfg_kw, *_ = load_case("tiny_right")
+    seed, std = int(fx["seed"]), float(fx["std"])
+    m = build_model(cfg_kw, seed, std, "fp32")
+    tok = SyntheticTokenizer(cfg_kw["vocab_size"])
+    emb = CustomEmbedder(model_name="synthetic/tiny-neo", model=m, tokenizer=tok, method="weightedmean", specb=True,
+                         maxseqlen=40, dataset="unit")
+    rng = np.random.default_rng(9)
+    corpus = {f"d{i}": {"title": t.split(" ")[0], "text": t} for i, t in enumerate(_texts(rng, 150, 3, 60))}
+    queries = {f"q{i}": t for i, t in enumerate(_texts(rng, 9, 2, 8))}
+    queries["d3"] = "gene cell ?"                                      # id collides with a corpus id
+    res = DenseRetrievalExactSearch(emb, corpus_chunk_size=64).search(corpus, queries, 5, "cos_sim")
+
+    # oracle on the same ids
+    cfg = O.NeoConfig(**cfg_kw)
+    w = O.synth_weights(cfg, seed=seed, std=std)
+    ids_of = lambda t, q: O.specb_wrap(tok.convert_tokens_to_ids(tok.tokenize(t.replace("\n", " "))), q, 38)  # noqa
+    cids = sorted(corpus, key=lambda k: len(corpus[k]["title"] + corpus[k]["text"]), reverse=True)
+    cemb = O.encode(w, cfg, [ids_of((corpus[c]["title"] + " " + corpus[c]["text"]).strip(), False) for c in cids])
+    qemb = O.encode(w, cfg, [ids_of(queries[q], True) for q in queries])
+    want = O.exact_search(qemb, list(queries), cemb, cids, 5, "cos_sim", chunk_size=64)
+    for qid in queries:
+        assert "d3" not in res["d3"]
+        # order-insensitive id-set parity except where the boundary scores tie within tolerance
+        common = set(res[qid]) & set(want[qid])
+        assert len(common) >= len(want[qid]) - 1
+        for c in common:
+            assert abs(res[qid][c] - want[qid][c]) < 1e-3
+    # encode_queries / encode_corpus return row-aligned ndarrays (beir_dense_retriever.py:316-348)
+    qarr = emb.encode_queries([(q, queries[q]) for q in queries], batch_size=4)
+    assert isinstance(qarr, np.ndarray) and qarr.shape == (len(queries), cfg.hidden_size)
+    assert maxabs(qarr, qemb) < 1e-3
+    carr = emb.encode_corpus([(c, corpus[c]) for c in cids[:7]], batch_size=4, batch_num=0)
+    assert maxabs(carr, cemb[:7]) < 1e-3
+    # other pooling methods of the adapter
+    for method in ("mean", "lasttoken", "meanmean", "lasttokenmean"):
+        e2 = CustomEmbedder(model_name="synthetic/tiny-neo", model=m, tokenizer=tok, method=method, dataset="unit")
+        seqs = [tok.convert_tokens_to_ids(tok.tokenize(queries[q])) for q in queries]
+        got = e2.embed_device([queries[q] for q in queries], True).cpu().numpy()
+        assert maxabs(got, O.encode(w, cfg, seqs, mode=method)) < 1e-3, method
+
+
+def test_embedding_pickle_cache_roundtrip(tmp_path, monkeypatch):
+    """--saveemb cache format {id: ndarray} (beir_dense_retriever.py:311-312,319-323)."""
+    import pickle
+    from sgpt_amd.beir import CustomEmbedder
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    monkeypatch.chdir(tmp_path)
+    fx, cfg_kw, *_ = load_case("tiny_right")
+    m = build_model(cfg_kw, int(fx["seed"]), float(fx["std"]), "fp32")
+    emb = CustomEmbedder(model_name="synthetic/tiny-neo", model=m, tokenizer=SyntheticTokenizer(cfg_kw["vocab_size"]),
+                         method="weightedmean", dataset="cache", save_emb=True)
+    qs = [("a", "alpha beta"), ("b", "gamma")]
+    first = emb.encode_queries(qs, batch_size=2)
+    cache = pickle.load(open("embeddings/tiny-neo/weightedmean/cache_queries.pickle", "rb"))
+    assert set(cache) == {"a", "b"} and np.array_equal(cache["a"], first[0])
+    assert np.array_equal(emb.encode_queries(list(reversed(qs)), batch_size=2), first[::-1])   # served from cache
+
+
+def test_st_encode_and_useb_semb_fn():
+    from sgpt_amd.st import SentenceTransformerSGPT
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    from sgpt_amd.useb import CustomEmbedder as UsebEmbedder, make_semb_fn
+    from sgpt_amd.beir import SentenceBERTBOSEOS
+    fx, cfg_kw, *_ = load_case("tiny_right")
+    seed, std = int(fx["seed"]), float(fx["std"])
+    m = build_model(cfg_kw, seed, std, "fp32")
+    cfg = O.NeoConfig(**cfg_kw)
+    w = O.synth_weights(cfg, seed=seed, std=std)
+    tok = SyntheticTokenizer(cfg_kw["vocab_size"])
+    st = SentenceTransformerSGPT(m, tok, max_seq_length=50)
+    sents = ["alpha beta gamma", "the cell of gene ?", "paris"]
+    want = O.encode(w, cfg, [tok.convert_tokens_to_ids(tok.tokenize(s)) for s in sents])
+    out = st.encode(sents, batch_size=2)
+    assert isinstance(out, np.ndarray) and maxabs(out, want) < 1e-3
+    one = st.encode("paris")
+    assert one.shape == (cfg.hidden_size,) and maxabs(one, want[2]) < 1e-3          # single string -> 1-D
+    t = st.encode(sents, convert_to_tensor=True, normalize_embeddings=True)
+    assert isinstance(t, torch.Tensor) and maxabs(t.cpu().numpy(), O.normalize(want)) < 1e-3
+    lst = st.encode(sents, convert_to_numpy=False)
+    assert isinstance(lst, list) and len(lst) == 3
+    tokemb = st.encode(sents, output_value="token_embeddings")
+    assert [e.shape[0] for e in tokemb] == [3, 5, 1]
+    # USEB closure: torch.Tensor[len, d] on the CPU (useb_dense_retriever.py:455-497)
+    fn = make_semb_fn(UsebEmbedder(m, tok, method="weightedmean"))
+    r = fn(sents, dataset_name="askubuntu", add_name="", idx=0)
+    assert isinstance(r, torch.Tensor) and not r.is_cuda and maxabs(r.numpy(), want) < 1e-3
+    # --usest --specb adapter: brackets on ids, upstream-DRES input conventions
+    sb = SentenceBERTBOSEOS(model=m, tokenizer=tok, specb=True, max_seq_length=50)
+    q = sb.encode_queries(["alpha beta gamma"], convert_to_tensor=True)
+    wq = O.encode(w, cfg, [O.specb_wrap(tok.convert_tokens_to_ids(tok.tokenize("alpha beta gamma")), True)])
+    assert maxabs(q.cpu().numpy(), wq) < 1e-3
+    dd = sb.encode_corpus([{"title": "paris", "text": "the cell"}])
+    wd = O.encode(w, cfg, [O.specb_wrap(tok.convert_tokens_to_ids(tok.tokenize("paris the cell")), False)])
+    assert maxabs(dd, wd) < 1e-3
