@@ -183,6 +183,12 @@ sgpt_status sgpt_topk(sgpt_ctx* ctx, const float* scores, int32_t nq, int64_t n,
 sgpt_status sgpt_prof_enable(sgpt_ctx* ctx, int32_t on);
 sgpt_status sgpt_prof_read(sgpt_ctx* ctx, int64_t* launches, double* ms, double* flops, int32_t reset);
 
+/* Micro-benchmark of one GEMM launch configuration (library-owned pseudo-random operands, never
+ * zeros): average milliseconds per launch over `iters` launches.  epi: 0 store, 1 bias+gelu,
+ * 2 bias+residual, 3 score, 4 V^T store (see sgpt_amd/csrc/common.h GemmEpi). */
+sgpt_status sgpt_bench_gemm(sgpt_ctx* ctx, int32_t dtype, int32_t epi, int32_t out_dtype,
+                            int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

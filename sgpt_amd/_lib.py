@@ -48,6 +48,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgpt_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64,
                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgpt_bench_gemm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.POINTER(C.c_float)]),
     "sgpt_prof_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "sgpt_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.c_int32]),

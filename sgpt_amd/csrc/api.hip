@@ -453,4 +453,38 @@ sgpt_status sgpt_topk(sgpt_ctx* c, const float* scores, int32_t nq, int64_t n, i
     return SGPT_OK;
 }
 
+
+sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out_dtype, int32_t M, int32_t N, int32_t K,
+                            int32_t iters, float* ms_out) {
+    if (!c || !ms_out || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_bench_gemm: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t esz = dtype == SGPT_BF16 ? 2 : 4, osz = out_dtype == SGPT_BF16 ? 2 : 4;
+    void *A = nullptr, *W = nullptr, *O = nullptr; float* bias = nullptr;
+    HIPC(c, hipMalloc(&A, (size_t)M * K * esz));
+    HIPC(c, hipMalloc(&W, (size_t)N * K * esz));
+    HIPC(c, hipMalloc(&O, (size_t)M * N * (epi == EPI_BIAS_RESID ? 4 : osz) + 4096));
+    HIPC(c, hipMalloc((void**)&bias, (size_t)N * 4));
+    launch_fill_rand(A, (long)M * K, dtype, 1u, 1.0f, 0);
+    launch_fill_rand(W, (long)N * K, dtype, 2u, 0.05f, 0);
+    launch_fill_rand(bias, N, 0, 3u, 0.1f, 0);
+    launch_fill_rand(O, (long)M * N, epi == EPI_BIAS_RESID ? 0 : out_dtype, 4u, 1.0f, 0);
+    GemmArgs g{};
+    g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.m_valid = M; g.N = N; g.K = K; g.out = O;
+    g.ldo = epi == EPI_VT ? M : N; g.bias = bias; g.resid = epi == EPI_BIAS_RESID ? (const float*)O : nullptr;
+    hipEvent_t e0, e1;
+    HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_gemm(dtype, epi, out_dtype, g, 0);
+    HIPC(c, hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) launch_gemm(dtype, epi, out_dtype, g, 0);
+    HIPC(c, hipEventRecord(e1, 0));
+    HIPC(c, hipEventSynchronize(e1));
+    float ms = 0;
+    HIPC(c, hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(A); hipFree(W); hipFree(O); hipFree(bias);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
 }  // extern "C"

@@ -40,6 +40,13 @@ __device__ __forceinline__ float gelu_new(float u) {
     return 0.5f * u * (1.0f + tanhf(t));
 }
 
+// bf16 path: 0.5u(1+tanh(t)) == u * sigmoid(2t); one v_exp_f32 + one v_rcp_f32 instead of tanhf
+__device__ __forceinline__ float gelu_new_fast(float u) {
+    const float c2 = 2.0f * 0.7978845608028654f;
+    const float t2 = c2 * (u + 0.044715f * u * u * u);
+    return u * __frcp_rn(1.0f + __expf(-t2));
+}
+
 // ---- launch descriptors shared between the .hip translation units and api.cpp ----
 enum GemmEpi {
     EPI_STORE = 0,        // out[m][n] = acc                          (row-major, OutT)
@@ -89,6 +96,7 @@ void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, i
 void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s);
 void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s);
 void launch_fill_f32(float* p, long n, float v, hipStream_t s);
+void launch_fill_rand(void* p, long n, int dtype, unsigned seed, float scale, hipStream_t s);
 
 // top-k: one block per query row over a virtual row = [scores(n) | prev(n_prev)]
 void launch_topk_select(const float* scores, long ld, long n, long idx_base, const float* prev_val,

@@ -217,6 +217,18 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
+// deterministic pseudo-random fill in [-scale, scale) (micro-benchmarks: never time MFMA on zeros, DVFS)
+template <typename T>
+__global__ __launch_bounds__(256) void fill_rand_kernel(T* __restrict__ p, long n, unsigned seed, float scale) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        unsigned h = (unsigned)i * 2654435761u ^ seed;
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        const float v = ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
+        if constexpr (sizeof(T) == 4) p[i] = v; else p[i] = f32_to_bf16(v);
+    }
+}
+
 inline int cap_grid(long blocks) { return (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks)); }
 
 }  // namespace
@@ -277,4 +289,11 @@ void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s) {
 
 void launch_fill_f32(float* p, long n, float v, hipStream_t s) {
     hipLaunchKernelGGL(fill_kernel, dim3(cap_grid((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+}
+
+void launch_fill_rand(void* p, long n, int dtype, unsigned seed, float scale, hipStream_t s) {
+    if (dtype == 1)
+        hipLaunchKernelGGL(fill_rand_kernel<bf16_t>, dim3(cap_grid((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)p, n, seed, scale);
+    else
+        hipLaunchKernelGGL(fill_rand_kernel<float>, dim3(cap_grid((n + 255) / 256)), dim3(256), 0, s, (float*)p, n, seed, scale);
 }

@@ -21,6 +21,8 @@
 //   * SWAP=true feeds the weight fragment as the MFMA A-operand, so a lane ends up with
 //     4 consecutive n for one m: row-major stores are 8 B (bf16) / 16 B (fp32) per lane.
 //     SWAP=false gives 4 consecutive m for one n: used for the transposed V^T store.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -70,10 +72,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
     const int M = p.M, N = p.N, K = p.K;
     const int MT = (M + BM - 1) / BM, NT = (N + BN - 1) / BN;
-    // XCD-aware order (block b runs on XCD b%8): XCD x owns M-tiles x, x+8, ...
+    // XCD-aware supertile order (block b runs on XCD b%8, ~64 blocks resident per XCD):
+    // XCD x owns M-tiles x, x+8, ...; its blocks walk GM x GN supertiles so the ~64 co-resident
+    // blocks share GM activation panels and GN weight panels (<= 16 x 192 KiB, fits the 4 MiB L2).
     const int b = blockIdx.x;
     const int xcd = b & 7, local = b >> 3;
-    const int mt = xcd + 8 * (local / NT), nt = local % NT;
+    constexpr int GM = 8, GN = 8;
+    const int per_band = GM * NT;              // blocks per band of GM M-tiles
+    const int band = local / per_band, inb = local % per_band;
+    const int ng = inb / (GM * GN);            // N-group inside the band
+    const int gn = (NT - ng * GN) < GN ? (NT - ng * GN) : GN;   // width of this N-group
+    const int r = inb - ng * GM * GN;
+    const int mi = r / gn, ni = r % gn;
+    const int mt = xcd + 8 * (band * GM + mi), nt = ng * GN + ni;
     if (mt >= MT) return;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 }
                 if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_new(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = sizeof(T) == 2 ? gelu_new_fast(v[r]) : gelu_new(v[r]);
                 }
                 if constexpr (EPI == EPI_BIAS_RESID) {
                     const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
@@ -221,10 +232,165 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4, 128x64 per wave), bf16 only: the throughput kernel of the encoder.
+// Why not the 128^2 kernel above: per k-step it moves 64 KiB LDS->VGPR plus 32 KiB VGPR->LDS
+// (ds_write_b128 ~79 B/clk) = ~660 LDS cycles against 512 MFMA cycles: LDS-bound by construction.
+// Here the per-wave tile doubles (LDS reads per FLOP x0.75), the block tile quadruples (fills
+// per FLOP x0.5) and the fill is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
+// ds_write).  The DMA writes LDS lane-linearly, so the 16-B chunk swizzle (chunk ^ row&7) is
+// applied on the per-lane SOURCE address and again on the fragment read (cdna guide rule 21).
+// Two LDS stages of 64 KiB; the DMA of k-step k+1 is in flight during the MFMAs of k-step k.
+template <int EPI, typename OutT, bool SWAP>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
+    typedef __attribute__((address_space(3))) char* lds_cptr_t;
+    constexpr int TM = 256, TN = 256;
+    __shared__ __attribute__((aligned(16))) uint4 lds[2][2][TM * CH];  // 128 KiB
+
+    const int N = p.N, K = p.K;
+    const int MT = p.M / TM, NT = N / TN;
+    // XCD-aware supertiles (32 resident blocks per XCD): 4 M-tiles x 8 N-tiles
+    const int b = blockIdx.x;
+    const int xcd = b & 7, local = b >> 3;
+    constexpr int GM = 4, GN = 8;
+    const int per_band = GM * NT;
+    const int band = local / per_band, inb = local % per_band;
+    const int ng = inb / (GM * GN);
+    const int gn = (NT - ng * GN) < GN ? (NT - ng * GN) : GN;
+    const int r = inb - ng * GM * GN;
+    const int mt = xcd + 8 * (band * GM + r / gn), nt = ng * GN + r % gn;
+    if (mt >= MT) return;
+    const int m0 = mt * TM, n0 = nt * TN;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, g = lane >> 4;
+
+    // LDS-DMA: wave w fills rows [32w, 32w+32) of both operands, 8 rows (1 KiB) per instruction.
+    // lane l -> LDS (row 8q + (l>>3), slot l&7) <- global chunk (l&7)^(l>>3) of that row.
+    const bf16_t* __restrict__ Ag = static_cast<const bf16_t*>(p.A);
+    const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(p.W);
+    const int lrow = wave * 32 + (lane >> 3);
+    const int lchunk = (lane & 7) ^ (lane >> 3);
+    const bf16_t* asrc = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
+    const bf16_t* wsrc = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
+    const long astep = 8 * p.lda, wstep = 8 * p.ldw;
+
+    // Inline asm, not __builtin_amdgcn_global_load_lds: hipcc treats the builtin as an LDS store and
+    // drains it (s_waitcnt vmcnt(0)) in front of the very next ds_read, which would serialise the
+    // DMA of k-step k+1 with the MFMAs of k-step k.  The asm form is invisible to that pass; its
+    // completion is waited for by hand (vmcnt(0) + barrier at the top of the next iteration).
+    // M0 = wave-uniform LDS byte address of the 1-KiB destination (saved/restored: compiler-reserved).
+    const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0][0][0]);
+    auto dma16 = [&](const bf16_t* src, unsigned dst_byte) {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(dst_byte);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(dst)
+                     : "memory");
+    };
+    auto issue = [&](int kt, int st) {
+        const int kc = kt * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned row_off = (unsigned)((wave * 32 + q * 8) * CH * 16);
+            dma16(asrc + q * astep + kc, lds_base + (unsigned)((st * 2 + 0) * TM * CH * 16) + row_off);
+            dma16(wsrc + q * wstep + kc, lds_base + (unsigned)((st * 2 + 1) * TM * CH * 16) + row_off);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int st) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[8], wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + fr;
+                wf[j] = lds[st][1][row * CH + ((4 * ks + g) ^ (row & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wm * 128 + i * 16 + fr;
+                af[i] = lds[st][0][row * CH + ((4 * ks + g) ^ (row & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma<bf16_t, SWAP>(acc[i][j], af[i], wf[j]);
+        }
+    };
+
+    const int nk = K / 64;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of k-step kt has landed
+        __syncthreads();                                   // everyone's has; stage (kt+1)&1 is free again
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
+    }
+
+    // ---------------- epilogue (same lane maps as the 128^2 kernel) ----------------
+    OutT* __restrict__ out = static_cast<OutT*>(p.out);
+    if constexpr (SWAP) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wm * 128 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + 4 * g;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_new_fast(v[e]);
+                }
+                if constexpr (EPI == EPI_BIAS_RESID) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
+                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                }
+                store4<OutT>(out + (long)m * p.ldo + n, v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + wm * 128 + i * 16 + 4 * g;
+                store4<OutT>(out + (long)n * p.ldo + m, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+    }
+}
+
+template <int EPI, typename OutT, bool SWAP>
+void launch256(const GemmArgs& a, hipStream_t s) {
+    const int MT = a.M / 256, NT = a.N / 256;
+    const int mt_per_xcd = (MT + 7) / 8;
+    const int bands = (mt_per_xcd + 3) / 4;
+    const int grid = 8 * bands * 4 * NT;
+    hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, SWAP>), dim3(grid), dim3(512), 0, s, a);
+}
+
 template <typename T, int EPI, typename OutT, bool SWAP>
 void launch(const GemmArgs& a, hipStream_t s) {
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
-    const int grid = ((MT + 7) / 8) * 8 * NT;
+    const int mt_per_xcd = (MT + 7) / 8;
+    const int bands = (mt_per_xcd + 7) / 8;
+    const int grid = 8 * bands * 8 * NT;
     hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP>), dim3(grid), dim3(256), 0, s, a);
 }
 
@@ -232,6 +398,13 @@ void launch(const GemmArgs& a, hipStream_t s) {
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     const bool bf = dtype == 1, obf = out_dtype == 1;
+    static const bool use256 = getenv("SGPT_GEMM128") == nullptr;
+    if (bf && use256 && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.m_valid == a.M) {
+        if (epi == EPI_STORE && obf) return launch256<EPI_STORE, bf16_t, true>(a, s);
+        if (epi == EPI_VT) return launch256<EPI_VT, bf16_t, false>(a, s);
+        if (epi == EPI_BIAS_GELU) return launch256<EPI_BIAS_GELU, bf16_t, true>(a, s);
+        if (epi == EPI_BIAS_RESID) return launch256<EPI_BIAS_RESID, float, true>(a, s);
+    }
     if (bf) {
         if (epi == EPI_STORE && obf) return launch<bf16_t, EPI_STORE, bf16_t, true>(a, s);
         if (epi == EPI_STORE && !obf) return launch<bf16_t, EPI_STORE, float, true>(a, s);

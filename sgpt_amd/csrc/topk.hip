@@ -2,11 +2,22 @@
 // custommodels/exact_search.py:102-108 plus the heapq.nlargest merge of :121-132.
 //
 // One 256-thread workgroup per query scans a VIRTUAL row = [chunk scores (n) | previous best
-// (n_prev)]: 4 radix passes (8 bits each, LDS histogram, MSB first) on the order-preserving
-// uint32 image of the fp32 score find the exact k-th largest key; a final pass gathers every
-// element above it plus the lowest-index ties, and the k survivors are bitonic-sorted in LDS
-// (descending score, ascending index) so the output is deterministic.  The row is re-read
-// 5x from L2 / Infinity Cache (the score chunk is sized to stay on-die by the caller).
+// (n_prev)].  Output: the k best, sorted by descending score, ties by ascending index
+// (deterministic), unused tail (-inf, -1).
+//
+//   fast path (k <= 128, row >= 4096): ONE pass.  A strided 1024-element sample is bitonic-sorted
+//     in LDS; its k-th largest value tau is a lower bound of the row's k-th largest, so every
+//     element >= tau (expected k*row/1024 of them) is appended to an LDS candidate list (rare LDS
+//     atomics), and the k best are the head of the sorted candidate list.  Falls back to the radix
+//     path if the list overflows (adversarial order / massive ties).
+//   radix path: 4 passes of 8 bits (MSB first) over the order-preserving uint32 image of the fp32
+//     score find the exact k-th largest key.  Scores cluster in a few exponent/mantissa bins, so
+//     histogram updates are wave-aggregated (ballot-peel the 4 most common digits of the wave, one
+//     LDS atomic each; only the stragglers issue their own).  A gather pass collects the elements
+//     above the threshold; ties AT the threshold are taken in ascending position by a parallel
+//     count + prefix-sum pass.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -17,15 +28,27 @@ __device__ __forceinline__ uint32_t f2key(float f) {  // ascending uint order ==
 }
 
 constexpr int TK_THREADS = 256;
-constexpr int TK_SORT_MAX = 2048;  // k <= 2048 sorted in LDS (the driver's k+1 = 1001 fits)
+constexpr int TK_SORT_MAX = 2048;   // k <= 2048 sorted in LDS (the driver's k+1 = 1001 fits)
+constexpr int TK_SAMPLE = 1024;
+constexpr int TK_FAST_KMAX = 128;
+constexpr long TK_FAST_MIN_ROW = 4096;
 
 struct Row {
     const float* sc; long n; long idx_base;
     const float* pv; const int64_t* pi; int n_prev; int nan_to_m1; int64_t excl;
     __device__ __forceinline__ long total() const { return n + n_prev; }
+    // Both legs are always addressed in-bounds (clamped index, never-null base): hipcc may hoist /
+    // speculate these loads out of their guards (seen: pi[i-n] issued for i < n with pi == nullptr).
     __device__ __forceinline__ float val(long i) const {
-        float v = i < n ? sc[i] : pv[i - n];
-        if (i >= n && (pi[i - n] < 0 || pi[i - n] == excl)) v = -INFINITY;  // empty slot / excluded (self) id
+        const bool isp = i >= n;
+        const long j = isp ? i - n : 0;
+        float v;
+        if (isp) {
+            const int64_t id = pi[j];
+            v = (id < 0 || id == excl) ? -INFINITY : pv[j];   // empty slot / excluded (self) id
+        } else {
+            v = sc[i];
+        }
         if (nan_to_m1 && v != v) v = -1.0f;                   // exact_search.py:99
         return v;
     }
@@ -36,45 +59,122 @@ struct Row {
     }
 };
 
-__global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* __restrict__ scores, long ld, long n,
-                                                                long idx_base, const float* __restrict__ prev_val,
-                                                                const int64_t* __restrict__ prev_idx, int n_prev,
-                                                                long prev_ld, int k, int nan_to_m1,
-                                                                const int64_t* __restrict__ exclude_idx,
-                                                                float* __restrict__ out_val,
-                                                                int64_t* __restrict__ out_idx) {
+__device__ __forceinline__ bool sorts_before(float va, int64_t ia, float vb, int64_t ib) {
+    return va > vb || (va == vb && ia < ib);
+}
+
+// in-LDS bitonic sort of np2 (power of two) entries: descending value, ascending index
+template <bool WITH_IDX>
+__device__ __forceinline__ void bitonic_desc(float* s_val, int64_t* s_idx, int np2, int t) {
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = t; i < np2; i += TK_THREADS) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool up = (i & size) == 0;  // this run ends in final (descending) order
+                    const float va = s_val[i], vb = s_val[j];
+                    const int64_t ia = WITH_IDX ? s_idx[i] : 0, ib = WITH_IDX ? s_idx[j] : 0;
+                    const bool swap = up ? sorts_before(vb, ib, va, ia) : sorts_before(va, ia, vb, ib);
+                    if (swap) {
+                        s_val[i] = vb; s_val[j] = va;
+                        if (WITH_IDX) { s_idx[i] = ib; s_idx[j] = ia; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// wave-aggregated histogram update: peel up to 4 distinct digits with ballots, rest by plain atomics
+__device__ __forceinline__ void hist_add(unsigned* hist, bool match, unsigned dgt, int lane) {
+    unsigned long long todo = __ballot(match);
+#pragma unroll 1
+    for (int it = 0; it < 4 && todo; ++it) {
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)dgt, leader);
+        const unsigned long long same = __ballot(match && dgt == d0) & todo;
+        if (lane == leader) atomicAdd(&hist[d0 & 0xff], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&hist[dgt & 0xff], 1u);
+}
+
+__global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* scores, long ld, long n, long idx_base,
+                                                                const float* prev_val, const int64_t* prev_idx,
+                                                                int n_prev, long prev_ld, int k, int nan_to_m1,
+                                                                const int64_t* exclude_idx, float* out_val,
+                                                                int64_t* out_idx) {
     __shared__ unsigned hist[256];
-    __shared__ unsigned sh_prefix, sh_krem, sh_cnt_gt, sh_cnt_eq;
+    __shared__ unsigned sh_prefix, sh_krem, sh_cnt;
     __shared__ float s_val[TK_SORT_MAX];
     __shared__ int64_t s_idx[TK_SORT_MAX];
 
-    const int qrow = blockIdx.x, t = threadIdx.x;
-    Row r{scores + (long)qrow * ld, n, idx_base, prev_val ? prev_val + (long)qrow * prev_ld : nullptr,
-          prev_idx ? prev_idx + (long)qrow * prev_ld : nullptr, prev_val ? n_prev : 0, nan_to_m1,
-          exclude_idx ? exclude_idx[qrow] : (int64_t)-1};
+    const int qrow = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    // no previous list: alias the prev pointers to valid memory (n_prev = 0, never selected)
+    const bool has_prev = prev_val != nullptr && prev_idx != nullptr && n_prev > 0;
+    Row r{scores + (long)qrow * ld, n, idx_base,
+          has_prev ? prev_val + (long)qrow * prev_ld : scores,
+          has_prev ? prev_idx + (long)qrow * prev_ld : reinterpret_cast<const int64_t*>(out_idx),
+          has_prev ? n_prev : 0, nan_to_m1, exclude_idx ? exclude_idx[qrow] : (int64_t)-1};
     const long total = r.total();
     float* ov = out_val + (long)qrow * k;
     int64_t* oi = out_idx + (long)qrow * k;
     const int kk = total < k ? (int)total : k;  // number of real outputs
+    const bool in_lds = k <= TK_SORT_MAX;
+    int n_sorted = kk;                           // entries of s_val/s_idx to sort at the end
 
+    bool done = false;
     if (total <= k) {  // everything survives
         for (long i = t; i < k; i += TK_THREADS) {
             const bool ok = i < total;
-            const float v = ok ? r.val(i) : -INFINITY;
-            const int64_t id = ok ? r.idx(i) : -1;
-            if (k <= TK_SORT_MAX) { s_val[i] = v; s_idx[i] = id; } else { ov[i] = v; oi[i] = id; }
+            const float v = ok ? r.val(ok ? i : 0) : -INFINITY;
+            const int64_t id = ok ? r.idx(ok ? i : 0) : -1;
+            if (in_lds) { s_val[i] = v; s_idx[i] = id; } else { ov[i] = v; oi[i] = id; }
         }
-    } else {
-        // ---- radix select: find key of the k-th largest ----
+        done = true;
+    } else if (k <= TK_FAST_KMAX && total >= TK_FAST_MIN_ROW) {
+        // ---------------- fast path: sample threshold + one pass ----------------
+        const long stride = total / TK_SAMPLE;
+        for (int s = t; s < TK_SAMPLE; s += TK_THREADS) s_val[s] = r.val((long)s * stride);
+        if (t == 0) sh_cnt = 0;
+        __syncthreads();
+        bitonic_desc<false>(s_val, s_idx, TK_SAMPLE, t);
+        const float tau = s_val[k - 1];
+        __syncthreads();
+        if (tau > -INFINITY) {
+            for (long i0 = 0; i0 < total; i0 += TK_THREADS) {
+                const long i = i0 + t;
+                if (i < total) {
+                    const float v = r.val(i);
+                    if (v >= tau) {
+                        const unsigned slot = atomicAdd(&sh_cnt, 1u);
+                        if (slot < TK_SORT_MAX) { s_val[slot] = v; s_idx[slot] = r.idx(i); }
+                    }
+                }
+            }
+            __syncthreads();
+            const unsigned cnt = sh_cnt;
+            if (cnt <= TK_SORT_MAX) {   // cnt >= k always: the sample's k best are >= tau
+                n_sorted = (int)cnt;
+                done = true;
+            }
+        }
+        __syncthreads();
+    }
+    if (!done) {
+        // ---------------- radix select: key of the k-th largest ----------------
         unsigned prefix = 0, krem = (unsigned)k;
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 24 - 8 * pass;
             hist[t] = 0;
             __syncthreads();
             const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            for (long i = t; i < total; i += TK_THREADS) {
-                const uint32_t key = f2key(r.val(i));
-                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+            for (long i0 = 0; i0 < total; i0 += TK_THREADS) {
+                const long i = i0 + t;
+                const bool act = i < total;
+                const uint32_t key = f2key(r.val(act ? i : 0));
+                hist_add(hist, act && (key & himask) == prefix, (key >> shift) & 0xff, lane);
             }
             __syncthreads();
             if (t == 0) {
@@ -94,72 +194,49 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* __
             __syncthreads();
         }
         const uint32_t thr = prefix;  // exact key of the k-th largest; krem = how many == thr to keep
-        // ---- gather: all > thr, then the krem lowest-index == thr ----
-        if (t == 0) { sh_cnt_gt = 0; sh_cnt_eq = 0; }
-        __syncthreads();
         const unsigned n_gt = (unsigned)k - krem;
-        // ties: deterministic lowest-index choice needs an ordered scan; ties at the threshold are
-        // rare, so thread 0 resolves them serially only when there are more ties than slots.
+        // ---- gather everything above the threshold ----
+        if (t == 0) sh_cnt = 0;
+        __syncthreads();
         for (long i = t; i < total; i += TK_THREADS) {
             const float v = r.val(i);
-            const uint32_t key = f2key(v);
-            if (key > thr) {
-                const unsigned slot = atomicAdd(&sh_cnt_gt, 1u);
-                if (k <= TK_SORT_MAX) { s_val[slot] = v; s_idx[slot] = r.idx(i); } else { ov[slot] = v; oi[slot] = r.idx(i); }
-            } else if (key == thr) {
-                atomicAdd(&sh_cnt_eq, 1u);
+            if (f2key(v) > thr) {
+                const unsigned slot = atomicAdd(&sh_cnt, 1u);
+                if (in_lds) { s_val[slot] = v; s_idx[slot] = r.idx(i); } else { ov[slot] = v; oi[slot] = r.idx(i); }
             }
         }
+        // ---- ties at the threshold: the krem lowest positions, in parallel ----
+        // thread t owns the contiguous range [t*per, (t+1)*per): count, exclusive scan, emit
+        const long per = (total + TK_THREADS - 1) / TK_THREADS;
+        const long lo = (long)t * per, hi = (lo + per) < total ? (lo + per) : total;
+        unsigned mine = 0;
+        for (long i = lo; i < hi; ++i) mine += f2key(r.val(i)) == thr ? 1u : 0u;
+        hist[t] = mine;
         __syncthreads();
-        const unsigned n_eq = sh_cnt_eq;
+        if (t == 0) {
+            unsigned run = 0;
+            for (int q = 0; q < TK_THREADS; ++q) { const unsigned c = hist[q]; hist[q] = run; run += c; }
+        }
         __syncthreads();
-        if (n_eq == krem) {  // common case: take every tie
-            if (t == 0) sh_cnt_eq = 0;
-            __syncthreads();
-            for (long i = t; i < total; i += TK_THREADS) {
-                const float v = r.val(i);
-                if (f2key(v) == thr) {
-                    const unsigned slot = n_gt + atomicAdd(&sh_cnt_eq, 1u);
-                    if (k <= TK_SORT_MAX) { s_val[slot] = v; s_idx[slot] = r.idx(i); } else { ov[slot] = v; oi[slot] = r.idx(i); }
-                }
-            }
-        } else if (t == 0) {  // more ties than slots: lowest positions first (serial, rare)
-            unsigned taken = 0;
-            for (long i = 0; i < total && taken < krem; ++i) {
-                const float v = r.val(i);
-                if (f2key(v) == thr) {
-                    const unsigned slot = n_gt + taken++;
-                    if (k <= TK_SORT_MAX) { s_val[slot] = v; s_idx[slot] = r.idx(i); } else { ov[slot] = v; oi[slot] = r.idx(i); }
-                }
+        unsigned off = hist[t];
+        for (long i = lo; i < hi && off < krem; ++i) {
+            const float v = r.val(i);
+            if (f2key(v) == thr) {
+                const unsigned slot = n_gt + off++;
+                if (in_lds) { s_val[slot] = v; s_idx[slot] = r.idx(i); } else { ov[slot] = v; oi[slot] = r.idx(i); }
             }
         }
+        n_sorted = kk;
     }
     __syncthreads();
-    if (k > TK_SORT_MAX) return;  // unsorted output for very large k
-    // ---- bitonic sort of the survivors: descending value, ascending index ----
+    if (!in_lds) return;  // unsorted output for very large k
+    // ---------------- sort the survivors ----------------
     int np2 = 1;
-    while (np2 < k) np2 <<= 1;
-    for (int i = kk + t; i < np2; i += TK_THREADS)
-        if (i < TK_SORT_MAX) { s_val[i] = -INFINITY; s_idx[i] = 0x7fffffffffffffffLL; }
+    while (np2 < n_sorted || np2 < k) np2 <<= 1;
+    if (np2 > TK_SORT_MAX) np2 = TK_SORT_MAX;
+    for (int i = n_sorted + t; i < np2; i += TK_THREADS) { s_val[i] = -INFINITY; s_idx[i] = 0x7fffffffffffffffLL; }
     __syncthreads();
-    auto before = [](float va, int64_t ia, float vb, int64_t ib) {  // a sorts before b
-        return va > vb || (va == vb && ia < ib);
-    };
-    for (int size = 2; size <= np2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = t; i < np2; i += TK_THREADS) {
-                const int j = i ^ stride;
-                if (j > i) {
-                    const bool up = (i & size) == 0;  // "up" = this run is in final (descending) order
-                    const float va = s_val[i], vb = s_val[j];
-                    const int64_t ia = s_idx[i], ib = s_idx[j];
-                    const bool swap = up ? before(vb, ib, va, ia) : before(va, ia, vb, ib);
-                    if (swap) { s_val[i] = vb; s_val[j] = va; s_idx[i] = ib; s_idx[j] = ia; }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_desc<true>(s_val, s_idx, np2, t);
     for (int i = t; i < k; i += TK_THREADS) {
         const bool ok = i < kk;
         ov[i] = ok ? s_val[i] : -INFINITY;

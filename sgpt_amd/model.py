@@ -18,7 +18,7 @@ from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F32
 from .runtime import Context, get_context, _p, _stream_ptr
 
 ALIGN = 16         # sequence starts on the packed token axis (MFMA 16-row tiles; V^T 8-byte loads)
-TOKEN_TILE = 128   # GEMM M tile
+TOKEN_TILE = 256   # GEMM M tile (256x256 LDS-DMA kernel)
 
 
 @dataclass

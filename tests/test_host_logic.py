@@ -63,7 +63,7 @@ def test_pack_host_layout():
     from sgpt_amd.model import pack_host, ALIGN
     seqs = [[5, 6, 7], list(range(1, 18)), [9] * 16, [1]]
     h = pack_host(seqs, pad_left=[2, 0, 0, 7])
-    assert h["B"] == 4 and h["T_pad"] % 128 == 0 and h["max_alloc"] == 32 and h["n_tokens"] == 37
+    assert h["B"] == 4 and h["T_pad"] % 256 == 0 and h["max_alloc"] == 32 and h["n_tokens"] == 37
     off = h["seq_off"]
     assert off.tolist() == [0, 16, 48, 64, 80] and all(o % ALIGN == 0 for o in off)
     for b, s in enumerate(seqs):
