@@ -11,16 +11,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN kept quiet (same as torch.Tensor.to(bfloat16))
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even: one v_cvt_pk_bf16_f32 (gfx950), same result as
+// torch.Tensor.to(bfloat16) (checked bit-for-bit in tests/test_gpu_kernels.py::test_l2_normalize)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -54,6 +53,7 @@ enum GemmEpi {
     EPI_BIAS_RESID = 2,   // out[m][n] = resid[m][n] + acc + bias[n]  (fp32, may alias)
     EPI_SCORE = 3,        // out[m][n] = isnan(acc) ? -1 : acc        (fp32)
     EPI_VT = 4,           // out[n][m] = acc  (transposed store, bf16: V^T for the attention B-operand)
+    EPI_NONE = 5,         // micro-benchmark only: no stores (accumulators kept live)
 };
 
 struct GemmArgs {
@@ -65,6 +65,7 @@ struct GemmArgs {
     int M, N, K;
     long lda, ldw, ldo;
     int m_valid;        // rows >= m_valid are computed from clamped reads and not stored
+    int skew;           // persistent kernel: start-up stagger (shader cycles per phase), see gemm256_kernel
 };
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);

@@ -27,6 +27,11 @@
 
 namespace {
 
+// LDS scratch is written and re-read through different vector types: exempt from strict aliasing
+typedef uint2 __attribute__((may_alias)) uint2_a;
+typedef uint4 __attribute__((may_alias)) uint4_a;
+typedef float4 __attribute__((may_alias)) float4_a;
+
 constexpr int BM = 128, BN = 128, CH = 8;  // CH = 16-byte chunks per row per k-step
 
 template <typename T> struct ElemTraits;
@@ -250,18 +255,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 
     const int N = p.N, K = p.K;
     const int MT = p.M / TM, NT = N / TN;
-    // XCD-aware supertiles (32 resident blocks per XCD): 4 M-tiles x 8 N-tiles
-    const int b = blockIdx.x;
-    const int xcd = b & 7, local = b >> 3;
+    // Persistent: one workgroup per CU walks tiles b, b+grid, ... (grid is a multiple of 8, so a
+    // workgroup's tiles stay on its XCD).  Tile order inside an XCD = 4 x 8 supertiles, so the ~32
+    // tiles in flight per XCD share 4 activation panels and <= 8 weight panels in the 4 MiB L2.
     constexpr int GM = 4, GN = 8;
     const int per_band = GM * NT;
-    const int band = local / per_band, inb = local % per_band;
-    const int ng = inb / (GM * GN);
-    const int gn = (NT - ng * GN) < GN ? (NT - ng * GN) : GN;
-    const int r = inb - ng * GM * GN;
-    const int mt = xcd + 8 * (band * GM + r / gn), nt = ng * GN + r % gn;
-    if (mt >= MT) return;
-    const int m0 = mt * TM, n0 = nt * TN;
+    const int tiles_total = ((MT + 7) / 8 + GM - 1) / GM * GM * 8 * NT;   // padded tile-id space
+    auto tile_coords = [&](int tile, int& m0, int& n0) -> bool {
+        const int xcd = tile & 7, local = tile >> 3;
+        const int band = local / per_band, inb = local % per_band;
+        const int ng = inb / (GM * GN);
+        const int gn = (NT - ng * GN) < GN ? (NT - ng * GN) : GN;
+        const int r = inb - ng * GM * GN;
+        const int mt = xcd + 8 * (band * GM + r / gn), nt = ng * GN + r % gn;
+        m0 = mt * TM; n0 = nt * TN;
+        return mt < MT;
+    };
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -273,14 +282,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(p.W);
     const int lrow = wave * 32 + (lane >> 3);
     const int lchunk = (lane & 7) ^ (lane >> 3);
-    const bf16_t* asrc = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
-    const bf16_t* wsrc = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
     const long astep = 8 * p.lda, wstep = 8 * p.ldw;
 
     // Inline asm, not __builtin_amdgcn_global_load_lds: hipcc treats the builtin as an LDS store and
     // drains it (s_waitcnt vmcnt(0)) in front of the very next ds_read, which would serialise the
     // DMA of k-step k+1 with the MFMAs of k-step k.  The asm form is invisible to that pass; its
-    // completion is waited for by hand (vmcnt(0) + barrier at the top of the next iteration).
+    // completion is waited for by hand (vmcnt(0) + barrier at the top of the next step).
     // M0 = wave-uniform LDS byte address of the 1-KiB destination (saved/restored: compiler-reserved).
     const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0][0][0]);
     auto dma16 = [&](const bf16_t* src, unsigned dst_byte) {
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                      : "v"(src), "s"(dst)
                      : "memory");
     };
-    auto issue = [&](int kt, int st) {
+    auto issue = [&](const bf16_t* asrc, const bf16_t* wsrc, int kt, int st) {
         const int kc = kt * 64;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -330,59 +337,167 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     };
 
     const int nk = K / 64;
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of k-step kt has landed
-        __syncthreads();                                   // everyone's has; stage (kt+1)&1 is free again
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        compute(kt & 1);
-    }
-
-    // ---------------- epilogue (same lane maps as the 128^2 kernel) ----------------
     OutT* __restrict__ out = static_cast<OutT*>(p.out);
-    if constexpr (SWAP) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wm * 128 + i * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + 4 * g;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_new_fast(v[e]);
-                }
-                if constexpr (EPI == EPI_BIAS_RESID) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
-                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                }
-                store4<OutT>(out + (long)m * p.ldo + n, v[0], v[1], v[2], v[3]);
-            }
+
+    // first valid tile of this workgroup
+    int tile = blockIdx.x, m0 = 0, n0 = 0;
+    while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
+    if (tile >= tiles_total) return;
+    const bf16_t* asrc = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
+    const bf16_t* wsrc = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
+    int st = 0;
+    bool first_tile = true;
+    // Start-up stagger: all 256 workgroups run equally long tiles, so without it every CU reaches its
+    // epilogue (the HBM-heavy phase: residual read-modify-write) at the same moment and the chip
+    // alternates between an HBM-bound and an MFMA-bound phase.  Four phases per XCD, offset by
+    // `skew` cycles each, spread the epilogue traffic under the other CUs' MFMA phases.
+    if (p.skew > 0) {
+        const int phase = (blockIdx.x >> 3) & 3;
+        const long until = (long)__builtin_amdgcn_s_memtime() + (long)phase * p.skew;
+        while (phase && (long)__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
+    issue(asrc, wsrc, 0, 0);
+    while (true) {
+        // look up the next tile now: its first k-step is prefetched under this tile's last MFMAs
+        int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
+        while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
+        const bool has_next = ntile < tiles_total;
+        const bf16_t* nasrc = Ag + (long)(nm0 + lrow) * p.lda + lchunk * 8;
+        const bf16_t* nwsrc = Wg + (long)(nn0 + lrow) * p.ldw + lchunk * 8;
+        for (int kt = 0; kt < nk; ++kt) {
+            // this wave's DMA of this step has landed.  Step 0 of a follow-up tile was already waited for
+            // BEFORE the previous epilogue issued its stores (below), so those stores get a whole k-step
+            // of MFMAs to drain before the next vmcnt(0) (CDNA vmcnt counts stores as well).
+            if (kt > 0 || first_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                   // everyone's has; the other stage is free
+            if (kt + 1 < nk) issue(asrc, wsrc, kt + 1, st ^ 1);
+            else if (has_next) issue(nasrc, nwsrc, 0, st ^ 1);
+            compute(st);
+            st ^= 1;
         }
-    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's step-0 DMA landed (nothing else pending)
+        first_tile = false;
+
+        // ---------------- epilogue: transpose through LDS, full-row 16-byte stores ----------------
+        // The MFMA C layout gives a lane 4 consecutive elements of ONE row per fragment, i.e. 16 rows x
+        // 32..64-byte pieces per store instruction -- store-issue-bound (measured: 1186 TF/s without
+        // stores, 510-830 with).  Each wave instead round-trips its 128x64 tile through its 8-KiB slice
+        // of the LDS stage that was just consumed (the other stage already holds the next tile's first
+        // k-step), 16 rows at a time, and stores whole 128/256-byte rows with dwordx4.
+        __syncthreads();  // every wave is done reading the consumed stage
+        char* scr = reinterpret_cast<char*>(&lds[st ^ 1][0][0]) + wave * 8192;
+        if constexpr (EPI == EPI_NONE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fr;
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm volatile("" ::"v"(acc[i][j]));
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        } else if constexpr (SWAP && sizeof(OutT) == 2) {
+            // bf16 row-major: 16 rows x 128 B per round, LDS row stride 144 B
+            constexpr int RS = 144;
+            const int rrow = lane >> 3, rchunk = lane & 7;
+            float4 bb[4];
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 16 + 4 * g);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int m = m0 + wm * 128 + i * 16 + 4 * g;
-                store4<OutT>(out + (long)n * p.ldo + m, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if constexpr (EPI == EPI_BIAS_GELU) {
+                        v[0] = gelu_new_fast(v[0] + bb[j].x); v[1] = gelu_new_fast(v[1] + bb[j].y);
+                        v[2] = gelu_new_fast(v[2] + bb[j].z); v[3] = gelu_new_fast(v[3] + bb[j].w);
+                    }
+                    *reinterpret_cast<uint2_a*>(scr + fr * RS + (j * 16 + 4 * g) * 2) =
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = h * 8 + rrow;
+                    const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
+                    const int m = m0 + wm * 128 + i * 16 + row;
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (long)m * p.ldo + n0 + wn * 64 + rchunk * 8) = v;
+                }
+            }
+        } else if constexpr (SWAP) {
+            // fp32 row-major (+bias +residual): 16 rows x 256 B per round, LDS row stride 272 B
+            constexpr int RS = 272;
+            const int rrow = lane >> 4, rchunk = lane & 15;
+            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (EPI == EPI_BIAS_RESID) bb = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + rchunk * 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float4 rr[4];
+                float* gp[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int m = m0 + wm * 128 + i * 16 + h * 4 + rrow;
+                    gp[h] = reinterpret_cast<float*>(out) + (long)m * p.ldo + n0 + wn * 64 + rchunk * 4;
+                    if constexpr (EPI == EPI_BIAS_RESID)
+                        rr[h] = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n0 + wn * 64 + rchunk * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    *reinterpret_cast<float4_a*>(scr + fr * RS + (j * 16 + 4 * g) * 4) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    float4 v = *reinterpret_cast<const float4_a*>(scr + (h * 4 + rrow) * RS + rchunk * 16);
+                    if constexpr (EPI == EPI_BIAS_RESID) {
+                        v.x += bb.x + rr[h].x; v.y += bb.y + rr[h].y; v.z += bb.z + rr[h].z; v.w += bb.w + rr[h].w;
+                    }
+                    *reinterpret_cast<float4*>(gp[h]) = v;
+                }
+            }
+        } else {
+            // V^T (bf16, out[n][m]): 16 n-rows x 256 B (128 m) per round, LDS row stride 272 B
+            constexpr int RS = 272;
+            const int rrow = lane >> 4, rchunk = lane & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    *reinterpret_cast<uint2_a*>(scr + fr * RS + (i * 16 + 4 * g) * 2) =
+                        make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int row = h * 4 + rrow;
+                    const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
+                    const int n = n0 + wn * 64 + j * 16 + row;
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (long)n * p.ldo + m0 + wm * 128 + rchunk * 8) = v;
+                }
             }
         }
+        if (!has_next) break;
+        tile = ntile; m0 = nm0; n0 = nn0; asrc = nasrc; wsrc = nwsrc;
     }
 }
 
 template <int EPI, typename OutT, bool SWAP>
 void launch256(const GemmArgs& a, hipStream_t s) {
     const int MT = a.M / 256, NT = a.N / 256;
-    const int mt_per_xcd = (MT + 7) / 8;
-    const int bands = (mt_per_xcd + 3) / 4;
-    const int grid = 8 * bands * 4 * NT;
-    hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, SWAP>), dim3(grid), dim3(512), 0, s, a);
+    const int tiles_total = ((MT + 7) / 8 + 3) / 4 * 4 * 8 * NT;
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n / 8 * 8;
+    }();
+    const int grid = tiles_total < ncu ? tiles_total : ncu;
+    GemmArgs b = a;
+    static const int skew_env = getenv("SGPT_SKEW") ? atoi(getenv("SGPT_SKEW")) : -1;
+    if (skew_env >= 0) b.skew = skew_env;
+    if (tiles_total < 2 * grid) b.skew = 0;   // a single tile per workgroup: nothing to interleave with
+    hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, SWAP>), dim3(grid), dim3(512), 0, s, b);
 }
 
 template <typename T, int EPI, typename OutT, bool SWAP>
@@ -404,6 +519,7 @@ void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream
         if (epi == EPI_VT) return launch256<EPI_VT, bf16_t, false>(a, s);
         if (epi == EPI_BIAS_GELU) return launch256<EPI_BIAS_GELU, bf16_t, true>(a, s);
         if (epi == EPI_BIAS_RESID) return launch256<EPI_BIAS_RESID, float, true>(a, s);
+        if (epi == EPI_NONE) return launch256<EPI_NONE, bf16_t, true>(a, s);
     }
     if (bf) {
         if (epi == EPI_STORE && obf) return launch<bf16_t, EPI_STORE, bf16_t, true>(a, s);
