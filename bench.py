@@ -86,21 +86,16 @@ def main():
     # queries: lengths U{4..32}; encoded sharded by rank, then ONE all-gather
     qrng = np.random.default_rng(7)
     queries = [qrng.integers(0, 50256, size=int(qrng.integers(4, 33))).tolist() for _ in range(args.nq)]
-    per = (args.nq + world - 1) // world
-    mine = queries[rank * per: (rank + 1) * per]
+    from sgpt_amd.dist import all_gather_queries, exchange_topk, shard_range
+    qlo, qhi = shard_range(args.nq, rank, world)
+    mine = queries[qlo:qhi]
 
     corpus = torch.empty((n_steps * args.chunk, d), dtype=score_dt, device=dev)   # this rank's shard, stays in HBM
     emb32 = torch.empty((args.chunk, d), dtype=torch.float32, device=dev)
 
     def encode_queries():
         local_q = model.encode_ids(mine, normalize=True) if mine else torch.empty((0, d), device=dev)
-        if not dist_on:
-            return local_q
-        pad = torch.zeros((per, d), dtype=torch.float32, device=dev)
-        pad[: local_q.shape[0]] = local_q
-        allq = torch.empty((world * per, d), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(allq, pad)
-        return allq[: args.nq]
+        return all_gather_queries(local_q, args.nq) if dist_on else local_q   # RCCL all-gather over xGMI
 
     def step(i, q, run):
         base = i * args.chunk
@@ -134,11 +129,8 @@ def main():
     for i in range(args.warmup, n_steps):
         run = step(i, q, run)
     if dist_on:   # exchange step: per-rank top-(k+1) lists -> every rank, merge
-        gv = torch.empty((world,) + tuple(run[0].shape), dtype=torch.float32, device=dev)
-        gi = torch.empty((world,) + tuple(run[1].shape), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(gv, run[0])
-        dist.all_gather_into_tensor(gi, run[1])
-        fv, fi = ctx.topk_merge(gv.permute(1, 0, 2).reshape(args.nq, -1), gi.permute(1, 0, 2).reshape(args.nq, -1), k1)
+        cv, ci = exchange_topk(run[0], run[1])
+        fv, fi = ctx.topk_merge(cv, ci, k1)
     else:
         fv, fi = run[0], run[1]
     sync()
@@ -155,12 +147,19 @@ def main():
     sent_per_s = sentences / dt
 
     # ---- queries/sec: scoring + top-k only, against this job's encoded corpus and a 1M-doc synthetic shard ----
+    def search_once(cmat):
+        v, i, _ = ctx.score_topk(q, cmat, k1, idx_base=rank * cmat.shape[0], dtype=score_dt)
+        if dist_on:
+            cv, ci = exchange_topk(v, i)
+            v, i = ctx.topk_merge(cv, ci, k1)
+        return v, i
+
     def time_search(cmat, reps=5):
-        ctx.score_topk(q, cmat, k1, dtype=score_dt)
+        search_once(cmat)
         sync()
         t = time.perf_counter()
         for _ in range(reps):
-            ctx.score_topk(q, cmat, k1, dtype=score_dt)
+            search_once(cmat)
         sync()
         return args.nq * reps / (time.perf_counter() - t)
 

@@ -16,6 +16,8 @@
 //   m starts at -1e30 so a fully masked step contributes exp(-inf) = 0 without NaN.
 //
 // fp32 path (attn_f32_kernel): exact-fp32 VALU kernel for the parity gate, one wave per query row.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -123,6 +125,146 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs p) {
             make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
 }
 
+// ---- v2: K / V^T tiles of 64 keys staged in LDS and shared by the block's 4 waves ----
+// The direct-from-global kernel above re-fetches every K/V fragment once per wave (4x) with 16
+// scattered 64-byte pieces per instruction and has one dependent global round trip per 8 MFMAs
+// (measured 2.4 % MFMA-busy).  Here a 256-thread block (64 queries of one (sequence, head)) loads
+// each 64-key tile ONCE with row-contiguous 16-byte loads into LDS
+//     Ks[64 keys][DH]   (16-B chunk index XOR (key & 7): conflict-free ds_read_b128 fragments)
+//     Vs[DH][64 keys]   (same swizzle; ds_read_b64 pairs for the permuted k-slots)
+// and every wave takes its MFMA operands from there.  Same math / lane maps as above.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bf16_lds_kernel(const AttnArgs p) {
+    constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
+    __shared__ __attribute__((aligned(16))) uint4 Ks[64 * CPR];
+    __shared__ __attribute__((aligned(16))) uint4 Vs[DH * 8];
+    const int sq = blockIdx.z, head = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int s0 = p.seq_off[sq];
+    const int alloc = p.seq_off[sq + 1] - s0;
+    const int qb0 = blockIdx.x * 64;
+    if (qb0 >= alloc) return;                       // whole block out of range (uniform)
+    const int q0 = qb0 + wave * 16;
+    const bool wave_on = q0 < alloc;
+    const int fr = lane & 15, g = lane >> 4;
+
+    const bf16_t* __restrict__ qb = static_cast<const bf16_t*>(p.q) + (long)head * DH;
+    const bf16_t* __restrict__ kb = static_cast<const bf16_t*>(p.k) + (long)head * DH;
+    const bf16_t* __restrict__ vt = static_cast<const bf16_t*>(p.v) + (long)head * DH * p.ldvt;
+
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (long)(s0 + q0 + fr) * p.ldq + ks * 32 + 8 * g);
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+    const int qi = q0 + fr;
+
+    int j_lo = 0;
+    if (p.window > 0) { j_lo = qb0 - p.window + 1; j_lo = j_lo < 0 ? 0 : (j_lo & ~63); }
+    const int j_hi = qb0 + 63;                       // last key any query of the block may see
+    for (int j0 = j_lo; j0 <= j_hi; j0 += 64) {
+        // ---- cooperative tile load (row-contiguous 16-B pieces) ----
+        uint4 kreg[CPR / 4], vreg[DH / 32];
+#pragma unroll
+        for (int u = 0; u < CPR / 4; ++u) {
+            const int c = t + 256 * u, row = c / CPR, ch = c % CPR;
+            kreg[u] = *reinterpret_cast<const uint4*>(kb + (long)(s0 + j0 + row) * p.ldq + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < DH / 32; ++u) {
+            const int c = t + 256 * u, row = c >> 3, ch = c & 7;
+            vreg[u] = *reinterpret_cast<const uint4*>(vt + (long)row * p.ldvt + s0 + j0 + ch * 8);
+        }
+        __syncthreads();                             // previous tile fully consumed
+#pragma unroll
+        for (int u = 0; u < CPR / 4; ++u) {
+            const int c = t + 256 * u, row = c / CPR, ch = c % CPR;
+            Ks[row * CPR + (ch ^ (row & 7))] = kreg[u];
+        }
+#pragma unroll
+        for (int u = 0; u < DH / 32; ++u) {
+            const int c = t + 256 * u, row = c >> 3, ch = c & 7;
+            Vs[row * 8 + (ch ^ (row & 7))] = vreg[u];
+        }
+        __syncthreads();
+        if (!wave_on || j0 > q0 + 15) continue;      // nothing visible for this wave in this tile
+        // ---- S^T = K.Q^T : 4 tiles of [16 keys][16 queries] ----
+        f32x4 s[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int row = nt * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 kv = Ks[row * CPR + ((ks * 4 + g) ^ (row & 7))];
+                s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kv), qf[ks], s[nt], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kj = j0 + nt * 16 + 4 * g + r;
+                const bool vis = (kj <= qi) && (p.window <= 0 || kj > qi - p.window);
+                const float v = vis ? s[nt][r] * p.scale : -INFINITY;
+                s[nt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float ps = 0.f;
+        uint32_t pw[8];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float e0 = __expf(s[nt][0] - m_new), e1 = __expf(s[nt][1] - m_new);
+            const float e2 = __expf(s[nt][2] - m_new), e3 = __expf(s[nt][3] - m_new);
+            ps += (e0 + e1) + (e2 + e3);
+            pw[nt * 2] = pack_bf16x2(e0, e1);
+            pw[nt * 2 + 1] = pack_bf16x2(e2, e3);
+        }
+        l_run = l_run * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
+        }
+        // ---- O^T += V^T . P^T, two 32-key steps; k-slot j <-> key 32*step + 16*(j>>2) + 4g + (j&3) ----
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            uint4 pu;
+            pu.x = pw[step * 4]; pu.y = pw[step * 4 + 1]; pu.z = pw[step * 4 + 2]; pu.w = pw[step * 4 + 3];
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pu);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int row = dt * 16 + fr;
+                // keys 32*step + 4g .. +3 live in 16-B chunk (4*step + g/2), 8-B half (g&1); +16 keys = +2 chunks
+                const char* vrow = reinterpret_cast<const char*>(&Vs[row * 8]);
+                const int c0 = (4 * step + (g >> 1)) ^ (row & 7), c1 = (4 * step + 2 + (g >> 1)) ^ (row & 7);
+                const uint2 v0 = *reinterpret_cast<const uint2*>(vrow + c0 * 16 + (g & 1) * 8);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + c1 * 16 + (g & 1) * 8);
+                uint4 vu; vu.x = v0.x; vu.y = v0.y; vu.z = v1.x; vu.w = v1.y;
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vu), pf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_on) return;
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_run;
+    bf16_t* orow = static_cast<bf16_t*>(p.ctx) + (long)(s0 + qi) * p.ldo + (long)head * DH + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+        *reinterpret_cast<uint2*>(orow + dt * 16) =
+            make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+}
+
 // Exact fp32: one wave per query row.  Scores in LDS (max 2048 keys per wave).
 constexpr int F32_MAXKEYS = 2048;
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
@@ -176,8 +318,15 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
 
 void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.max_alloc_len + 63) / 64, a.H, a.B);
-    if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_kernel<64>, grid, dim3(256), 0, s, a);
-    else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_kernel<128>, grid, dim3(256), 0, s, a);
+    static const bool direct = getenv("SGPT_ATTN_DIRECT") != nullptr;   // A/B switch: LDS-staged (default) vs direct
+    if (direct) {
+        if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_kernel<64>, grid, dim3(256), 0, s, a);
+        else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_kernel<128>, grid, dim3(256), 0, s, a);
+        else abort();
+        return;
+    }
+    if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_lds_kernel<64>, grid, dim3(256), 0, s, a);
+    else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_lds_kernel<128>, grid, dim3(256), 0, s, a);
     else abort();
 }
 
