@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -473,6 +474,8 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
     g.ldo = epi == EPI_VT ? M : N; g.bias = bias; g.resid = epi == EPI_BIAS_RESID ? (const float*)O : nullptr;
     hipEvent_t e0, e1;
     HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
+    long long* dbg = nullptr;
+    if (getenv("SGPT_GEMM_DBG")) { HIPC(c, hipMalloc((void**)&dbg, 64 * 8)); HIPC(c, hipMemset(dbg, 0, 64 * 8)); g.dbg = dbg; }
     for (int i = 0; i < 3; ++i) launch_gemm(dtype, epi, out_dtype, g, 0);
     HIPC(c, hipEventRecord(e0, 0));
     for (int i = 0; i < iters; ++i) launch_gemm(dtype, epi, out_dtype, g, 0);
@@ -481,6 +484,17 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
     float ms = 0;
     HIPC(c, hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / iters;
+    if (dbg) {
+        long long h[64];
+        HIPC(c, hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+        for (int tl = 0; tl < 6; ++tl) {
+            const long long* r = h + tl * 8;
+            fprintf(stderr, "tile %d: kloop_end->dma_wait %lld | ->barrier %lld | epilogue %lld | next: step0 barrier@%lld  step1 wait@%lld barrier@%lld (cycles rel. to k-loop end)  tile-to-tile %lld\n",
+                    tl, r[1] - r[0], r[2] - r[1], r[3] - r[2], h[(tl + 1) * 8 + 4] - r[0], h[(tl + 1) * 8 + 5] - r[0],
+                    h[(tl + 1) * 8 + 6] - r[0], h[(tl + 1) * 8 + 0] - r[0]);
+        }
+        hipFree(dbg);
+    }
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(A); hipFree(W); hipFree(O); hipFree(bias);
     HIPC(c, hipGetLastError());

@@ -66,6 +66,7 @@ struct GemmArgs {
     long lda, ldw, ldo;
     int m_valid;        // rows >= m_valid are computed from clamped reads and not stored
     int skew;           // persistent kernel: start-up stagger (shader cycles per phase), see gemm256_kernel
+    long long* dbg;     // optional s_memtime stamps of workgroup 0 / wave 0 (micro-benchmark diagnostics)
 };
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);

@@ -315,7 +315,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int st) {
+    // one k-step = two 32-wide slices.  The 8 DMA pieces of the NEXT step are issued one behind every
+    // 4 MFMAs of slice 0, so their ~60 issue cycles each hide under the matrix pipe instead of sitting
+    // between the barrier and the first ds_read.
+    auto kstep = [&](int st, const bf16_t* ia, const bf16_t* iw, int ikt) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 af[8], wf[4];
@@ -330,9 +333,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                 af[i] = lds[st][0][row * CH + ((4 * ks + g) ^ (row & 7))];
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma<bf16_t, SWAP>(acc[i][j], af[i], wf[j]);
+                if (ks == 0) {   // one 1-KiB DMA piece behind every 4 MFMAs of slice 0 (branch-free)
+                    const int q = i >> 1;
+                    const unsigned row_off = (unsigned)((wave * 32 + q * 8) * CH * 16);
+                    if (i & 1) dma16(iw + q * wstep + ikt * 64, lds_base + (unsigned)(((st ^ 1) * 2 + 1) * TM * CH * 16) + row_off);
+                    else dma16(ia + q * astep + ikt * 64, lds_base + (unsigned)(((st ^ 1) * 2 + 0) * TM * CH * 16) + row_off);
+                }
+            }
         }
     };
 
@@ -346,6 +356,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     const bf16_t* asrc = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
     const bf16_t* wsrc = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
     int st = 0;
+    int dbg_tile = 0;
+#define STAMP(k)                                                                                   \
+    if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 8) p.dbg[dbg_tile * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
     bool first_tile = true;
     // Start-up stagger: all 256 workgroups run equally long tiles, so without it every CU reaches its
     // epilogue (the HBM-heavy phase: residual read-modify-write) at the same moment and the chip
@@ -369,14 +382,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             // BEFORE the previous epilogue issued its stores (below), so those stores get a whole k-step
             // of MFMAs to drain before the next vmcnt(0) (CDNA vmcnt counts stores as well).
             if (kt > 0 || first_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kt == 1) STAMP(5);
             __syncthreads();                                   // everyone's has; the other stage is free
-            if (kt + 1 < nk) issue(asrc, wsrc, kt + 1, st ^ 1);
-            else if (has_next) issue(nasrc, nwsrc, 0, st ^ 1);
-            compute(st);
+            if (kt == 0) STAMP(4);
+            if (kt == 1) STAMP(6);
+            // prefetch target: next k-step of this tile, or step 0 of the next tile; the very last step
+            // of the last tile re-fetches its own step 0 into the idle stage (harmless, keeps the loop
+            // branch-free: a branch per DMA piece splits the MFMA block and makes hipcc spill)
+            const bool intile = kt + 1 < nk;
+            const bf16_t* ia = intile ? asrc : (has_next ? nasrc : asrc);
+            const bf16_t* iw = intile ? wsrc : (has_next ? nwsrc : wsrc);
+            kstep(st, ia, iw, intile ? kt + 1 : 0);
             st ^= 1;
         }
+        STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's step-0 DMA landed (nothing else pending)
         first_tile = false;
+        STAMP(1);
 
         // ---------------- epilogue: transpose through LDS, full-row 16-byte stores ----------------
         // The MFMA C layout gives a lane 4 consecutive elements of ONE row per fragment, i.e. 16 rows x
@@ -385,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         // of the LDS stage that was just consumed (the other stage already holds the next tile's first
         // k-step), 16 rows at a time, and stores whole 128/256-byte rows with dwordx4.
         __syncthreads();  // every wave is done reading the consumed stage
+        STAMP(2);
         char* scr = reinterpret_cast<char*>(&lds[st ^ 1][0][0]) + wave * 8192;
         if constexpr (EPI == EPI_NONE) {
 #pragma unroll
@@ -425,21 +448,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                 }
             }
         } else if constexpr (SWAP) {
-            // fp32 row-major (+bias +residual): 16 rows x 256 B per round, LDS row stride 272 B
+            // fp32 row-major (+bias +residual): 16 rows x 256 B per round, LDS row stride 272 B.
+            // (This epilogue is HBM-bound chip-wide -- every CU reads and writes 256 KiB per tile at about
+            // the same time; keeping more residual rounds in flight only added register spills.)
             constexpr int RS = 272;
             const int rrow = lane >> 4, rchunk = lane & 15;
             float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (EPI == EPI_BIAS_RESID) bb = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + rchunk * 4);
+            const long gbase = (long)(m0 + wm * 128 + rrow) * p.ldo + n0 + wn * 64 + rchunk * 4;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float4 rr[4];
-                float* gp[4];
+                if constexpr (EPI == EPI_BIAS_RESID) {
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int m = m0 + wm * 128 + i * 16 + h * 4 + rrow;
-                    gp[h] = reinterpret_cast<float*>(out) + (long)m * p.ldo + n0 + wn * 64 + rchunk * 4;
-                    if constexpr (EPI == EPI_BIAS_RESID)
-                        rr[h] = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n0 + wn * 64 + rchunk * 4);
+                    for (int h = 0; h < 4; ++h)
+                        rr[h] = *reinterpret_cast<const float4*>(p.resid + gbase + (long)(i * 16 + h * 4) * p.ldo);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -453,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                     if constexpr (EPI == EPI_BIAS_RESID) {
                         v.x += bb.x + rr[h].x; v.y += bb.y + rr[h].y; v.z += bb.z + rr[h].z; v.w += bb.w + rr[h].w;
                     }
-                    *reinterpret_cast<float4*>(gp[h]) = v;
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + gbase + (long)(i * 16 + h * 4) * p.ldo) = v;
                 }
             }
         } else {
@@ -477,6 +500,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                 }
             }
         }
+        STAMP(3);
+        ++dbg_tile;
         if (!has_next) break;
         tile = ntile; m0 = nm0; n0 = nn0; asrc = nasrc; wsrc = nwsrc;
     }
