@@ -134,15 +134,18 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs p) {
 //     Vs[DH][64 keys]   (same swizzle; ds_read_b64 pairs for the permuted k-slots)
 // and every wave takes its MFMA operands from there.  Same math / lane maps as above.
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bf16_lds_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
     constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
+    constexpr int NT = 512, QB = 128;                          // 8 waves x 16 queries per block
+    constexpr int ORS = DH * 2 + 16;                           // output-transpose row stride (bytes)
     __shared__ __attribute__((aligned(16))) uint4 Ks[64 * CPR];
     __shared__ __attribute__((aligned(16))) uint4 Vs[DH * 8];
+    __shared__ __attribute__((aligned(16))) char Os[8][16 * ORS];
     const int sq = blockIdx.z, head = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int s0 = p.seq_off[sq];
     const int alloc = p.seq_off[sq + 1] - s0;
-    const int qb0 = blockIdx.x * 64;
+    const int qb0 = blockIdx.x * QB;
     if (qb0 >= alloc) return;                       // whole block out of range (uniform)
     const int q0 = qb0 + wave * 16;
     const bool wave_on = q0 < alloc;
@@ -165,30 +168,32 @@ __global__ __launch_bounds__(256) void attn_bf16_lds_kernel(const AttnArgs p) {
 
     int j_lo = 0;
     if (p.window > 0) { j_lo = qb0 - p.window + 1; j_lo = j_lo < 0 ? 0 : (j_lo & ~63); }
-    const int j_hi = qb0 + 63;                       // last key any query of the block may see
+    int j_hi = qb0 + QB - 1;                         // last key any query of the block may see
+    if (j_hi > alloc - 1) j_hi = alloc - 1;
     for (int j0 = j_lo; j0 <= j_hi; j0 += 64) {
         // ---- cooperative tile load (row-contiguous 16-B pieces) ----
-        uint4 kreg[CPR / 4], vreg[DH / 32];
+        constexpr int KU = (64 * CPR + NT - 1) / NT, VU = (DH * 8 + NT - 1) / NT;
+        uint4 kreg[KU], vreg[VU];
 #pragma unroll
-        for (int u = 0; u < CPR / 4; ++u) {
-            const int c = t + 256 * u, row = c / CPR, ch = c % CPR;
-            kreg[u] = *reinterpret_cast<const uint4*>(kb + (long)(s0 + j0 + row) * p.ldq + ch * 8);
+        for (int u = 0; u < KU; ++u) {
+            const int c = t + NT * u, row = c / CPR, ch = c % CPR;
+            if (c < 64 * CPR) kreg[u] = *reinterpret_cast<const uint4*>(kb + (long)(s0 + j0 + row) * p.ldq + ch * 8);
         }
 #pragma unroll
-        for (int u = 0; u < DH / 32; ++u) {
-            const int c = t + 256 * u, row = c >> 3, ch = c & 7;
-            vreg[u] = *reinterpret_cast<const uint4*>(vt + (long)row * p.ldvt + s0 + j0 + ch * 8);
+        for (int u = 0; u < VU; ++u) {
+            const int c = t + NT * u, row = c >> 3, ch = c & 7;
+            if (c < DH * 8) vreg[u] = *reinterpret_cast<const uint4*>(vt + (long)row * p.ldvt + s0 + j0 + ch * 8);
         }
         __syncthreads();                             // previous tile fully consumed
 #pragma unroll
-        for (int u = 0; u < CPR / 4; ++u) {
-            const int c = t + 256 * u, row = c / CPR, ch = c % CPR;
-            Ks[row * CPR + (ch ^ (row & 7))] = kreg[u];
+        for (int u = 0; u < KU; ++u) {
+            const int c = t + NT * u, row = c / CPR, ch = c % CPR;
+            if (c < 64 * CPR) Ks[row * CPR + (ch ^ (row & 7))] = kreg[u];
         }
 #pragma unroll
-        for (int u = 0; u < DH / 32; ++u) {
-            const int c = t + 256 * u, row = c >> 3, ch = c & 7;
-            Vs[row * 8 + (ch ^ (row & 7))] = vreg[u];
+        for (int u = 0; u < VU; ++u) {
+            const int c = t + NT * u, row = c >> 3, ch = c & 7;
+            if (c < DH * 8) Vs[row * 8 + (ch ^ (row & 7))] = vreg[u];
         }
         __syncthreads();
         if (!wave_on || j0 > q0 + 15) continue;      // nothing visible for this wave in this tile
@@ -258,11 +263,22 @@ __global__ __launch_bounds__(256) void attn_bf16_lds_kernel(const AttnArgs p) {
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_run;
-    bf16_t* orow = static_cast<bf16_t*>(p.ctx) + (long)(s0 + qi) * p.ldo + (long)head * DH + 4 * g;
+    // O^T tile dt: lane holds head-dim elements dt*16 + 4g + r of query fr.  Transpose through a per-wave
+    // LDS slice so every store instruction writes whole 2*DH-byte rows with 16 B per lane (the direct
+    // 8-B-per-lane form wrote 3.6x the bytes: 32-B pieces of 16 different lines per instruction).
+    char* os = Os[wave];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
-        *reinterpret_cast<uint2*>(orow + dt * 16) =
+        *reinterpret_cast<uint2_a*>(os + fr * ORS + (dt * 16 + 4 * g) * 2) =
             make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+    constexpr int RPI = 64 / CPR;                    // rows per store instruction
+    bf16_t* obase = static_cast<bf16_t*>(p.ctx) + (long)(s0 + q0) * p.ldo + (long)head * DH;
+#pragma unroll
+    for (int h = 0; h < 16 / RPI; ++h) {
+        const int row = h * RPI + lane / CPR, ch = lane % CPR;
+        const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
+        *reinterpret_cast<uint4*>(obase + (long)row * p.ldo + ch * 8) = v;
+    }
 }
 
 // Exact fp32: one wave per query row.  Scores in LDS (max 2048 keys per wave).
@@ -325,8 +341,9 @@ void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
         else abort();
         return;
     }
-    if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_lds_kernel<64>, grid, dim3(256), 0, s, a);
-    else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_lds_kernel<128>, grid, dim3(256), 0, s, a);
+    dim3 grid2((a.max_alloc_len + 127) / 128, a.H, a.B);
+    if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_lds_kernel<64>, grid2, dim3(512), 0, s, a);
+    else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_lds_kernel<128>, grid2, dim3(512), 0, s, a);
     else abort();
 }
 

@@ -9,6 +9,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define WAVE 64
 
+// LDS scratch is written and re-read through different vector types: exempt from strict aliasing
+typedef uint2 __attribute__((may_alias)) uint2_a;
+typedef uint4 __attribute__((may_alias)) uint4_a;
+typedef float4 __attribute__((may_alias)) float4_a;
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // fp32 -> bf16, round-to-nearest-even: one v_cvt_pk_bf16_f32 (gfx950), same result as

@@ -27,11 +27,6 @@
 
 namespace {
 
-// LDS scratch is written and re-read through different vector types: exempt from strict aliasing
-typedef uint2 __attribute__((may_alias)) uint2_a;
-typedef uint4 __attribute__((may_alias)) uint4_a;
-typedef float4 __attribute__((may_alias)) float4_a;
-
 constexpr int BM = 128, BN = 128, CH = 8;  // CH = 16-byte chunks per row per k-step
 
 template <typename T> struct ElemTraits;
