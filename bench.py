@@ -186,10 +186,21 @@ def main():
 
     # ---- roofline of the dominant kernel (the MFMA GEMM) from live hipEvent timings ----
     gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "gemm_kernel<bf16,128x128x64>", "achieved": round(gemm_tflops, 2),
-                "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                "frac": round(gemm_tflops / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                "traffic": None, "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(n_launch, 1), 5),
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    # HBM bytes per launch from the committed PMC passes of this same command (profiles/, rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 corrections applied there); null if not collected
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if args.dtype == "bf16" and args.call * S == 131072 and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("gemm_avg_hbm_bytes_per_launch")
+    roofline = {"bound": "mfma",
+                "kernel": "gemm256_kernel (bf16 256x256x64 persistent LDS-DMA GEMM; the 5 projection launches per block)"
+                          if args.dtype == "bf16" else "gemm_kernel<float> (exact fp32 MFMA 128x128x32)",
+                "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, avg over the 5 GEMM launch shapes)",
+                "algorithmic_flops_per_launch": round(gemm_flops / max(n_launch, 1), 1),
+                "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(n_launch, 1), 5),
                 "gemm_share_of_step": round(gemm_ms * 1e-3 / dt, 4),
                 "end_to_end_frac_of_mfma_roofline": round(
                     sent_per_s / world * flops_per_sentence(S) / (PEAK_BF16_TFLOPS * 1e12), 4)}

@@ -4,7 +4,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+agg = defaultdict(lambda: defaultdict(list))
 for path in sys.argv[1:]:
     db = sqlite3.connect(path)
     tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
@@ -16,12 +16,11 @@ for path in sys.argv[1:]:
         for kn, cn, v, did in db.execute(q):
             per_dispatch[(kn, cn, did)] += float(v)          # sum over XCDs / instances
         for (kn, cn, did), v in per_dispatch.items():
-            a = agg[kn][cn]
-            a[0] += v
-            a[1] += 1
+            agg[kn][cn].append(v)
     else:
         print("# no counters_collection view in", path, "tables:", [t for t in tabs if "pmc" in t or "counter" in t])
-print("kernel,counter,avg_per_dispatch,dispatches")
-for kn in sorted(agg, key=lambda k: -sum(a[0] for a in agg[k].values())):
-    for cn, (tot, n) in sorted(agg[kn].items()):
-        print('"%s",%s,%.1f,%d' % (kn[:100], cn, tot / max(n, 1), n))
+print("kernel,counter,avg_per_dispatch,median_per_dispatch,max_per_dispatch,dispatches")
+for kn in sorted(agg, key=lambda k: -sum(sum(a) for a in agg[k].values())):
+    for cn, vals in sorted(agg[kn].items()):
+        vs = sorted(vals)
+        print('"%s",%s,%.1f,%.1f,%.1f,%d' % (kn[:100], cn, sum(vs) / len(vs), vs[len(vs) // 2], vs[-1], len(vs)))
