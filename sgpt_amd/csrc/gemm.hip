@@ -520,6 +520,240 @@ void launch256(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, SWAP>), dim3(grid), dim3(512), 0, s, b);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Variant P2: 256x128 tile, 4 waves (2 x 2, 128x64 per wave), BK = 32, three LDS stages of 24 KiB
+// (72 KiB per workgroup) -> TWO persistent workgroups per CU.  Rationale (s_memtime stamps of
+// gemm256_kernel): the k-loop alone runs at 1350 TFLOP/s but the epilogue of a tile (LDS transpose,
+// residual read-modify-write, stores) leaves the matrix pipe idle; with two independent workgroups
+// per CU one's epilogue runs under the other's MFMAs.  Pipeline: DMA of k-step s+2 is issued at the
+// top of step s; `s_waitcnt vmcnt(6)` (6 DMA pieces per wave per step) keeps one step in flight
+// across the barrier (counted vmcnt is exact while only loads are pending; loads retire in order).
+// 64-byte LDS rows: 16-B chunk index is XORed with (row>>2)&3 -> 16 lanes of a ds_read_b128 group
+// hit 16 different 16-B slots.
+template <int EPI, typename OutT, bool SWAP>
+__global__ __launch_bounds__(256, 2) void gemm_p2_kernel(const GemmArgs p) {
+    typedef __attribute__((address_space(3))) char* lds_cptr_t;
+    constexpr int TM = 256, TN = 128, NST = 3, CHK = 4, ROWS = TM + TN;
+    constexpr int STAGE_U4 = ROWS * CHK;                       // uint4 per stage (24 KiB)
+    __shared__ __attribute__((aligned(16))) uint4 lds[NST][STAGE_U4];
+
+    const int N = p.N, K = p.K;
+    const int MT = p.M / TM, NT = N / TN;
+    constexpr int GM = 8, GN = 8;                              // 64 tiles in flight per XCD
+    const int per_band = GM * NT;
+    const int tiles_total = ((MT + 7) / 8 + GM - 1) / GM * GM * 8 * NT;
+    auto tile_coords = [&](int tile, int& m0, int& n0) -> bool {
+        const int xcd = tile & 7, local = tile >> 3;
+        const int band = local / per_band, inb = local % per_band;
+        const int ng = inb / (GM * GN);
+        const int gn = (NT - ng * GN) < GN ? (NT - ng * GN) : GN;
+        const int r = inb - ng * GM * GN;
+        const int mt = xcd + 8 * (band * GM + r / gn), nt = ng * GN + r % gn;
+        m0 = mt * TM; n0 = nt * TN;
+        return mt < MT;
+    };
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, g = lane >> 4;
+
+    // LDS-DMA: 24 pieces of 16 rows x 64 B per k-step; wave w issues pieces w, w+4, ..., w+20
+    // (4 of A, 2 of W).  lane l -> LDS (row l>>2, slot l&3) <- global chunk (l&3) ^ (l>>4).
+    const bf16_t* __restrict__ Ag = static_cast<const bf16_t*>(p.A);
+    const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(p.W);
+    const int lrow = wave * 16 + (lane >> 2);
+    const int lchunk = (lane & 3) ^ (lane >> 4);
+    const long astep = 64 * p.lda, wstep = 64 * p.ldw;
+    const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0][0]);
+    auto dma16 = [&](const bf16_t* src, unsigned dst_byte) {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(dst_byte);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(dst)
+                     : "memory");
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one k-step (32 wide): 12 fragment reads, 32 MFMAs, the 6 DMA pieces of step s+2 spread behind them
+    auto kstep = [&](int st, int dst_st, const bf16_t* ia, const bf16_t* iw, int ikt) {
+        uint4 af[8], wf[4];
+        const uint4* sp = lds[st];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = TM + wn * 64 + j * 16 + fr;
+            wf[j] = sp[row * CHK + (g ^ ((row >> 2) & 3))];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = wm * 128 + i * 16 + fr;
+            af[i] = sp[row * CHK + (g ^ ((row >> 2) & 3))];
+        }
+        const unsigned dbase = lds_base + (unsigned)(dst_st * STAGE_U4 * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma<bf16_t, SWAP>(acc[i][j], af[i], wf[j]);
+            if (i < 4) dma16(ia + i * astep + ikt * 32, dbase + (unsigned)((wave + 4 * i) * 1024));
+            else if (i < 6) dma16(iw + (i - 4) * wstep + ikt * 32, dbase + (unsigned)((16 + wave + 4 * (i - 4)) * 1024));
+        }
+    };
+    auto issue_all = [&](int dst_st, const bf16_t* ia, const bf16_t* iw, int ikt) {
+        const unsigned dbase = lds_base + (unsigned)(dst_st * STAGE_U4 * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(ia + i * astep + ikt * 32, dbase + (unsigned)((wave + 4 * i) * 1024));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(iw + i * wstep + ikt * 32, dbase + (unsigned)((16 + wave + 4 * i) * 1024));
+    };
+
+    const int nk = K / 32;   // >= 2
+    OutT* __restrict__ out = static_cast<OutT*>(p.out);
+
+    int tile = blockIdx.x, m0 = 0, n0 = 0;
+    while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
+    if (tile >= tiles_total) return;
+    const bf16_t* asrc = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
+    const bf16_t* wsrc = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
+    int st = 0;               // stage of the step being computed
+    int skip_wait = 0;        // steps whose DMA was already waited for before the previous epilogue
+    issue_all(0, asrc, wsrc, 0);
+    issue_all(1, asrc, wsrc, 1);
+    while (true) {
+        int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
+        while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
+        const bool has_next = ntile < tiles_total;
+        const bf16_t* nasrc = has_next ? Ag + (long)(nm0 + lrow) * p.lda + lchunk * 8 : asrc;
+        const bf16_t* nwsrc = has_next ? Wg + (long)(nn0 + lrow) * p.ldw + lchunk * 8 : wsrc;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (skip_wait > 0) --skip_wait;
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // DMA of this step landed; next step's may fly
+            __syncthreads();
+            // prefetch step kt+2 (of this tile, or steps 0/1 of the next; past the very end: harmless re-fetch)
+            const int pk = kt + 2;
+            const bool intile = pk < nk;
+            int st2 = st + 2; st2 = st2 >= NST ? st2 - NST : st2;
+            kstep(st, st2, intile ? asrc : nasrc, intile ? wsrc : nwsrc, intile ? pk : pk - nk);
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+        // the next tile's first two k-steps were issued before any store of this epilogue: wait for them now
+        // (loads only -> exact), so the stores below get two k-steps to drain before the next counted wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        skip_wait = 2;
+        __syncthreads();  // every wave is done with the stage just consumed: it becomes the epilogue scratch
+        int stc = st - 1; stc = stc < 0 ? stc + NST : stc;
+        char* scr = reinterpret_cast<char*>(&lds[stc][0]) + wave * 6144;
+        if constexpr (EPI == EPI_NONE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm volatile("" ::"v"(acc[i][j]));
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        } else if constexpr (SWAP && sizeof(OutT) == 2) {
+            constexpr int RS = 144;
+            const int rrow = lane >> 3, rchunk = lane & 7;
+            float4 bb[4];
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 16 + 4 * g);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if constexpr (EPI == EPI_BIAS_GELU) {
+                        v[0] = gelu_new_fast(v[0] + bb[j].x); v[1] = gelu_new_fast(v[1] + bb[j].y);
+                        v[2] = gelu_new_fast(v[2] + bb[j].z); v[3] = gelu_new_fast(v[3] + bb[j].w);
+                    }
+                    *reinterpret_cast<uint2_a*>(scr + fr * RS + (j * 16 + 4 * g) * 2) =
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = h * 8 + rrow;
+                    const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
+                    const int m = m0 + wm * 128 + i * 16 + row;
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (long)m * p.ldo + n0 + wn * 64 + rchunk * 8) = v;
+                }
+            }
+        } else if constexpr (SWAP) {
+            constexpr int RS = 272;
+            const int rrow = lane >> 4, rchunk = lane & 15;
+            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (EPI == EPI_BIAS_RESID) bb = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + rchunk * 4);
+            const long gbase = (long)(m0 + wm * 128 + rrow) * p.ldo + n0 + wn * 64 + rchunk * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float4 rr[4];
+                if constexpr (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h)
+                        rr[h] = *reinterpret_cast<const float4*>(p.resid + gbase + (long)(i * 16 + h * 4) * p.ldo);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    *reinterpret_cast<float4_a*>(scr + fr * RS + (j * 16 + 4 * g) * 4) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    float4 v = *reinterpret_cast<const float4_a*>(scr + (h * 4 + rrow) * RS + rchunk * 16);
+                    if constexpr (EPI == EPI_BIAS_RESID) {
+                        v.x += bb.x + rr[h].x; v.y += bb.y + rr[h].y; v.z += bb.z + rr[h].z; v.w += bb.w + rr[h].w;
+                    }
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + gbase + (long)(i * 16 + h * 4) * p.ldo) = v;
+                }
+            }
+        } else {
+            constexpr int RS = 272;
+            const int rrow = lane >> 4, rchunk = lane & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    *reinterpret_cast<uint2_a*>(scr + fr * RS + (i * 16 + 4 * g) * 2) =
+                        make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int row = h * 4 + rrow;
+                    const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
+                    const int n = n0 + wn * 64 + j * 16 + row;
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (long)n * p.ldo + m0 + wm * 128 + rchunk * 8) = v;
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; m0 = nm0; n0 = nn0; asrc = nasrc; wsrc = nwsrc;
+    }
+}
+
+template <int EPI, typename OutT, bool SWAP>
+void launch_p2(const GemmArgs& a, hipStream_t s) {
+    const int MT = a.M / 256, NT = a.N / 128;
+    const int tiles_total = ((MT + 7) / 8 + 7) / 8 * 8 * 8 * NT;
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n / 8 * 8;
+    }();
+    const int grid = tiles_total < 2 * ncu ? tiles_total : 2 * ncu;
+    hipLaunchKernelGGL((gemm_p2_kernel<EPI, OutT, SWAP>), dim3(grid), dim3(256), 0, s, a);
+}
+
 template <typename T, int EPI, typename OutT, bool SWAP>
 void launch(const GemmArgs& a, hipStream_t s) {
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
@@ -534,6 +768,14 @@ void launch(const GemmArgs& a, hipStream_t s) {
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     const bool bf = dtype == 1, obf = out_dtype == 1;
     static const bool use256 = getenv("SGPT_GEMM128") == nullptr;
+    static const bool use_p2 = getenv("SGPT_GEMM_P2") != nullptr;
+    if (bf && use_p2 && a.M % 256 == 0 && a.N % 128 == 0 && a.K % 32 == 0 && a.K >= 64 && a.m_valid == a.M) {
+        if (epi == EPI_STORE && obf) return launch_p2<EPI_STORE, bf16_t, true>(a, s);
+        if (epi == EPI_VT) return launch_p2<EPI_VT, bf16_t, false>(a, s);
+        if (epi == EPI_BIAS_GELU) return launch_p2<EPI_BIAS_GELU, bf16_t, true>(a, s);
+        if (epi == EPI_BIAS_RESID) return launch_p2<EPI_BIAS_RESID, float, true>(a, s);
+        if (epi == EPI_NONE) return launch_p2<EPI_NONE, bf16_t, true>(a, s);
+    }
     if (bf && use256 && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.m_valid == a.M) {
         if (epi == EPI_STORE && obf) return launch256<EPI_STORE, bf16_t, true>(a, s);
         if (epi == EPI_VT) return launch256<EPI_VT, bf16_t, false>(a, s);

@@ -152,3 +152,30 @@ def test_cfg2_full_size_properties():
     cs = torch.max(torch.abs(e[:64] @ e[:64].T - e32 @ e32.T)).item()
     print(f"cfg2 bf16 vs fp32: max|emb diff| = {dev:.3e}, max|cos diff| = {cs:.3e}")
     assert dev < TOL_BF16_ABS and cs < 1e-2
+
+
+@pytest.mark.parametrize("name,shape", [("1.3B", dict(hidden_size=2048, num_heads=16)),
+                                        ("2.7B", dict(hidden_size=2560, num_heads=20))])
+def test_encode_larger_gptneo_shapes_vs_oracle(name, shape):
+    """BASELINE config 3 width (SGPT-1.3B: d=2048, 16 heads of 128) and SGPT-2.7B width (d=2560, 20 heads),
+    truncated to 2 layers and a small vocabulary so the numpy oracle runs in seconds; asymmetric specb
+    inputs (queries [..], documents {..} up to 300 tokens -> local window live)."""
+    from sgpt_amd import SGPTConfig, SGPTModel
+    cfg_kw = dict(vocab_size=1000, max_position_embeddings=512, num_layers=2, window_size=256, **shape)
+    cfg = O.NeoConfig(**cfg_kw)
+    w = O.synth_weights(cfg, seed=21, std=0.02)
+    rng = np.random.default_rng(21)
+    docs = [O.specb_wrap(rng.integers(0, 1000, size=n).tolist(), False) for n in (298, 131, 64, 5)]
+    qs = [O.specb_wrap(rng.integers(0, 1000, size=n).tolist(), True) for n in (30, 3)]
+    seqs = docs + qs
+    want = O.encode(w, cfg, seqs, batch_size=len(seqs))
+    m32 = SGPTModel(SGPTConfig(**cfg_kw), w, device="cuda:0", dtype="fp32")
+    got = m32.encode_ids(seqs).cpu().numpy()
+    m32.close()
+    assert maxabs(got, want) < TOL_FP32, name
+    mbf = SGPTModel(SGPTConfig(**cfg_kw), w, device="cuda:0", dtype="bf16")
+    gb = mbf.encode_ids(seqs).cpu().numpy()
+    mbf.close()
+    err, cosmin = maxabs(gb, want), float(row_cos(gb, want).min())
+    print(f"SGPT-{name} width bf16: max|emb - oracle| = {err:.3e}, min row cosine = {cosmin:.6f}")
+    assert np.isfinite(gb).all() and err < TOL_BF16_ABS and cosmin > TOL_BF16_COS
