@@ -45,14 +45,14 @@ typedef struct sgpt_ctx sgpt_ctx;
 typedef struct sgpt_model sgpt_model;
 
 enum { SGPT_F32 = 0, SGPT_BF16 = 1 };                      /* element types */
-enum { SGPT_ARCH_GPTNEO = 0 };                             /* GPT-J / BLOOM: later rounds */
+enum { SGPT_ARCH_GPTNEO = 0, SGPT_ARCH_GPTJ = 1 };         /* BLOOM: later rounds */
 enum { SGPT_POOL_WEIGHTEDMEAN = 0, SGPT_POOL_MEAN = 1, SGPT_POOL_LASTTOKEN = 2 };
 enum { SGPT_COS = 0, SGPT_DOT = 1 };
 
 /* Model hyper-parameters = the fields of HF GPTNeoConfig the forward pass reads
  * (HF:gpt_neo/configuration_gpt_neo.py; values of the SGPT checkpoints in SURVEY.md 8). */
 typedef struct {
-    int32_t arch;            /* SGPT_ARCH_GPTNEO */
+    int32_t arch;            /* SGPT_ARCH_GPTNEO (SGPT-125M/1.3B/2.7B) | SGPT_ARCH_GPTJ (SGPT-5.8B) */
     int32_t n_layers;
     int32_t d_model;         /* multiple of 128 */
     int32_t n_heads;         /* d_model / n_heads in {64, 128} */
@@ -61,14 +61,18 @@ typedef struct {
     int32_t max_pos;
     int32_t window;          /* GPT-Neo local-attention window (256) */
     float ln_eps;            /* 1e-5 */
-    float attn_scale;        /* 1.0 for GPT-Neo (no 1/sqrt(dh), HF:gpt_neo:110) */
+    float attn_scale;        /* 1.0 for GPT-Neo (no 1/sqrt(dh), HF:gpt_neo:110); 1/sqrt(dh) for GPT-J (HF:gptj:148) */
     int32_t compute_dtype;   /* SGPT_BF16: bf16 MFMA operands, fp32 accumulate/residual/LN/softmax;
                                 SGPT_F32 : exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the parity gate */
     const uint8_t* layer_is_local;  /* host, [n_layers]: 1 = sliding-window layer (HF:gpt_neo:66) */
+    int32_t rotary_dim;      /* GPT-J: leading dims of every head that get rotary position embedding (64) */
 } sgpt_model_desc;
 
 /* One named fp32 weight tensor under its HF state-dict name
- * ("wte.weight", "h.0.attn.attention.q_proj.weight", ..., "ln_f.bias"). */
+ * (GPT-Neo: "wte.weight", "wpe.weight", "h.0.attn.attention.q_proj.weight", ..., "ln_f.bias";
+ *  GPT-J:   "wte.weight", "h.0.attn.q_proj.weight", "h.0.mlp.fc_in.weight", ..., plus the rotary tables
+ *           "rotary.sin" / "rotary.cos" fp32[max_pos, rotary_dim/2] = HF create_sinusoidal_positions,
+ *           HF:gptj/modeling_gptj.py:47-50, computed by the host so they match the reference bit for bit). */
 typedef struct {
     const char* name;
     const float* ptr;        /* device, contiguous fp32 */

@@ -198,6 +198,122 @@ def gptneo_forward(w: Dict[str, np.ndarray], cfg: NeoConfig, input_ids, attentio
 
 
 # ----------------------------------------------------------------------------
+# a2 (second family): GPT-J forward  (HF:gptj/modeling_gptj.py) -- SGPT-5.8B
+# ----------------------------------------------------------------------------
+class GPTJConfig:
+    """Subset of HF GPTJConfig the forward reads (HF:gptj/configuration_gptj.py)."""
+    model_type = "gptj"
+
+    def __init__(self, vocab_size=50400, n_positions=2048, n_embd=4096, n_layer=28, n_head=16, rotary_dim=64,
+                 n_inner=None, layer_norm_epsilon=1e-5):
+        self.vocab_size = vocab_size
+        self.max_position_embeddings = n_positions
+        self.hidden_size = n_embd
+        self.num_layers = n_layer
+        self.num_heads = n_head
+        self.rotary_dim = rotary_dim
+        self.intermediate_size = n_inner or 4 * n_embd
+        self.layer_norm_epsilon = layer_norm_epsilon
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_heads
+
+
+SGPT_5_8B = dict(vocab_size=50400, n_positions=2048, n_embd=4096, n_layer=28, n_head=16, rotary_dim=64)
+
+
+def synth_weights_gptj(cfg: GPTJConfig, seed: int = 0, std: float = 0.02, bf16_linear: bool = False):
+    """Seeded random-init weights under HF GPT-J state-dict names."""
+    rng = np.random.default_rng(seed)
+    d, ffn = cfg.hidden_size, cfg.intermediate_size
+
+    def nrm(*shape, s=std):
+        return (rng.standard_normal(shape, dtype=np.float32) * F32(s)).astype(F32)
+
+    q = bf16_round if bf16_linear else (lambda x: x)
+    w = {"wte.weight": nrm(cfg.vocab_size, d, s=std * 2)}
+    for i in range(cfg.num_layers):
+        p = f"h.{i}."
+        w[p + "ln_1.weight"] = (1.0 + nrm(d, s=0.1)).astype(F32)
+        w[p + "ln_1.bias"] = nrm(d, s=0.05)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            w[p + f"attn.{n}.weight"] = q(nrm(d, d))
+        w[p + "mlp.fc_in.weight"] = q(nrm(ffn, d))
+        w[p + "mlp.fc_in.bias"] = nrm(ffn, s=0.02)
+        w[p + "mlp.fc_out.weight"] = q(nrm(d, ffn))
+        w[p + "mlp.fc_out.bias"] = nrm(d, s=0.02)
+    w["ln_f.weight"] = (1.0 + nrm(d, s=0.1)).astype(F32)
+    w["ln_f.bias"] = nrm(d, s=0.05)
+    return w
+
+
+def rotary_tables(max_pos: int, dim: int):
+    """create_sinusoidal_positions (HF:gptj:47-50): sin/cos [max_pos, dim/2], float32 arithmetic throughout."""
+    inv_freq = (F32(1.0) / (F32(10000.0) ** (np.arange(0, dim, 2).astype(F32) / F32(dim)))).astype(F32)
+    ang = (np.arange(max_pos).astype(F32)[:, None] * inv_freq[None, :]).astype(F32)
+    return np.sin(ang).astype(F32), np.cos(ang).astype(F32)
+
+
+def _rotate_every_two(x):
+    """HF:gptj:57-61: (x0,x1,x2,x3,..) -> (-x1,x0,-x3,x2,..)."""
+    out = np.empty_like(x)
+    out[..., 0::2] = -x[..., 1::2]
+    out[..., 1::2] = x[..., 0::2]
+    return out
+
+
+def gptj_forward(w, cfg: GPTJConfig, input_ids, attention_mask=None, output_hidden_states=False):
+    """GPTJModel.forward (HF:gptj:433-560), eager attention (136-159), fp32.  Parallel block
+    x = attn(ln_1(x)) + mlp(ln_1(x)) + x (:400-411); rotary on the first rotary_dim dims of every head with
+    interleaved pairs (:64-67,190-210); scores / sqrt(head_dim) (:148); no q/k/v/out biases (:98-101);
+    positions = arange(S) (:500-503)."""
+    ids = np.asarray(input_ids)
+    B, S = ids.shape
+    d, H, dh, rd = cfg.hidden_size, cfg.num_heads, cfg.head_dim, cfg.rotary_dim
+    am = np.ones((B, S), dtype=np.int64) if attention_mask is None else np.asarray(attention_mask)
+    x = w["wte.weight"][ids].astype(F32)                                    # :484 (no position embedding)
+    sin, cos = rotary_tables(cfg.max_position_embeddings, rd)
+    sin = np.repeat(sin[:S], 2, axis=1)[None, :, None, :]                   # repeat_interleave(2) :65-66
+    cos = np.repeat(cos[:S], 2, axis=1)[None, :, None, :]
+    ii, jj = np.arange(S)[:, None], np.arange(S)[None, :]
+    causal = np.where(jj <= ii, F32(0), F32(FINFO_MIN)).astype(F32)[None, None]
+    pad_add = np.where(am[:, None, None, :] != 0, F32(0), F32(FINFO_MIN)).astype(F32)
+    with np.errstate(over="ignore"):
+        mask = np.maximum(causal + pad_add, F32(FINFO_MIN))               # 4-D additive mask (0 / finfo.min)
+    hs = []
+    for i in range(cfg.num_layers):
+        if output_hidden_states:
+            hs.append(x)
+        p = f"h.{i}."
+        a = layer_norm(x, w[p + "ln_1.weight"], w[p + "ln_1.bias"], cfg.layer_norm_epsilon)
+        q = (a @ w[p + "attn.q_proj.weight"].T).reshape(B, S, H, dh)
+        k = (a @ w[p + "attn.k_proj.weight"].T).reshape(B, S, H, dh)
+        v = (a @ w[p + "attn.v_proj.weight"].T).reshape(B, S, H, dh)
+        for t in (q, k):                                                     # :197-210
+            rot = t[..., :rd]
+            t[..., :rd] = rot * cos + _rotate_every_two(rot) * sin
+        q, k, v = (t.transpose(0, 2, 1, 3) for t in (q, k, v))
+        sc = (np.matmul(q, k.transpose(0, 1, 3, 2)) / F32(np.sqrt(dh))).astype(F32) + mask   # :147-151
+        ctx = np.matmul(_softmax_lastdim(sc), v).transpose(0, 2, 1, 3).reshape(B, S, d)
+        attn = ctx @ w[p + "attn.out_proj.weight"].T
+        mlp = gelu_new(a @ w[p + "mlp.fc_in.weight"].T + w[p + "mlp.fc_in.bias"]) @ w[p + "mlp.fc_out.weight"].T \
+            + w[p + "mlp.fc_out.bias"]
+        x = (attn + mlp + x).astype(F32)                                     # :411
+    x = layer_norm(x, w["ln_f.weight"], w["ln_f.bias"], cfg.layer_norm_epsilon)
+    if output_hidden_states:
+        hs.append(x)
+        return x, tuple(hs)
+    return x
+
+
+def forward_any(w, cfg, ids, mask, output_hidden_states=False):
+    if getattr(cfg, "model_type", "gpt_neo") == "gptj":
+        return gptj_forward(w, cfg, ids, mask, output_hidden_states=output_hidden_states)
+    return gptneo_forward(w, cfg, ids, mask, output_hidden_states=output_hidden_states)
+
+
+# ----------------------------------------------------------------------------
 # a4/a5: pooling
 # ----------------------------------------------------------------------------
 def pool(hidden, attention_mask, mode: str = "weightedmean", clamp: bool = True):
@@ -380,7 +496,7 @@ def encode(w, cfg, seqs: Sequence[Sequence[int]], mode="weightedmean", batch_siz
     out = []
     for i in range(0, len(seqs), batch_size):
         ids, mask = pad_batch(seqs[i:i + batch_size], pad_id=min(GPT2_PAD, cfg.vocab_size - 1), side=pad_side)
-        last, hs = gptneo_forward(w, cfg, ids, mask, output_hidden_states=True)
+        last, hs = forward_any(w, cfg, ids, mask, output_hidden_states=True)
         h = hs[layer_idx]
         if mode in ("meanmean", "lasttokenmean"):
             e = pool_layers(hs, mask, mode)

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsgpt_hip.so")
 
 SGPT_F32, SGPT_BF16 = 0, 1
-SGPT_ARCH_GPTNEO = 0
+SGPT_ARCH_GPTNEO, SGPT_ARCH_GPTJ = 0, 1
 POOL_MODES = {"weightedmean": 0, "mean": 1, "lasttoken": 2}
 
 
@@ -16,7 +16,7 @@ class ModelDesc(C.Structure):
     _fields_ = [("arch", C.c_int32), ("n_layers", C.c_int32), ("d_model", C.c_int32), ("n_heads", C.c_int32),
                 ("d_ffn", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("window", C.c_int32),
                 ("ln_eps", C.c_float), ("attn_scale", C.c_float), ("compute_dtype", C.c_int32),
-                ("layer_is_local", C.POINTER(C.c_uint8))]
+                ("layer_is_local", C.POINTER(C.c_uint8)), ("rotary_dim", C.c_int32)]
 
 
 class TensorView(C.Structure):

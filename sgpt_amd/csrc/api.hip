@@ -41,6 +41,8 @@ struct sgpt_model {
     sgpt_model_desc d;
     std::vector<LayerW> L;
     float *wte = nullptr, *wpe = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
+    float *rot_sin = nullptr, *rot_cos = nullptr;   // GPT-J rotary tables [max_pos, rotary_dim/2]
+    float* zero_bias = nullptr;                      // [max(d, ffn)] zeros: bias-free projections (GPT-J out_proj)
     std::vector<void*> allocs;
 };
 
@@ -155,15 +157,19 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     if (!c || !d || !tv || !out) return SGPT_ERR_INVALID;
     *out = nullptr;
     HIPC(c, hipSetDevice(c->device));
-    if (d->arch != SGPT_ARCH_GPTNEO) return fail(c, SGPT_ERR_INVALID, "only SGPT_ARCH_GPTNEO is built in this round");
+    if (d->arch != SGPT_ARCH_GPTNEO && d->arch != SGPT_ARCH_GPTJ)
+        return fail(c, SGPT_ERR_INVALID, "arch must be SGPT_ARCH_GPTNEO or SGPT_ARCH_GPTJ (BLOOM is not built yet)");
+    const bool gptj = d->arch == SGPT_ARCH_GPTJ;
     const int dm = d->d_model, ffn = d->d_ffn, H = d->n_heads;
     if (dm % 128 || ffn % 128 || H <= 0 || dm % H) return fail(c, SGPT_ERR_INVALID, "d_model and d_ffn must be multiples of 128");
     const int dh = dm / H;
-    if (d->compute_dtype == SGPT_BF16 && dh != 64 && dh != 128)
-        return fail(c, SGPT_ERR_INVALID, "bf16 attention supports head_dim 64 or 128");
+    if (d->compute_dtype == SGPT_BF16 && dh != 64 && dh != 128 && dh != 256)
+        return fail(c, SGPT_ERR_INVALID, "bf16 attention supports head_dim 64, 128 or 256");
     if (dh > 256 || dh % 4) return fail(c, SGPT_ERR_INVALID, "head_dim must be <= 256 and a multiple of 4");
     if (dm > 4096) return fail(c, SGPT_ERR_INVALID, "d_model > 4096 not supported");
     if (d->compute_dtype != SGPT_BF16 && d->compute_dtype != SGPT_F32) return fail(c, SGPT_ERR_INVALID, "bad compute_dtype");
+    if (gptj && (d->rotary_dim <= 0 || d->rotary_dim > dh || d->rotary_dim % 2))
+        return fail(c, SGPT_ERR_INVALID, "GPT-J needs an even rotary_dim in (0, head_dim]");
 
     std::unordered_map<std::string, const sgpt_tensor_view*> byname;
     for (size_t i = 0; i < nt; ++i) byname[tv[i].name] = &tv[i];
@@ -205,30 +211,46 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     };
 
     m->wte = copy_f32("wte.weight", (int64_t)d->vocab * dm);
-    m->wpe = copy_f32("wpe.weight", (int64_t)d->max_pos * dm);
+    if (!gptj) m->wpe = copy_f32("wpe.weight", (int64_t)d->max_pos * dm);
+    else {
+        m->rot_sin = copy_f32("rotary.sin", (int64_t)d->max_pos * (d->rotary_dim / 2));
+        m->rot_cos = copy_f32("rotary.cos", (int64_t)d->max_pos * (d->rotary_dim / 2));
+    }
     m->lnf_g = copy_f32("ln_f.weight", dm);
     m->lnf_b = copy_f32("ln_f.bias", dm);
+    m->zero_bias = (float*)dalloc((size_t)(ffn > dm ? ffn : dm) * 4);
+    if (m->zero_bias && hipMemsetAsync(m->zero_bias, 0, (size_t)(ffn > dm ? ffn : dm) * 4, 0) != hipSuccess)
+        st = fail(c, SGPT_ERR_HIP, "memset zero_bias");
     m->L.resize(d->n_layers);
+    // HF state-dict names: GPT-Neo h.N.attn.attention.{q,k,v,out}_proj / mlp.c_fc / mlp.c_proj (HF:gpt_neo:84-87,302-303);
+    //                      GPT-J   h.N.attn.{q,k,v,out}_proj (no biases) / mlp.fc_in / mlp.fc_out (HF:gptj:98-101,368-369)
+    const std::string attn = gptj ? "attn." : "attn.attention.";
+    const std::string fc1 = gptj ? "mlp.fc_in" : "mlp.c_fc", fc2 = gptj ? "mlp.fc_out" : "mlp.c_proj";
     for (int i = 0; i < d->n_layers && st == SGPT_OK; ++i) {
         const std::string p = "h." + std::to_string(i) + ".";
         LayerW& l = m->L[i];
-        l.is_local = d->layer_is_local ? d->layer_is_local[i] : (i & 1);
+        l.is_local = gptj ? 0 : (d->layer_is_local ? d->layer_is_local[i] : (i & 1));
         l.ln1_g = copy_f32(p + "ln_1.weight", dm); l.ln1_b = copy_f32(p + "ln_1.bias", dm);
-        l.ln2_g = copy_f32(p + "ln_2.weight", dm); l.ln2_b = copy_f32(p + "ln_2.bias", dm);
-        l.b_o = copy_f32(p + "attn.attention.out_proj.bias", dm);
-        l.b_fc = copy_f32(p + "mlp.c_fc.bias", ffn);
-        l.b_proj = copy_f32(p + "mlp.c_proj.bias", dm);
+        if (!gptj) {
+            l.ln2_g = copy_f32(p + "ln_2.weight", dm); l.ln2_b = copy_f32(p + "ln_2.bias", dm);
+            l.b_o = copy_f32(p + attn + "out_proj.bias", dm);
+        } else {
+            l.ln2_g = l.ln2_b = nullptr;
+            l.b_o = m->zero_bias;
+        }
+        l.b_fc = copy_f32(p + fc1 + ".bias", ffn);
+        l.b_proj = copy_f32(p + fc2 + ".bias", dm);
         l.w_qkv = dalloc((size_t)3 * dm * dm * esz);
         l.w_o = dalloc((size_t)dm * dm * esz);
         l.w_fc = dalloc((size_t)ffn * dm * esz);
         l.w_proj = dalloc((size_t)dm * ffn * esz);
         if (st != SGPT_OK) break;
-        pack_w(p + "attn.attention.q_proj.weight", (int64_t)dm * dm, l.w_qkv, 0);
-        pack_w(p + "attn.attention.k_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)dm * dm);
-        pack_w(p + "attn.attention.v_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)2 * dm * dm);
-        pack_w(p + "attn.attention.out_proj.weight", (int64_t)dm * dm, l.w_o, 0);
-        pack_w(p + "mlp.c_fc.weight", (int64_t)ffn * dm, l.w_fc, 0);
-        pack_w(p + "mlp.c_proj.weight", (int64_t)dm * ffn, l.w_proj, 0);
+        pack_w(p + attn + "q_proj.weight", (int64_t)dm * dm, l.w_qkv, 0);
+        pack_w(p + attn + "k_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)dm * dm);
+        pack_w(p + attn + "v_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)2 * dm * dm);
+        pack_w(p + attn + "out_proj.weight", (int64_t)dm * dm, l.w_o, 0);
+        pack_w(p + fc1 + ".weight", (int64_t)ffn * dm, l.w_fc, 0);
+        pack_w(p + fc2 + ".weight", (int64_t)dm * ffn, l.w_proj, 0);
     }
     if (st == SGPT_OK && hipDeviceSynchronize() != hipSuccess) st = fail(c, SGPT_ERR_HIP, "sync after weight pack");
     if (st != SGPT_OK) { sgpt_model_free(m); return st; }
@@ -265,11 +287,13 @@ sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, c
     const size_t esz = bf ? 2 : 4;
     const size_t SLACK = 64;  // rows of zeroed slack behind buffers the attention key tiles may over-read
 
+    const bool gptj = m->d.arch == SGPT_ARCH_GPTJ;
     // workspace carve (all offsets 256-B aligned)
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_x = carve((size_t)T * dm * 4);                        // residual stream fp32
-    const size_t o_a = carve((size_t)T * dm * esz);                      // LN output / attention ctx
+    const size_t o_a = carve((size_t)T * dm * esz);                      // LN output (GPT-Neo: also attention ctx)
+    const size_t o_c = gptj ? carve((size_t)T * dm * esz) : o_a;         // GPT-J: ctx separate (ln_1 output feeds the MLP too)
     const size_t o_qkv = carve(((size_t)T + SLACK) * 3 * dm * esz);      // bf16: [T][2d] qk + V^T [d][T]; fp32: [T][3d]
     const size_t o_h = carve((size_t)T * ffn * esz);                     // MLP hidden
     sgpt_status st = ensure(c, &c->ws, &c->ws_bytes, off);
@@ -277,10 +301,22 @@ sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, c
     char* base = (char*)c->ws;
     float* x = (float*)(base + o_x);
     void* a = base + o_a;
+    void* ctx = base + o_c;
     void* qkv = base + o_qkv;
     void* h = base + o_h;
     void* vt = bf ? (void*)((bf16_t*)qkv + ((size_t)T + SLACK) * 2 * dm) : nullptr;
 
+    // Rows that are over-read by the attention key tiles but never written in this call must be finite
+    // (a masked key contributes p = 0, and 0 * NaN = NaN): the slack behind the q/k/v buffers, and -- when
+    // the attention context has its own buffer (GPT-J) -- the filler rows past the last sequence.  The
+    // workspace is reused across calls / dtypes, so stale bytes there can decode to NaN.
+    if (bf) {
+        HIPC(c, hipMemsetAsync((bf16_t*)qkv + (size_t)T * 2 * dm, 0, SLACK * 2 * dm * esz, s));
+        HIPC(c, hipMemsetAsync((bf16_t*)vt + (size_t)T * dm, 0, SLACK * dm * esz, s));
+    } else {
+        HIPC(c, hipMemsetAsync((float*)qkv + (size_t)T * 3 * dm, 0, SLACK * 3 * dm * esz, s));
+    }
+    if (gptj) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz, s));
     launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, s);
     for (int li = 0; li < n_layers_run; ++li) {
         const LayerW& l = m->L[li];
@@ -289,27 +325,29 @@ sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, c
         g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
         AttnArgs at{};
         at.seq_off = seq_off; at.B = B; at.H = H; at.dh = dh; at.window = l.is_local ? m->d.window : 0;
-        at.scale = m->d.attn_scale; at.max_alloc_len = max_alloc; at.ctx = a; at.ldo = dm;
+        at.scale = m->d.attn_scale; at.max_alloc_len = max_alloc; at.ctx = ctx; at.ldo = dm;
         if (bf) {
             // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]
             g.W = l.w_qkv; g.N = 2 * dm; g.out = qkv; g.ldo = 2 * dm;
             gemm(c, dt, EPI_STORE, SGPT_BF16, g, s);
             g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; g.N = dm; g.out = vt; g.ldo = T;
             gemm(c, dt, EPI_VT, SGPT_BF16, g, s);
+            if (gptj) launch_rope(qkv, SGPT_BF16, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
             at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
             launch_attn_bf16(at, s);
         } else {
             g.W = l.w_qkv; g.N = 3 * dm; g.out = qkv; g.ldo = 3 * dm;
             gemm(c, dt, EPI_STORE, SGPT_F32, g, s);
+            if (gptj) launch_rope(qkv, SGPT_F32, 3 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
             at.q = qkv; at.k = (float*)qkv + dm; at.v = (float*)qkv + 2 * dm; at.ldq = 3 * dm;
             launch_attn_f32(at, s);
         }
-        // x += ctx . Wo^T + bo
-        g.W = l.w_o; g.N = dm; g.K = dm; g.ldw = dm; g.out = x; g.ldo = dm; g.bias = l.b_o; g.resid = x;
+        // x += ctx . Wo^T (+ bo)
+        g.A = ctx; g.W = l.w_o; g.N = dm; g.K = dm; g.ldw = dm; g.out = x; g.ldo = dm; g.bias = l.b_o; g.resid = x;
         gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
-        // x += gelu_new(LN2(x) . W1^T + b1) . W2^T + b2
-        launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s);
-        g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
+        // GPT-Neo: x += MLP(LN2(x));  GPT-J (parallel block, HF:gptj:400-411): x += MLP(LN1(x_old)), `a` still holds it
+        if (!gptj) launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s);
+        g.A = a; g.lda = dm; g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
         gemm(c, dt, EPI_BIAS_GELU, dt, g, s);
         g.A = h; g.lda = ffn; g.W = l.w_proj; g.N = dm; g.K = ffn; g.ldw = ffn; g.out = x; g.ldo = dm;
         g.bias = l.b_proj; g.resid = x;

@@ -338,12 +338,14 @@ void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     if (direct) {
         if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_kernel<64>, grid, dim3(256), 0, s, a);
         else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_kernel<128>, grid, dim3(256), 0, s, a);
+        else if (a.dh == 256) hipLaunchKernelGGL(attn_bf16_kernel<256>, grid, dim3(256), 0, s, a);
         else abort();
         return;
     }
     dim3 grid2((a.max_alloc_len + 127) / 128, a.H, a.B);
     if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_lds_kernel<64>, grid2, dim3(512), 0, s, a);
     else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_lds_kernel<128>, grid2, dim3(512), 0, s, a);
+    else if (a.dh == 256) hipLaunchKernelGGL(attn_bf16_lds_kernel<256>, grid2, dim3(512), 0, s, a);
     else abort();
 }
 

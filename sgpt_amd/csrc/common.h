@@ -103,6 +103,9 @@ void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, i
 void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s);
 void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s);
 void launch_fill_f32(float* p, long n, float v, hipStream_t s);
+// GPT-J rotary embedding, in place on the q / k columns of the projection buffer
+void launch_rope(void* qk, int dtype, long ld, long k_off, const int* pos, const float* sin_t, const float* cos_t, int T,
+                 int H, int dh, int rotary_dim, hipStream_t s);
 void launch_fill_rand(void* p, long n, int dtype, unsigned seed, float scale, hipStream_t s);
 
 // top-k: one block per query row over a virtual row = [scores(n) | prev(n_prev)]

@@ -14,8 +14,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ ids,
     if (row >= T) return;
     const int lane = threadIdx.x & 63;
     const float4* a = reinterpret_cast<const float4*>(wte + (long)ids[row] * d);
-    const float4* b = reinterpret_cast<const float4*>(wpe + (long)pos[row] * d);
     float4* o = reinterpret_cast<float4*>(x + (long)row * d);
+    if (wpe == nullptr) {  // GPT-J: no learned position embedding (HF:gptj:484)
+        for (int c = lane; c < d / 4; c += 64) o[c] = a[c];
+        return;
+    }
+    const float4* b = reinterpret_cast<const float4*>(wpe + (long)pos[row] * d);
     for (int c = lane; c < d / 4; c += 64) {
         const float4 u = a[c], v = b[c];
         o[c] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
@@ -206,6 +210,36 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ i
     }
 }
 
+// ---- GPT-J rotary position embedding (HF:gptj/modeling_gptj.py:57-67,190-210) ----
+// For every token, head and pair i < rotary_dim/2 of the head's leading dims:
+//   (x[2i], x[2i+1]) <- (x[2i] cos - x[2i+1] sin, x[2i+1] cos + x[2i] sin),  angle = pos * inv_freq[i]
+// applied in place to q (column 0) and k (column k_off) of the projection buffer.  One thread per pair.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ buf, long ld, long k_off, const int* __restrict__ pos,
+                                                   const float* __restrict__ sin_t, const float* __restrict__ cos_t,
+                                                   int Tn, int H, int dh, int half) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_tok = (long)H * half;
+    if (idx >= (long)Tn * per_tok) return;
+    const int tkn = (int)(idx / per_tok);
+    const int rem = (int)(idx - (long)tkn * per_tok);
+    const int h = rem / half, i = rem - h * half;
+    const float sn = sin_t[(long)pos[tkn] * half + i], cs = cos_t[(long)pos[tkn] * half + i];
+    T* q = buf + (long)tkn * ld + (long)h * dh + 2 * i;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        T* ptr = q + which * k_off;
+        if constexpr (sizeof(T) == 4) {
+            const float2 v = *reinterpret_cast<const float2*>(ptr);
+            *reinterpret_cast<float2*>(ptr) = make_float2(v.x * cs - v.y * sn, v.y * cs + v.x * sn);
+        } else {
+            const uint32_t u = *reinterpret_cast<const uint32_t*>(ptr);
+            const float x0 = __uint_as_float(u << 16), x1 = __uint_as_float(u & 0xffff0000u);
+            *reinterpret_cast<uint32_t*>(ptr) = pack_bf16x2(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, long numel,
                                                        bf16_t* __restrict__ out) {
     const long stride = (long)gridDim.x * 256;
@@ -296,4 +330,15 @@ void launch_fill_rand(void* p, long n, int dtype, unsigned seed, float scale, hi
         hipLaunchKernelGGL(fill_rand_kernel<bf16_t>, dim3(cap_grid((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)p, n, seed, scale);
     else
         hipLaunchKernelGGL(fill_rand_kernel<float>, dim3(cap_grid((n + 255) / 256)), dim3(256), 0, s, (float*)p, n, seed, scale);
+}
+
+void launch_rope(void* qk, int dtype, long ld, long k_off, const int* pos, const float* sin_t, const float* cos_t, int T,
+                 int H, int dh, int rotary_dim, hipStream_t s) {
+    const int half = rotary_dim / 2;
+    const long n = (long)T * H * half;
+    const int grid = (int)((n + 255) / 256);
+    if (dtype == 1)
+        hipLaunchKernelGGL(rope_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)qk, ld, k_off, pos, sin_t, cos_t, T, H, dh, half);
+    else
+        hipLaunchKernelGGL(rope_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)qk, ld, k_off, pos, sin_t, cos_t, T, H, dh, half);
 }

@@ -33,6 +33,8 @@ class SGPTConfig:
     window_size: int = 256
     attention_layers: Optional[List[str]] = None
     layer_norm_epsilon: float = 1e-5
+    model_type: str = "gpt_neo"          # "gpt_neo" (SGPT-125M/1.3B/2.7B) | "gptj" (SGPT-5.8B)
+    rotary_dim: int = 0                   # GPT-J only (HF GPTJConfig.rotary_dim = 64)
 
     def __post_init__(self):
         if self.intermediate_size is None:
@@ -43,8 +45,14 @@ class SGPTConfig:
     @classmethod
     def from_hf_dict(cls, c: dict) -> "SGPTConfig":
         mt = c.get("model_type", "gpt_neo")
+        if mt == "gptj":   # HF GPTJConfig field names (HF:gptj/configuration_gptj.py)
+            return cls(vocab_size=c["vocab_size"], max_position_embeddings=c["n_positions"], hidden_size=c["n_embd"],
+                       num_layers=c["n_layer"], num_heads=c["n_head"], intermediate_size=c.get("n_inner"),
+                       layer_norm_epsilon=c.get("layer_norm_epsilon", 1e-5), model_type="gptj",
+                       rotary_dim=c.get("rotary_dim") or c["n_embd"] // c["n_head"], window_size=0,
+                       attention_layers=["global"] * c["n_layer"])
         if mt != "gpt_neo":
-            raise NotImplementedError(f"model_type {mt!r}: only GPT-Neo (SGPT-125M/1.3B/2.7B) is built in this round")
+            raise NotImplementedError(f"model_type {mt!r}: GPT-Neo and GPT-J are built; BLOOM is not yet")
         layers = c.get("attention_layers")
         if layers is None and c.get("attention_types"):
             layers = []
@@ -110,16 +118,23 @@ class SGPTModel:
         self.max_tokens_per_call = max_tokens_per_call
         lib = self.ctx.lib
         local = (C.c_uint8 * cfg.num_layers)(*[1 if a == "local" else 0 for a in cfg.attention_layers])
-        desc = ModelDesc(arch=_lib.SGPT_ARCH_GPTNEO, n_layers=cfg.num_layers, d_model=cfg.hidden_size,
-                         n_heads=cfg.num_heads, d_ffn=cfg.intermediate_size, vocab=cfg.vocab_size,
-                         max_pos=cfg.max_position_embeddings, window=cfg.window_size,
-                         ln_eps=cfg.layer_norm_epsilon, attn_scale=1.0,
+        gptj = cfg.model_type == "gptj"
+        dh = cfg.hidden_size // cfg.num_heads
+        desc = ModelDesc(arch=_lib.SGPT_ARCH_GPTJ if gptj else _lib.SGPT_ARCH_GPTNEO, n_layers=cfg.num_layers,
+                         d_model=cfg.hidden_size, n_heads=cfg.num_heads, d_ffn=cfg.intermediate_size,
+                         vocab=cfg.vocab_size, max_pos=cfg.max_position_embeddings, window=cfg.window_size,
+                         ln_eps=cfg.layer_norm_epsilon,
+                         attn_scale=float(1.0 / np.sqrt(np.float32(dh))) if gptj else 1.0,   # HF:gptj:96,148 / HF:gpt_neo:110
                          compute_dtype=SGPT_BF16 if dtype == "bf16" else SGPT_F32,
-                         layer_is_local=C.cast(local, C.POINTER(C.c_uint8)))
+                         layer_is_local=C.cast(local, C.POINTER(C.c_uint8)), rotary_dim=cfg.rotary_dim if gptj else 0)
+        if gptj:
+            weights = dict(weights)
+            weights["rotary.sin"], weights["rotary.cos"] = rotary_tables(cfg.max_position_embeddings, cfg.rotary_dim)
         names, keep = [], []
         for k, v in weights.items():
             k2 = k[len("transformer."):] if k.startswith("transformer.") else k
-            if k2.endswith("attn.attention.bias") or k2.endswith("masked_bias") or k2.startswith("lm_head"):
+            if (k2.endswith("attn.attention.bias") or k2.endswith("attn.bias") or k2.endswith("masked_bias")
+                    or k2.endswith("embed_positions") or k2.startswith("lm_head")):
                 continue
             t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
             t = t.to(device=self.device, dtype=torch.float32).contiguous()   # H2D staging only
@@ -228,6 +243,14 @@ class SGPTModel:
         _, hid = self.encode_packed(pb, layer_idx=layer_idx, return_hidden=True)
         off = pb.seq_off.cpu().tolist()
         return [hid[off[i]: off[i] + len(s)] for i, s in enumerate(seqs)]
+
+
+def rotary_tables(max_pos: int, dim: int):
+    """HF create_sinusoidal_positions (HF:gptj/modeling_gptj.py:47-50) in float32: sin, cos [max_pos, dim/2]."""
+    f32 = np.float32
+    inv_freq = (f32(1.0) / (f32(10000.0) ** (np.arange(0, dim, 2).astype(f32) / f32(dim)))).astype(f32)
+    ang = (np.arange(max_pos).astype(f32)[:, None] * inv_freq[None, :]).astype(f32)
+    return np.sin(ang).astype(f32), np.cos(ang).astype(f32)
 
 
 def synthetic_weights(cfg: SGPTConfig, seed: int = 0, std: float = 0.02) -> Dict[str, np.ndarray]:

@@ -89,6 +89,21 @@ def hf_model(cfg: O.NeoConfig, w):
     return m
 
 
+def hf_model_gptj(cfg, w):
+    from transformers import GPTJConfig, GPTJModel
+    hc = GPTJConfig(vocab_size=cfg.vocab_size, n_positions=cfg.max_position_embeddings, n_embd=cfg.hidden_size,
+                    n_layer=cfg.num_layers, n_head=cfg.num_heads, rotary_dim=cfg.rotary_dim,
+                    n_inner=cfg.intermediate_size, layer_norm_epsilon=cfg.layer_norm_epsilon,
+                    resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0, activation_function="gelu_new")
+    hc._attn_implementation = "eager"
+    m = GPTJModel(hc).eval()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in w.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("attn.bias" in k or "masked_bias" in k or "embed_positions" in k for k in missing), missing
+    return m
+
+
 def rand_seqs(rng, n, lo, hi, vocab):
     return [rng.integers(0, vocab, size=int(rng.integers(lo, hi + 1))).tolist() for _ in range(n)]
 
@@ -100,10 +115,15 @@ def check(name, got, want, tol):
     return err
 
 
-def encoder_case(tag, cfg_kw, seed, seqs, pad_side="right", std=0.02, store_hidden=False, Pooling=None):
-    cfg = O.NeoConfig(**cfg_kw)
-    w = O.synth_weights(cfg, seed=seed, std=std)
-    model = hf_model(cfg, w)
+def encoder_case(tag, cfg_kw, seed, seqs, pad_side="right", std=0.02, store_hidden=False, Pooling=None, arch="gpt_neo"):
+    if arch == "gptj":
+        cfg = O.GPTJConfig(**cfg_kw)
+        w = O.synth_weights_gptj(cfg, seed=seed, std=std)
+        model = hf_model_gptj(cfg, w)
+    else:
+        cfg = O.NeoConfig(**cfg_kw)
+        w = O.synth_weights(cfg, seed=seed, std=std)
+        model = hf_model(cfg, w)
     ids, mask = O.pad_batch(seqs, pad_id=min(O.GPT2_PAD, cfg.vocab_size - 1), side=pad_side)
     with torch.no_grad():
         out = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
@@ -132,7 +152,7 @@ def encoder_case(tag, cfg_kw, seed, seqs, pad_side="right", std=0.02, store_hidd
                          "attention_mask": torch.from_numpy(mask)})["sentence_embedding"].numpy()
 
     # ---- pin the oracle ----
-    o_last, o_hs = O.gptneo_forward(w, cfg, ids, mask, output_hidden_states=True)
+    o_last, o_hs = O.forward_any(w, cfg, ids, mask, output_hidden_states=True)
     real = mask.astype(bool)
     check(f"{tag} last_hidden (real tokens)", o_last[real], last[real], 2e-4)
     for li in (0, 1, len(hs) - 2):
@@ -143,7 +163,7 @@ def encoder_case(tag, cfg_kw, seed, seqs, pad_side="right", std=0.02, store_hidd
     enc = O.encode(w, cfg, seqs, mode="weightedmean", batch_size=len(seqs), pad_side=pad_side)
     check(f"{tag} encode()", enc, emb["weightedmean"], 2e-4)
 
-    fx = dict(cfg=np.array(repr(cfg_kw)), seed=seed, std=std, pad_side=np.array(pad_side),
+    fx = dict(cfg=np.array(repr(cfg_kw)), arch=np.array(arch), seed=seed, std=std, pad_side=np.array(pad_side),
               seq_lens=np.array([len(s) for s in seqs]), ids=ids.astype(np.int32), mask=mask.astype(np.int8),
               emb_weightedmean=emb["weightedmean"], emb_mean=emb["mean"], emb_lasttoken=emb["lasttoken"],
               emb_weightedmean_layer_m2=emb_l2)
@@ -155,6 +175,7 @@ def encoder_case(tag, cfg_kw, seed, seqs, pad_side="right", std=0.02, store_hidd
 
 
 def main():
+    only_j = bool(os.environ.get("GOLDEN_ONLY_GPTJ"))
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
     Pooling = load_file_module("ref_pooling", f"{ST}/models/Pooling.py")
@@ -162,6 +183,9 @@ def main():
     ES = load_ref_exact_search(U)
 
     # ---------------- encoder + pooling ----------------
+    if only_j:
+        _gptj_cases(Pooling)
+        return
     tiny = dict(vocab_size=211, max_position_embeddings=96, hidden_size=128, num_layers=4,
                 num_heads=2, window_size=8)
     rng = np.random.default_rng(100)
@@ -184,7 +208,23 @@ def main():
     qs = [O.specb_wrap(rng.integers(0, 50256, size=n).tolist(), is_query=True) for n in (30, 7)]
     encoder_case("cfg3_125m_specb_s300", O.SGPT_125M, seed=2, seqs=docs + qs, Pooling=Pooling)
 
+    _gptj_cases(Pooling)
+
     # ---------------- scoring / top-k (reference util.py + exact_search.py) ----------------
+    _scoring_cases(U, ES)
+
+
+def _gptj_cases(Pooling):
+    # GPT-J family (SGPT-5.8B, BASELINE config 4): head_dim 256, rotary_dim 64, parallel block
+    tinyj = dict(vocab_size=211, n_positions=96, n_embd=512, n_layer=2, n_head=2, rotary_dim=64)
+    rng = np.random.default_rng(300)
+    encoder_case("tiny_gptj_right", tinyj, seed=31, seqs=rand_seqs(rng, 7, 1, 70, 211), std=0.04,
+                 store_hidden=True, Pooling=Pooling, arch="gptj")
+    encoder_case("tiny_gptj_left", tinyj, seed=31, seqs=rand_seqs(rng, 5, 2, 40, 211), pad_side="left", std=0.04,
+                 store_hidden=True, Pooling=Pooling, arch="gptj")
+
+
+def _scoring_cases(U, ES):
     rng = np.random.default_rng(7)
     a = rng.standard_normal((50, 100)).astype(np.float32)
     b = rng.standard_normal((37, 100)).astype(np.float32)

@@ -24,13 +24,25 @@ def load_case(tag):
 _models = {}
 
 
+def oracle_cfg_weights(cfg_kw, seed, std, bf16_linear=False):
+    if "n_embd" in cfg_kw:      # GPT-J field names
+        cfg = O.GPTJConfig(**cfg_kw)
+        return cfg, O.synth_weights_gptj(cfg, seed=seed, std=std, bf16_linear=bf16_linear)
+    cfg = O.NeoConfig(**cfg_kw)
+    return cfg, O.synth_weights(cfg, seed=seed, std=std, bf16_linear=bf16_linear)
+
+
 def build_model(cfg_kw, seed, std, dtype):
     """SGPTModel on cuda:0 with the oracle's seeded synthetic weights (cached per test session)."""
     from sgpt_amd import SGPTConfig, SGPTModel
     key = (repr(sorted(cfg_kw.items())), seed, std, dtype)
     if key not in _models:
-        w = O.synth_weights(O.NeoConfig(**cfg_kw), seed=seed, std=std)
-        _models[key] = SGPTModel(SGPTConfig(**cfg_kw), w, device="cuda:0", dtype=dtype)
+        _, w = oracle_cfg_weights(cfg_kw, seed, std)
+        if "n_embd" in cfg_kw:
+            scfg = SGPTConfig.from_hf_dict(dict(cfg_kw, model_type="gptj"))
+        else:
+            scfg = SGPTConfig(**cfg_kw)
+        _models[key] = SGPTModel(scfg, w, device="cuda:0", dtype=dtype)
     return _models[key]
 
 

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == declared
     assert lib.sgpt_abi_version() == 1
     # struct layout mirrors the header
-    assert ctypes.sizeof(_lib.ModelDesc) == 56 and ctypes.sizeof(_lib.TensorView) == 24
+    assert ctypes.sizeof(_lib.ModelDesc) == 64 and ctypes.sizeof(_lib.TensorView) == 24
 
 
 def test_no_gpu_means_loud_failure():

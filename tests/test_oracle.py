@@ -14,7 +14,8 @@ from oracle import sgpt_oracle as O
 
 def load_case(golden_dir, tag):
     fx = np.load(os.path.join(golden_dir, f"{tag}.npz"))
-    cfg = O.NeoConfig(**ast.literal_eval(str(fx["cfg"])))
+    kw = ast.literal_eval(str(fx["cfg"]))
+    cfg = O.GPTJConfig(**kw) if "n_embd" in kw else O.NeoConfig(**kw)
     lens = fx["seq_lens"].tolist()
     ids, mask = fx["ids"].astype(np.int64), fx["mask"].astype(np.int64)
     side = str(fx["pad_side"])
@@ -22,11 +23,14 @@ def load_case(golden_dir, tag):
     return fx, cfg, seqs, ids, mask, side
 
 
-@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128"])
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128", "tiny_gptj_right", "tiny_gptj_left"])
 def test_oracle_encoder_matches_hf_golden(golden_dir, tag):
     fx, cfg, seqs, ids, mask, side = load_case(golden_dir, tag)
-    w = O.synth_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
-    last, hs = O.gptneo_forward(w, cfg, ids, mask, output_hidden_states=True)
+    if isinstance(cfg, O.GPTJConfig):
+        w = O.synth_weights_gptj(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    else:
+        w = O.synth_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    last, hs = O.forward_any(w, cfg, ids, mask, output_hidden_states=True)
     real = mask.astype(bool)
     assert np.abs(last[real] - fx["last_hidden"][real]).max() < 2e-4
     assert np.abs(hs[1][real] - fx["hidden_1"][real]).max() < 2e-4
