@@ -27,6 +27,41 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 SGPT_125M = dict(vocab_size=50257, max_position_embeddings=2048, hidden_size=768, num_layers=12, num_heads=12,
                  window_size=256)
+# other SGPT sizes (not the default metric; `--model`): shapes from SURVEY.md 8
+MODELS = {
+    "125m": dict(SGPT_125M),
+    "1.3b": dict(vocab_size=50257, max_position_embeddings=2048, hidden_size=2048, num_layers=24, num_heads=16, window_size=256),
+    "2.7b": dict(vocab_size=50257, max_position_embeddings=2048, hidden_size=2560, num_layers=32, num_heads=20, window_size=256),
+    "5.8b": dict(model_type="gptj", vocab_size=50400, n_positions=2048, n_embd=4096, n_layer=28, n_head=16, rotary_dim=64),
+}
+
+
+def device_random_weights(cfg, device, seed=1, std=0.02):
+    """Random-init weights generated directly in HBM (the 5.8B model is 23 GB in fp32: not worth a host
+    round trip for a throughput measurement).  HF state-dict names; same scales as synthetic_weights."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    d, ffn, gptj = cfg.hidden_size, cfg.intermediate_size, cfg.model_type == "gptj"
+
+    def nrm(*shape, s=std, mean=0.0):
+        return torch.randn(shape, generator=g, device=device, dtype=torch.float32) * s + mean
+
+    w = {"wte.weight": nrm(cfg.vocab_size, d)}
+    if not gptj:
+        w["wpe.weight"] = nrm(cfg.max_position_embeddings, d, s=std / 2)
+    attn = "attn." if gptj else "attn.attention."
+    fc1, fc2 = ("mlp.fc_in", "mlp.fc_out") if gptj else ("mlp.c_fc", "mlp.c_proj")
+    for i in range(cfg.num_layers):
+        p = f"h.{i}."
+        w[p + "ln_1.weight"], w[p + "ln_1.bias"] = nrm(d, s=0.1, mean=1.0), nrm(d, s=0.05)
+        if not gptj:
+            w[p + "ln_2.weight"], w[p + "ln_2.bias"] = nrm(d, s=0.1, mean=1.0), nrm(d, s=0.05)
+            w[p + attn + "out_proj.bias"] = nrm(d)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            w[p + attn + n + ".weight"] = nrm(d, d)
+        w[p + fc1 + ".weight"], w[p + fc1 + ".bias"] = nrm(ffn, d), nrm(ffn)
+        w[p + fc2 + ".weight"], w[p + fc2 + ".bias"] = nrm(d, ffn), nrm(d)
+    w["ln_f.weight"], w["ln_f.bias"] = nrm(d, s=0.1, mean=1.0), nrm(d, s=0.05)
+    return w
 
 
 def flops_per_sentence(S, L=12, d=768):
@@ -45,6 +80,7 @@ def main():
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="125m", choices=sorted(MODELS), help="SGPT size (default: the BASELINE metric's 125M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the queries/sec @ 1M-doc scoring leg")
     ap.add_argument("--cpu-sample", type=int, default=48, help="sentences in the bounded CPU-baseline sample")
@@ -63,9 +99,12 @@ def main():
 
     from sgpt_amd import SGPTConfig, SGPTModel, get_context, synthetic_weights
     ctx = get_context(dev)
-    cfg = SGPTConfig(**SGPT_125M)
-    model = SGPTModel(cfg, synthetic_weights(cfg, seed=1), device=dev, dtype=args.dtype,
-                      max_tokens_per_call=args.call * args.seq)
+    mkw = MODELS[args.model]
+    cfg = SGPTConfig.from_hf_dict(mkw) if mkw.get("model_type") == "gptj" else SGPTConfig(**mkw)
+    weights = synthetic_weights(cfg, seed=1) if args.model == "125m" else device_random_weights(cfg, dev)
+    model = SGPTModel(cfg, weights, device=dev, dtype=args.dtype, max_tokens_per_call=args.call * args.seq)
+    del weights
+    torch.cuda.empty_cache()
     d, S, k1 = cfg.hidden_size, args.seq, args.topk + 1      # the reference keeps top_k+1 (exact_search.py:104)
     score_dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
@@ -80,7 +119,7 @@ def main():
         for _ in range(calls_per_step):
             nb = min(args.call, left)
             left -= nb
-            ids = rng.integers(0, 50256, size=(nb, S), dtype=np.int64)
+            ids = rng.integers(0, min(50256, cfg.vocab_size), size=(nb, S), dtype=np.int64)
             row.append(model.pack([r for r in ids.tolist()]))
         packed.append(row)
     # queries: lengths U{4..32}; encoded sharded by rank, then ONE all-gather
@@ -203,11 +242,11 @@ def main():
                 "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(n_launch, 1), 5),
                 "gemm_share_of_step": round(gemm_ms * 1e-3 / dt, 4),
                 "end_to_end_frac_of_mfma_roofline": round(
-                    sent_per_s / world * flops_per_sentence(S) / (PEAK_BF16_TFLOPS * 1e12), 4)}
+                    sent_per_s / world * flops_per_sentence(S, cfg.num_layers, cfg.hidden_size) / (PEAK_BF16_TFLOPS * 1e12), 4)}
 
     # ---- CPU baseline: the numpy oracle (a port of the reference CPU path) on a bounded sample ----
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and args.model == "125m":
         from oracle import sgpt_oracle as O      # checker / reported baseline only, never the measured path
         ocfg = O.NeoConfig(**SGPT_125M)
         ow = O.synth_weights(ocfg, seed=1)
@@ -227,7 +266,8 @@ def main():
            "value": round(sent_per_s, 1), "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": "BASELINE configs[1]: SGPT-125M-shape random-init weights, bf16 MFMA, "
+           "config": {"workload": ("BASELINE configs[1]: SGPT-125M" if args.model == "125m" else f"SGPT-{args.model.upper()}") +
+                                  "-shape random-init weights, " + args.dtype + " MFMA, "
                                   f"{args.steps * args.chunk} docs/GPU x seq_len {S}, nq={args.nq}, cosine top-{args.topk} "
                                   "(top_k+1 kept), corpus rows bf16 in HBM",
                       "docs_per_step": args.chunk, "docs_per_encode_call": args.call, "seq_len": S, "nq": args.nq,

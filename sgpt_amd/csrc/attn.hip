@@ -22,6 +22,11 @@
 
 namespace {
 
+#ifndef SGPT_ATTN_NT
+#define SGPT_ATTN_NT 1
+#endif
+constexpr bool ATTN_NT = SGPT_ATTN_NT != 0;
+
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs p) {
     constexpr int KS = DH / 32;  // k-slices of the QK^T contraction
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
     for (int h = 0; h < 16 / RPI; ++h) {
         const int row = h * RPI + lane / CPR, ch = lane % CPR;
         const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
-        *reinterpret_cast<uint4*>(obase + (long)row * p.ldo + ch * 8) = v;
+        gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);
     }
 }
 

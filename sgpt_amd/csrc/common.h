@@ -26,6 +26,31 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
+// 16-byte global store.  NT = non-temporal (`global_store_dwordx4 ... nt`): for streaming outputs the producing
+// kernel never re-reads.  Measured on the GEMM epilogues: plain stores write-allocate in the 4 MiB XCD L2 and
+// evict the activation / weight panels the k-loop is sharing (QK projection 369 -> 297 us with nt).
+template <bool NT>
+__device__ __forceinline__ void gstore16(void* ptr, uint4 v) {
+    if constexpr (NT) {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(ptr));
+    } else {
+        *reinterpret_cast<uint4*>(ptr) = v;
+    }
+}
+
+template <bool NT>
+__device__ __forceinline__ float4 ldg16(const float* ptr) {
+    if constexpr (NT) {
+        typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+        const f32x4v_t w = __builtin_nontemporal_load(reinterpret_cast<const f32x4v_t*>(ptr));
+        return make_float4(w[0], w[1], w[2], w[3]);
+    } else {
+        return *reinterpret_cast<const float4*>(ptr);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -27,6 +27,14 @@
 
 namespace {
 
+#ifndef SGPT_RESID_NT
+#define SGPT_RESID_NT 0
+#endif
+constexpr bool RESID_NT = SGPT_RESID_NT != 0;
+#ifndef SGPT_RESID_LD_NT
+#define SGPT_RESID_LD_NT 0
+#endif
+constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 constexpr int BM = 128, BN = 128, CH = 8;  // CH = 16-byte chunks per row per k-step
 
 template <typename T> struct ElemTraits;
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                     const int row = h * 8 + rrow;
                     const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
                     const int m = m0 + wm * 128 + i * 16 + row;
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (long)m * p.ldo + n0 + wn * 64 + rchunk * 8) = v;
+                    gstore16<true>(reinterpret_cast<bf16_t*>(out) + (long)m * p.ldo + n0 + wn * 64 + rchunk * 8, v);
                 }
             }
         } else if constexpr (SWAP) {
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                 if constexpr (EPI == EPI_BIAS_RESID) {
 #pragma unroll
                     for (int h = 0; h < 4; ++h)
-                        rr[h] = *reinterpret_cast<const float4*>(p.resid + gbase + (long)(i * 16 + h * 4) * p.ldo);
+                        rr[h] = ldg16<RESID_LD_NT>(p.resid + gbase + (long)(i * 16 + h * 4) * p.ldo);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                     if constexpr (EPI == EPI_BIAS_RESID) {
                         v.x += bb.x + rr[h].x; v.y += bb.y + rr[h].y; v.z += bb.z + rr[h].z; v.w += bb.w + rr[h].w;
                     }
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + gbase + (long)(i * 16 + h * 4) * p.ldo) = v;
+                    gstore16<RESID_NT>(reinterpret_cast<float*>(out) + gbase + (long)(i * 16 + h * 4) * p.ldo, __builtin_bit_cast(uint4, v));
                 }
             }
         } else {
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                     const int row = h * 4 + rrow;
                     const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
                     const int n = n0 + wn * 64 + j * 16 + row;
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (long)n * p.ldo + m0 + wm * 128 + rchunk * 8) = v;
+                    gstore16<true>(reinterpret_cast<bf16_t*>(out) + (long)n * p.ldo + m0 + wm * 128 + rchunk * 8, v);
                 }
             }
         }
