@@ -513,7 +513,7 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
     hipEvent_t e0, e1;
     HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
     long long* dbg = nullptr;
-    if (getenv("SGPT_GEMM_DBG")) { HIPC(c, hipMalloc((void**)&dbg, 64 * 8)); HIPC(c, hipMemset(dbg, 0, 64 * 8)); g.dbg = dbg; }
+    if (getenv("SGPT_GEMM_DBG")) { HIPC(c, hipMalloc((void**)&dbg, 128 * 8)); HIPC(c, hipMemset(dbg, 0, 128 * 8)); g.dbg = dbg; }
     for (int i = 0; i < 3; ++i) launch_gemm(dtype, epi, out_dtype, g, 0);
     HIPC(c, hipEventRecord(e0, 0));
     for (int i = 0; i < iters; ++i) launch_gemm(dtype, epi, out_dtype, g, 0);
@@ -523,13 +523,15 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
     HIPC(c, hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / iters;
     if (dbg) {
-        long long h[64];
+        long long h[128];
         HIPC(c, hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-        for (int tl = 0; tl < 6; ++tl) {
+        for (int tl = 0; tl < 4; ++tl) {
             const long long* r = h + tl * 8;
-            fprintf(stderr, "tile %d: kloop_end->dma_wait %lld | ->barrier %lld | epilogue %lld | next: step0 barrier@%lld  step1 wait@%lld barrier@%lld (cycles rel. to k-loop end)  tile-to-tile %lld\n",
-                    tl, r[1] - r[0], r[2] - r[1], r[3] - r[2], h[(tl + 1) * 8 + 4] - r[0], h[(tl + 1) * 8 + 5] - r[0],
-                    h[(tl + 1) * 8 + 6] - r[0], h[(tl + 1) * 8 + 0] - r[0]);
+            const long long* ks = h + 64 + tl * 16;
+            fprintf(stderr, "tile %d: k-step starts (rel. to step 0):", tl);
+            for (int q = 1; q < 12; ++q) fprintf(stderr, " %lld", ks[q] - ks[0]);
+            fprintf(stderr, " | kloop_end %lld  dma_wait +%lld  barrier +%lld  epilogue +%lld | next tile step0 at %lld\n",
+                    r[0] - ks[0], r[1] - r[0], r[2] - r[1], r[3] - r[2], h[64 + (tl + 1) * 16] - ks[0]);
         }
         hipFree(dbg);
     }

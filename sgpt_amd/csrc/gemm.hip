@@ -385,10 +385,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             // BEFORE the previous epilogue issued its stores (below), so those stores get a whole k-step
             // of MFMAs to drain before the next vmcnt(0) (CDNA vmcnt counts stores as well).
             if (kt > 0 || first_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (kt == 1) STAMP(5);
             __syncthreads();                                   // everyone's has; the other stage is free
-            if (kt == 0) STAMP(4);
-            if (kt == 1) STAMP(6);
+            if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 4 && kt < 12)
+                p.dbg[64 + dbg_tile * 16 + kt] = (long long)__builtin_amdgcn_s_memtime();
             // prefetch target: next k-step of this tile, or step 0 of the next tile; the very last step
             // of the last tile re-fetches its own step 0 into the idle stage (harmless, keeps the loop
             // branch-free: a branch per DMA piece splits the MFMA block and makes hipcc spill)

@@ -87,3 +87,64 @@ class SentenceTransformerSGPT:
         if input_was_string:
             emb = emb[0]
         return emb
+
+
+# ---- multi-process pool: SentenceTransformer.start_multi_process_pool / encode_multi_process (:257-353) ----
+def _pool_worker(target_device, model_factory, input_queue, results_queue):
+    """One process per device (SentenceTransformer._encode_multi_process_worker, :335-353): pulls
+    [chunk_id, batch_size, sentences] items, pushes [chunk_id, embeddings ndarray]."""
+    import queue as _q
+    model = model_factory(target_device)
+    while True:
+        try:
+            item = input_queue.get()
+            if item is None:
+                break
+            chunk_id, batch_size, sentences = item
+            emb = model.encode(sentences, batch_size=batch_size, convert_to_numpy=True, show_progress_bar=False)
+            results_queue.put([chunk_id, emb])
+        except _q.Empty:
+            break
+
+
+def start_multi_process_pool(model_factory, target_devices: List[str] = None):
+    """SentenceTransformer.start_multi_process_pool (:257-285): one spawned process per target device
+    (default: every visible GPU).  `model_factory(device) -> SentenceTransformerSGPT` is called inside each
+    worker (device handles cannot be pickled across processes; the reference re-moves the pickled model)."""
+    import torch.multiprocessing as mp
+    if target_devices is None:
+        target_devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
+    ctx = mp.get_context("spawn")
+    input_queue, output_queue, processes = ctx.Queue(), ctx.Queue(), []
+    for dev in target_devices:
+        p = ctx.Process(target=_pool_worker, args=(dev, model_factory, input_queue, output_queue), daemon=True)
+        p.start()
+        processes.append(p)
+    return {"input": input_queue, "output": output_queue, "processes": processes}
+
+
+def stop_multi_process_pool(pool):
+    """SentenceTransformer.stop_multi_process_pool (:288-301)."""
+    for _ in pool["processes"]:
+        pool["input"].put(None)
+    for p in pool["processes"]:
+        p.join(60)
+        if p.is_alive():
+            p.terminate()
+    pool["input"].close()
+    pool["output"].close()
+
+
+def encode_multi_process(sentences: List[str], pool, batch_size: int = 32, chunk_size: int = None) -> np.ndarray:
+    """SentenceTransformer.encode_multi_process (:304-332): sentences are cut into chunks
+    (min(ceil(n / procs / 10), 5000) by default, :317-318), sent to the workers, results concatenated in order."""
+    import math
+    if chunk_size is None:
+        chunk_size = min(math.ceil(len(sentences) / len(pool["processes"]) / 10), 5000)
+    chunk_size = max(1, chunk_size)
+    n_chunks = 0
+    for start in range(0, len(sentences), chunk_size):
+        pool["input"].put([n_chunks, batch_size, sentences[start:start + chunk_size]])
+        n_chunks += 1
+    results = sorted([pool["output"].get() for _ in range(n_chunks)], key=lambda x: x[0])
+    return np.concatenate([r[1] for r in results])

@@ -173,3 +173,34 @@ def test_st_encode_and_useb_semb_fn():
     dd = sb.encode_corpus([{"title": "paris", "text": "the cell"}])
     wd = O.encode(w, cfg, [O.specb_wrap(tok.convert_tokens_to_ids(tok.tokenize("paris the cell")), False)])
     assert maxabs(dd, wd) < 1e-3
+
+
+def _mp_factory(device):
+    """Runs inside each pool worker: rebuild the tiny model from its seed on that device."""
+    import ast, os
+    import numpy as np
+    from oracle import sgpt_oracle as O
+    from sgpt_amd import SGPTConfig, SGPTModel
+    from sgpt_amd.st import SentenceTransformerSGPT
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_right.npz"))
+    kw = ast.literal_eval(str(fx["cfg"]))
+    w = O.synth_weights(O.NeoConfig(**kw), seed=int(fx["seed"]), std=float(fx["std"]))
+    return SentenceTransformerSGPT(SGPTModel(SGPTConfig(**kw), w, device=device, dtype="fp32"),
+                                   SyntheticTokenizer(kw["vocab_size"]), max_seq_length=50)
+
+
+@pytest.mark.timeout(300)
+def test_encode_multi_process_matches_single_process():
+    """sentence-transformers/tests/test_multi_process.py:14-29 restated: a pool of two worker processes
+    (both on cuda:0 here, as the reference's test uses ['cpu','cpu']) must reproduce encode() within 1e-3."""
+    from sgpt_amd.st import encode_multi_process, start_multi_process_pool, stop_multi_process_pool
+    rng = np.random.default_rng(4)
+    sentences = _texts(rng, 203, 1, 30)
+    single = _mp_factory("cuda:0").encode(sentences)
+    pool = start_multi_process_pool(_mp_factory, ["cuda:0", "cuda:0"])
+    try:
+        emb = encode_multi_process(sentences, pool, batch_size=16, chunk_size=50)
+    finally:
+        stop_multi_process_pool(pool)
+    assert emb.shape == single.shape and np.abs(emb - single).max() < 1e-3
