@@ -207,10 +207,13 @@ def main():
     if not args.no_1m:
         n1m = 1_000_000 // world                           # 1M-doc corpus sharded over the ranks
         big = torch.empty((n1m, d), dtype=score_dt, device=dev)
-        blk = corpus[args.warmup * args.chunk:]
-        for s0 in range(0, n1m, blk.shape[0]):             # tile the encoded (anisotropic) embeddings
-            e0 = min(n1m, s0 + blk.shape[0])
-            big[s0:e0] = blk[: e0 - s0]
+        blk = corpus[args.warmup * args.chunk:].float()
+        gen = torch.Generator(device=dev).manual_seed(99 + rank)
+        for s0 in range(0, n1m, blk.shape[0]):             # synthetic 1M shard: the encoded (anisotropic) embeddings,
+            e0 = min(n1m, s0 + blk.shape[0])               # each copy perturbed so that scores are not exact duplicates
+            noisy = blk[: e0 - s0] + 0.02 * torch.randn((e0 - s0, d), generator=gen, device=dev)
+            big[s0:e0] = torch.nn.functional.normalize(noisy, dim=1).to(score_dt)
+        del blk
         qps_1m = time_search(big, reps=3)
         if dist_on:
             tq = torch.tensor([qps_1m], dtype=torch.float64, device=dev)

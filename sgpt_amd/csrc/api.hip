@@ -422,18 +422,34 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     if (st != SGPT_OK) return st;
     HIPC(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    // chunk the corpus so the fp32 score tile [nq, chunk] stays resident in the 256 MiB Infinity Cache
-    const size_t budget = (size_t)96 << 20;
+    // chunk the corpus so the fp32 score tile [nq, chunk] stays resident in the 256 MiB Infinity Cache, and so
+    // that the score GEMM has a whole number of 256-CU waves of 256x256 tiles (query tiles x document tiles)
+    const size_t budget = (size_t)160 << 20;
+    const int mtq = (nq + 255) / 256;
+    long unit = 256;                                  // documents per chunk granule
+    { int g = mtq, h = 256; while (h) { int r = g % h; g = h; h = r; } unit = 256L * (256 / g); }
     long chunk = (long)(budget / ((size_t)nq * 4));
-    chunk = chunk / 128 * 128;
-    if (chunk < 128) chunk = 128;
-    if (chunk > 65536) chunk = 65536;
+    if (chunk >= unit) chunk = chunk / unit * unit;
+    else { chunk = chunk / 256 * 256; if (chunk < 256) chunk = 256; }
+    if (chunk > 131072) chunk = 131072;
     if (chunk > N) chunk = (long)align_up((size_t)N, 4);
     const size_t sc_bytes = align_up((size_t)nq * chunk * 4, 256);
     const size_t tv_bytes = align_up((size_t)nq * k * 4, 256), ti_bytes = align_up((size_t)nq * k * 8, 256);
-    st = ensure(c, &c->ws2, &c->ws2_bytes, sc_bytes + 2 * (tv_bytes + ti_bytes));
+    // bf16 fast path: the 256x256 LDS-DMA GEMM needs the query rows padded to a multiple of 256 (zero rows,
+    // never stored) and d % 64 == 0; chunks that are multiples of 256 documents take it, the ragged tail and
+    // fp32 go through the 128^2 kernel.
+    const bool fast = dtype == SGPT_BF16 && d % 64 == 0;
+    const int nq_pad = (nq + 255) / 256 * 256;
+    const size_t qp_bytes = fast ? align_up((size_t)nq_pad * d * 2, 256) : 0;
+    st = ensure(c, &c->ws2, &c->ws2_bytes, sc_bytes + 2 * (tv_bytes + ti_bytes) + qp_bytes);
     if (st != SGPT_OK) return st;
     char* base = (char*)c->ws2;
+    void* qpad = nullptr;
+    if (fast) {
+        qpad = base + sc_bytes + 2 * (tv_bytes + ti_bytes);
+        HIPC(c, hipMemsetAsync(qpad, 0, (size_t)nq_pad * d * 2, s));
+        HIPC(c, hipMemcpyAsync(qpad, q, (size_t)nq * d * 2, hipMemcpyDeviceToDevice, s));
+    }
     float* sc = (float*)base;
     float* tv[2] = {(float*)(base + sc_bytes), (float*)(base + sc_bytes + tv_bytes)};
     int64_t* ti[2] = {(int64_t*)(base + sc_bytes + 2 * tv_bytes), (int64_t*)(base + sc_bytes + 2 * tv_bytes + ti_bytes)};
@@ -449,6 +465,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         g.A = q; g.lda = d; g.M = nq; g.m_valid = nq; g.K = d;
         g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = d; g.N = (int)nc;
         g.out = sc; g.ldo = chunk;
+        if (fast && nc % 256 == 0) { g.A = qpad; g.M = nq_pad; }
         gemm(c, dtype, EPI_SCORE, SGPT_F32, g, s);
         const bool last = c0 + nc >= N;
         float* ov = last ? run_val : tv[cur];

@@ -259,20 +259,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     const int N = p.N, K = p.K;
     const int MT = p.M / TM, NT = N / TN;
     // Persistent: one workgroup per CU walks tiles b, b+grid, ... (grid is a multiple of 8, so a
-    // workgroup's tiles stay on its XCD).  Tile order inside an XCD = 4 x 8 supertiles, so the ~32
-    // tiles in flight per XCD share 4 activation panels and <= 8 weight panels in the 4 MiB L2.
+    // workgroup's tiles stay on its XCD).  The LONGER tile axis ("major": tokens for the encoder GEMMs,
+    // documents for the scorer) is interleaved over the 8 XCDs; inside an XCD tiles are ordered in
+    // 4 (major) x 8 (minor) supertiles so the ~32 tiles in flight share 4 + 8 operand panels in the L2.
     constexpr int GM = 4, GN = 8;
-    const int per_band = GM * NT;
-    const int tiles_total = ((MT + 7) / 8 + GM - 1) / GM * GM * 8 * NT;   // padded tile-id space
+    const bool m_major = MT >= NT;
+    const int AT = m_major ? MT : NT, BT = m_major ? NT : MT;   // major / minor tile counts
+    const int per_band = GM * BT;
+    const int tiles_total = ((AT + 7) / 8 + GM - 1) / GM * GM * 8 * BT;   // padded tile-id space
     auto tile_coords = [&](int tile, int& m0, int& n0) -> bool {
         const int xcd = tile & 7, local = tile >> 3;
         const int band = local / per_band, inb = local % per_band;
         const int ng = inb / (GM * GN);
-        const int gn = (NT - ng * GN) < GN ? (NT - ng * GN) : GN;
+        const int gn = (BT - ng * GN) < GN ? (BT - ng * GN) : GN;
         const int r = inb - ng * GM * GN;
-        const int mt = xcd + 8 * (band * GM + r / gn), nt = ng * GN + r % gn;
-        m0 = mt * TM; n0 = nt * TN;
-        return mt < MT;
+        const int at = xcd + 8 * (band * GM + r / gn), bt = ng * GN + r % gn;
+        m0 = (m_major ? at : bt) * TM; n0 = (m_major ? bt : at) * TN;
+        return at < AT;
     };
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -478,6 +481,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                     if constexpr (EPI == EPI_BIAS_RESID) {
                         v.x += bb.x + rr[h].x; v.y += bb.y + rr[h].y; v.z += bb.z + rr[h].z; v.w += bb.w + rr[h].w;
                     }
+                    if constexpr (EPI == EPI_SCORE) {   // cos_scores[isnan] = -1 (exact_search.py:99); padded query rows skipped
+                        v.x = v.x != v.x ? -1.0f : v.x; v.y = v.y != v.y ? -1.0f : v.y;
+                        v.z = v.z != v.z ? -1.0f : v.z; v.w = v.w != v.w ? -1.0f : v.w;
+                        if (m0 + wm * 128 + i * 16 + h * 4 + rrow >= p.m_valid) continue;
+                    }
                     gstore16<RESID_NT>(reinterpret_cast<float*>(out) + gbase + (long)(i * 16 + h * 4) * p.ldo, __builtin_bit_cast(uint4, v));
                 }
             }
@@ -512,7 +520,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 template <int EPI, typename OutT, bool SWAP>
 void launch256(const GemmArgs& a, hipStream_t s) {
     const int MT = a.M / 256, NT = a.N / 256;
-    const int tiles_total = ((MT + 7) / 8 + 3) / 4 * 4 * 8 * NT;
+    const int AT = MT >= NT ? MT : NT, BT = MT >= NT ? NT : MT;
+    const int tiles_total = ((AT + 7) / 8 + 3) / 4 * 4 * 8 * BT;
     static const int ncu = [] {
         int dev = 0, n = 256;
         hipGetDevice(&dev);
@@ -783,6 +792,8 @@ void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream
         if (epi == EPI_BIAS_RESID) return launch_p2<EPI_BIAS_RESID, float, true>(a, s);
         if (epi == EPI_NONE) return launch_p2<EPI_NONE, bf16_t, true>(a, s);
     }
+    if (bf && use256 && epi == EPI_SCORE && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0)
+        return launch256<EPI_SCORE, float, true>(a, s);   // scorer: query rows padded to 256 by the caller (m_valid < M)
     if (bf && use256 && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.m_valid == a.M) {
         if (epi == EPI_STORE && obf) return launch256<EPI_STORE, bf16_t, true>(a, s);
         if (epi == EPI_VT) return launch256<EPI_VT, bf16_t, false>(a, s);

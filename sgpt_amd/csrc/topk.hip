@@ -29,8 +29,7 @@ __device__ __forceinline__ uint32_t f2key(float f) {  // ascending uint order ==
 
 constexpr int TK_THREADS = 256;
 constexpr int TK_SORT_MAX = 2048;   // k <= 2048 sorted in LDS (the driver's k+1 = 1001 fits)
-constexpr int TK_SAMPLE = 1024;
-constexpr int TK_FAST_KMAX = 128;
+constexpr int TK_FAST_KMAX = 64;
 constexpr long TK_FAST_MIN_ROW = 4096;
 
 struct Row {
@@ -134,31 +133,75 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
         }
         done = true;
     } else if (k <= TK_FAST_KMAX && total >= TK_FAST_MIN_ROW) {
-        // ---------------- fast path: sample threshold + one pass ----------------
-        const long stride = total / TK_SAMPLE;
-        for (int s = t; s < TK_SAMPLE; s += TK_THREADS) s_val[s] = r.val((long)s * stride);
+        // ---------------- fast path: sampled threshold + one pass ----------------
+        // Threshold: every thread takes the max of 16 strided samples; each wave sorts its 64 thread-maxima
+        // with shuffles (no LDS, no barrier); the k-th largest of them is a lower bound of the row's k-th
+        // largest (they are 64 distinct row elements), and so is the max over the 4 waves.
+        const long stride = total / (TK_THREADS * 16);
+        float smax = -INFINITY;
+#pragma unroll 4
+        for (int u = 0; u < 16; ++u) smax = fmaxf(smax, r.val(((long)u * TK_THREADS + t) * stride));
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+            for (int sd = size >> 1; sd > 0; sd >>= 1) {
+                const float other = __shfl_xor(smax, sd, 64);
+                const bool keep_max = ((lane & sd) == 0) == ((lane & size) == 0);
+                smax = keep_max ? fmaxf(smax, other) : fminf(smax, other);
+            }
+        const float tau_w = __shfl(smax, k - 1, 64);   // lane i holds the i-th largest of the wave
+        if (lane == 0) hist[t >> 6] = __float_as_uint(tau_w);
         if (t == 0) sh_cnt = 0;
         __syncthreads();
-        bitonic_desc<false>(s_val, s_idx, TK_SAMPLE, t);
-        const float tau = s_val[k - 1];
-        __syncthreads();
+        const float tau = fmaxf(fmaxf(__uint_as_float(hist[0]), __uint_as_float(hist[1])),
+                                fmaxf(__uint_as_float(hist[2]), __uint_as_float(hist[3])));
         if (tau > -INFINITY) {
-            for (long i0 = 0; i0 < total; i0 += TK_THREADS) {
-                const long i = i0 + t;
-                if (i < total) {
-                    const float v = r.val(i);
-                    if (v >= tau) {
-                        const unsigned slot = atomicAdd(&sh_cnt, 1u);
-                        if (slot < TK_SORT_MAX) { s_val[slot] = v; s_idx[slot] = r.idx(i); }
-                    }
+            auto take = [&](float v, long i) {
+                if (nan_to_m1 && v != v) v = -1.0f;
+                if (v >= tau) {
+                    const unsigned slot = atomicAdd(&sh_cnt, 1u);
+                    if (slot < TK_SORT_MAX) { s_val[slot] = v; s_idx[slot] = r.idx(i); }
                 }
+            };
+            // fresh-score leg: 16-byte loads, two per thread in flight (row base and n are multiples of 4
+            // for the scorer's chunks; anything else takes the scalar tail below)
+            const bool vec_ok = ((reinterpret_cast<size_t>(r.sc) & 15) == 0);
+            const long nv = vec_ok ? (n / 4) : 0;
+            const float4* sc4 = reinterpret_cast<const float4*>(r.sc);
+            for (long i0 = 0; i0 < nv; i0 += 2 * TK_THREADS) {
+                const long ia = i0 + t, ib = ia + TK_THREADS;
+                float4 a = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), b = a;
+                if (ia < nv) a = sc4[ia];
+                if (ib < nv) b = sc4[ib];
+                if (ia < nv) { take(a.x, 4 * ia); take(a.y, 4 * ia + 1); take(a.z, 4 * ia + 2); take(a.w, 4 * ia + 3); }
+                if (ib < nv) { take(b.x, 4 * ib); take(b.y, 4 * ib + 1); take(b.z, 4 * ib + 2); take(b.w, 4 * ib + 3); }
             }
+            for (long i = 4 * nv + t; i < total; i += TK_THREADS) take(r.val(i), i);   // tail + previous-best leg
             __syncthreads();
-            const unsigned cnt = sh_cnt;
-            if (cnt <= TK_SORT_MAX) {   // cnt >= k always: the sample's k best are >= tau
-                n_sorted = (int)cnt;
-                done = true;
+            const unsigned cnt = sh_cnt;          // cnt >= k always: k sampled elements are >= tau
+            if (cnt <= 1024 && in_lds) {
+                // k best of the candidates by k rounds of wave-wide arg-max (wave 0; sorted, ties -> lower index)
+                if (t < 64) {
+                    for (int round = 0; round < kk; ++round) {
+                        float bv = -INFINITY; int64_t bi = 0x7fffffffffffffffLL; int bp = -1;
+                        for (unsigned c0 = lane; c0 < cnt; c0 += 64) {
+                            const float v = s_val[c0]; const int64_t id = s_idx[c0];
+                            if (sorts_before(v, id, bv, bi)) { bv = v; bi = id; bp = (int)c0; }
+                        }
+#pragma unroll
+                        for (int sd = 32; sd > 0; sd >>= 1) {
+                            const float ov_ = __shfl_xor(bv, sd, 64);
+                            const long long oi_ = __shfl_xor((long long)bi, sd, 64);
+                            const int op_ = __shfl_xor(bp, sd, 64);
+                            if (sorts_before(ov_, (int64_t)oi_, bv, bi)) { bv = ov_; bi = (int64_t)oi_; bp = op_; }
+                        }
+                        if (lane == 0) { ov[round] = bv; oi[round] = bi; s_val[bp] = -INFINITY; s_idx[bp] = 0x7fffffffffffffffLL; }
+                    }
+                    for (int i = kk + lane; i < k; i += 64) { ov[i] = -INFINITY; oi[i] = -1; }
+                }
+                return;                            // block-uniform exit: output written
             }
+            if (cnt <= TK_SORT_MAX) { n_sorted = (int)cnt; done = true; }
         }
         __syncthreads();
     }
