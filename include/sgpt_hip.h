@@ -45,14 +45,14 @@ typedef struct sgpt_ctx sgpt_ctx;
 typedef struct sgpt_model sgpt_model;
 
 enum { SGPT_F32 = 0, SGPT_BF16 = 1 };                      /* element types */
-enum { SGPT_ARCH_GPTNEO = 0, SGPT_ARCH_GPTJ = 1 };         /* BLOOM: later rounds */
+enum { SGPT_ARCH_GPTNEO = 0, SGPT_ARCH_GPTJ = 1, SGPT_ARCH_BLOOM = 2 };
 enum { SGPT_POOL_WEIGHTEDMEAN = 0, SGPT_POOL_MEAN = 1, SGPT_POOL_LASTTOKEN = 2 };
 enum { SGPT_COS = 0, SGPT_DOT = 1 };
 
 /* Model hyper-parameters = the fields of HF GPTNeoConfig the forward pass reads
  * (HF:gpt_neo/configuration_gpt_neo.py; values of the SGPT checkpoints in SURVEY.md 8). */
 typedef struct {
-    int32_t arch;            /* SGPT_ARCH_GPTNEO (SGPT-125M/1.3B/2.7B) | SGPT_ARCH_GPTJ (SGPT-5.8B) */
+    int32_t arch;            /* SGPT_ARCH_GPTNEO (SGPT-125M/1.3B/2.7B) | SGPT_ARCH_GPTJ (SGPT-5.8B) | SGPT_ARCH_BLOOM (sgpt-bloom-7b1) */
     int32_t n_layers;
     int32_t d_model;         /* multiple of 128 */
     int32_t n_heads;         /* d_model / n_heads in {64, 128} */
@@ -61,7 +61,7 @@ typedef struct {
     int32_t max_pos;
     int32_t window;          /* GPT-Neo local-attention window (256) */
     float ln_eps;            /* 1e-5 */
-    float attn_scale;        /* 1.0 for GPT-Neo (no 1/sqrt(dh), HF:gpt_neo:110); 1/sqrt(dh) for GPT-J (HF:gptj:148) */
+    float attn_scale;        /* 1.0 for GPT-Neo (no 1/sqrt(dh), HF:gpt_neo:110); 1/sqrt(dh) for GPT-J (HF:gptj:148) and BLOOM (HF:bloom:186) */
     int32_t compute_dtype;   /* SGPT_BF16: bf16 MFMA operands, fp32 accumulate/residual/LN/softmax;
                                 SGPT_F32 : exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the parity gate */
     const uint8_t* layer_is_local;  /* host, [n_layers]: 1 = sliding-window layer (HF:gpt_neo:66) */
@@ -72,7 +72,11 @@ typedef struct {
  * (GPT-Neo: "wte.weight", "wpe.weight", "h.0.attn.attention.q_proj.weight", ..., "ln_f.bias";
  *  GPT-J:   "wte.weight", "h.0.attn.q_proj.weight", "h.0.mlp.fc_in.weight", ..., plus the rotary tables
  *           "rotary.sin" / "rotary.cos" fp32[max_pos, rotary_dim/2] = HF create_sinusoidal_positions,
- *           HF:gptj/modeling_gptj.py:47-50, computed by the host so they match the reference bit for bit). */
+ *           HF:gptj/modeling_gptj.py:47-50, computed by the host so they match the reference bit for bit;
+ *  BLOOM:   "word_embeddings.weight", "word_embeddings_layernorm.*", "h.0.self_attention.query_key_value.{weight,bias}"
+ *           (fused, head-interleaved [n_head, 3, head_dim] rows, HF:bloom:214 -- de-interleaved by the library),
+ *           "h.0.self_attention.dense.*", "h.0.mlp.dense_h_to_4h.*", ..., plus "alibi.slopes" fp32[n_head]
+ *           (HF build_alibi_tensor, HF:bloom:62-79)). */
 typedef struct {
     const char* name;
     const float* ptr;        /* device, contiguous fp32 */

@@ -307,9 +307,126 @@ def gptj_forward(w, cfg: GPTJConfig, input_ids, attention_mask=None, output_hidd
     return x
 
 
+# ----------------------------------------------------------------------------
+# a2 (third family): BLOOM forward  (HF:bloom/modeling_bloom.py) -- sgpt-bloom-7b1-msmarco
+# ----------------------------------------------------------------------------
+class BloomConfig:
+    """Subset of HF BloomConfig the forward reads (HF:bloom/configuration_bloom.py)."""
+    model_type = "bloom"
+
+    def __init__(self, vocab_size=250880, hidden_size=4096, n_layer=30, n_head=32, layer_norm_epsilon=1e-5):
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.num_layers = n_layer
+        self.num_heads = n_head
+        self.intermediate_size = 4 * hidden_size
+        self.layer_norm_epsilon = layer_norm_epsilon
+        self.max_position_embeddings = 2048          # ALiBi: no learned positions; packing limit only
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_heads
+
+
+SGPT_BLOOM_7B1 = dict(vocab_size=250880, hidden_size=4096, n_layer=30, n_head=32)
+
+
+def synth_weights_bloom(cfg: BloomConfig, seed: int = 0, std: float = 0.02, bf16_linear: bool = False):
+    """Seeded random-init weights under HF BLOOM state-dict names (fused, head-interleaved QKV)."""
+    rng = np.random.default_rng(seed)
+    d, ffn = cfg.hidden_size, cfg.intermediate_size
+
+    def nrm(*shape, s=std):
+        return (rng.standard_normal(shape, dtype=np.float32) * F32(s)).astype(F32)
+
+    q = bf16_round if bf16_linear else (lambda x: x)
+    w = {"word_embeddings.weight": nrm(cfg.vocab_size, d, s=std * 2),
+         "word_embeddings_layernorm.weight": (1.0 + nrm(d, s=0.1)).astype(F32),
+         "word_embeddings_layernorm.bias": nrm(d, s=0.05)}
+    for i in range(cfg.num_layers):
+        p = f"h.{i}."
+        for ln in ("input_layernorm", "post_attention_layernorm"):
+            w[p + ln + ".weight"] = (1.0 + nrm(d, s=0.1)).astype(F32)
+            w[p + ln + ".bias"] = nrm(d, s=0.05)
+        w[p + "self_attention.query_key_value.weight"] = q(nrm(3 * d, d))
+        w[p + "self_attention.query_key_value.bias"] = nrm(3 * d, s=0.02)
+        w[p + "self_attention.dense.weight"] = q(nrm(d, d))
+        w[p + "self_attention.dense.bias"] = nrm(d, s=0.02)
+        w[p + "mlp.dense_h_to_4h.weight"] = q(nrm(ffn, d))
+        w[p + "mlp.dense_h_to_4h.bias"] = nrm(ffn, s=0.02)
+        w[p + "mlp.dense_4h_to_h.weight"] = q(nrm(d, ffn))
+        w[p + "mlp.dense_4h_to_h.bias"] = nrm(d, s=0.02)
+    w["ln_f.weight"] = (1.0 + nrm(d, s=0.1)).astype(F32)
+    w["ln_f.bias"] = nrm(d, s=0.05)
+    return w
+
+
+def alibi_slopes(n_head: int) -> np.ndarray:
+    """build_alibi_tensor slopes (HF:bloom:62-79), float32."""
+    import math
+    cp2 = 2 ** math.floor(math.log2(n_head))
+    base = F32(2 ** (-(2 ** -(math.log2(cp2) - 3))))
+    slopes = np.power(base, np.arange(1, 1 + cp2, dtype=np.int32).astype(F32)).astype(F32)
+    if cp2 != n_head:
+        extra_base = F32(2 ** (-(2 ** -(math.log2(2 * cp2) - 3))))
+        nrem = min(cp2, n_head - cp2)
+        extra = np.power(extra_base, np.arange(1, 1 + 2 * nrem, 2, dtype=np.int32).astype(F32)).astype(F32)
+        slopes = np.concatenate([slopes, extra])
+    return slopes.astype(F32)
+
+
+def bloom_gelu(x):
+    """bloom_gelu_forward (HF:bloom:112-120) == gelu_new's tanh form."""
+    x = x.astype(F32)
+    return x * F32(0.5) * (F32(1.0) + np.tanh(F32(0.79788456) * x * (F32(1.0) + F32(0.044715) * x * x)))
+
+
+def bloom_forward(w, cfg: BloomConfig, input_ids, attention_mask=None, output_hidden_states=False):
+    """BloomModel.forward (HF:bloom:441-556): embedding LayerNorm (:499), ALiBi bias
+    slope_h * ((cumsum(mask)-1)*mask) (:45-89) added to q.k^T/sqrt(dh) (baddbmm :270-275), fused QKV viewed
+    [.., n_head, 3, head_dim] (:214), softmax fp32 (:283), sequential block with
+    apply_residual_connection_post_layernorm=False (:356-392)."""
+    ids = np.asarray(input_ids)
+    B, S = ids.shape
+    d, H, dh = cfg.hidden_size, cfg.num_heads, cfg.head_dim
+    am = np.ones((B, S), dtype=np.int64) if attention_mask is None else np.asarray(attention_mask)
+    x = layer_norm(w["word_embeddings.weight"][ids].astype(F32), w["word_embeddings_layernorm.weight"],
+                   w["word_embeddings_layernorm.bias"], cfg.layer_norm_epsilon)
+    ar = ((np.cumsum(am, axis=-1) - 1) * am).astype(F32)                       # [B,S]
+    alibi = (alibi_slopes(H)[None, :, None] * ar[:, None, :])[:, :, None, :]   # [B,H,1,S]
+    ii, jj = np.arange(S)[:, None], np.arange(S)[None, :]
+    causal = np.where(jj <= ii, F32(0), F32(FINFO_MIN)).astype(F32)[None, None]
+    pad_add = np.where(am[:, None, None, :] != 0, F32(0), F32(FINFO_MIN)).astype(F32)
+    with np.errstate(over="ignore"):
+        mask = np.maximum(causal + pad_add, F32(FINFO_MIN))
+    hs = []
+    for i in range(cfg.num_layers):
+        if output_hidden_states:
+            hs.append(x)
+        p = f"h.{i}."
+        ln = layer_norm(x, w[p + "input_layernorm.weight"], w[p + "input_layernorm.bias"], cfg.layer_norm_epsilon)
+        fused = (ln @ w[p + "self_attention.query_key_value.weight"].T + w[p + "self_attention.query_key_value.bias"])
+        fused = fused.reshape(B, S, H, 3, dh)
+        q, k, v = (fused[..., j, :].transpose(0, 2, 1, 3) for j in range(3))
+        sc = (alibi + np.matmul(q, k.transpose(0, 1, 3, 2)) * F32(1.0 / np.sqrt(dh))).astype(F32) + mask
+        ctx = np.matmul(_softmax_lastdim(sc), v).transpose(0, 2, 1, 3).reshape(B, S, d)
+        x = (ctx @ w[p + "self_attention.dense.weight"].T + w[p + "self_attention.dense.bias"] + x).astype(F32)
+        ln2 = layer_norm(x, w[p + "post_attention_layernorm.weight"], w[p + "post_attention_layernorm.bias"],
+                         cfg.layer_norm_epsilon)
+        h = bloom_gelu(ln2 @ w[p + "mlp.dense_h_to_4h.weight"].T + w[p + "mlp.dense_h_to_4h.bias"])
+        x = (h @ w[p + "mlp.dense_4h_to_h.weight"].T + w[p + "mlp.dense_4h_to_h.bias"] + x).astype(F32)
+    x = layer_norm(x, w["ln_f.weight"], w["ln_f.bias"], cfg.layer_norm_epsilon)
+    if output_hidden_states:
+        hs.append(x)
+        return x, tuple(hs)
+    return x
+
+
 def forward_any(w, cfg, ids, mask, output_hidden_states=False):
     if getattr(cfg, "model_type", "gpt_neo") == "gptj":
         return gptj_forward(w, cfg, ids, mask, output_hidden_states=output_hidden_states)
+    if getattr(cfg, "model_type", "gpt_neo") == "bloom":
+        return bloom_forward(w, cfg, ids, mask, output_hidden_states=output_hidden_states)
     return gptneo_forward(w, cfg, ids, mask, output_hidden_states=output_hidden_states)
 
 

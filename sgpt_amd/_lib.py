@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsgpt_hip.so")
 
 SGPT_F32, SGPT_BF16 = 0, 1
-SGPT_ARCH_GPTNEO, SGPT_ARCH_GPTJ = 0, 1
+SGPT_ARCH_GPTNEO, SGPT_ARCH_GPTJ, SGPT_ARCH_BLOOM = 0, 1, 2
 POOL_MODES = {"weightedmean": 0, "mean": 1, "lasttoken": 2}
 
 

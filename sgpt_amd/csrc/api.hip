@@ -33,6 +33,7 @@ struct LayerW {
     void* w_fc = nullptr;    // [ffn, d]
     void* w_proj = nullptr;  // [d, ffn]
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *b_o, *b_fc, *b_proj;
+    float* b_qkv = nullptr;  // BLOOM: [3d] de-interleaved (q | k | v) projection bias
     int is_local = 0;
 };
 
@@ -42,6 +43,7 @@ struct sgpt_model {
     std::vector<LayerW> L;
     float *wte = nullptr, *wpe = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
     float *rot_sin = nullptr, *rot_cos = nullptr;   // GPT-J rotary tables [max_pos, rotary_dim/2]
+    float *emb_ln_g = nullptr, *emb_ln_b = nullptr, *alibi = nullptr;   // BLOOM: embedding LayerNorm, ALiBi slopes [H]
     float* zero_bias = nullptr;                      // [max(d, ffn)] zeros: bias-free projections (GPT-J out_proj)
     std::vector<void*> allocs;
 };
@@ -157,9 +159,9 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     if (!c || !d || !tv || !out) return SGPT_ERR_INVALID;
     *out = nullptr;
     HIPC(c, hipSetDevice(c->device));
-    if (d->arch != SGPT_ARCH_GPTNEO && d->arch != SGPT_ARCH_GPTJ)
-        return fail(c, SGPT_ERR_INVALID, "arch must be SGPT_ARCH_GPTNEO or SGPT_ARCH_GPTJ (BLOOM is not built yet)");
-    const bool gptj = d->arch == SGPT_ARCH_GPTJ;
+    if (d->arch != SGPT_ARCH_GPTNEO && d->arch != SGPT_ARCH_GPTJ && d->arch != SGPT_ARCH_BLOOM)
+        return fail(c, SGPT_ERR_INVALID, "arch must be SGPT_ARCH_GPTNEO, SGPT_ARCH_GPTJ or SGPT_ARCH_BLOOM");
+    const bool gptj = d->arch == SGPT_ARCH_GPTJ, bloom = d->arch == SGPT_ARCH_BLOOM;
     const int dm = d->d_model, ffn = d->d_ffn, H = d->n_heads;
     if (dm % 128 || ffn % 128 || H <= 0 || dm % H) return fail(c, SGPT_ERR_INVALID, "d_model and d_ffn must be multiples of 128");
     const int dh = dm / H;
@@ -210,11 +212,16 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
             st = fail(c, SGPT_ERR_HIP, "memcpy " + name);
     };
 
-    m->wte = copy_f32("wte.weight", (int64_t)d->vocab * dm);
-    if (!gptj) m->wpe = copy_f32("wpe.weight", (int64_t)d->max_pos * dm);
-    else {
+    m->wte = copy_f32(bloom ? "word_embeddings.weight" : "wte.weight", (int64_t)d->vocab * dm);
+    if (gptj) {
         m->rot_sin = copy_f32("rotary.sin", (int64_t)d->max_pos * (d->rotary_dim / 2));
         m->rot_cos = copy_f32("rotary.cos", (int64_t)d->max_pos * (d->rotary_dim / 2));
+    } else if (bloom) {
+        m->emb_ln_g = copy_f32("word_embeddings_layernorm.weight", dm);
+        m->emb_ln_b = copy_f32("word_embeddings_layernorm.bias", dm);
+        m->alibi = copy_f32("alibi.slopes", H);
+    } else {
+        m->wpe = copy_f32("wpe.weight", (int64_t)d->max_pos * dm);
     }
     m->lnf_g = copy_f32("ln_f.weight", dm);
     m->lnf_b = copy_f32("ln_f.bias", dm);
@@ -222,22 +229,26 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     if (m->zero_bias && hipMemsetAsync(m->zero_bias, 0, (size_t)(ffn > dm ? ffn : dm) * 4, 0) != hipSuccess)
         st = fail(c, SGPT_ERR_HIP, "memset zero_bias");
     m->L.resize(d->n_layers);
-    // HF state-dict names: GPT-Neo h.N.attn.attention.{q,k,v,out}_proj / mlp.c_fc / mlp.c_proj (HF:gpt_neo:84-87,302-303);
-    //                      GPT-J   h.N.attn.{q,k,v,out}_proj (no biases) / mlp.fc_in / mlp.fc_out (HF:gptj:98-101,368-369)
+    // HF state-dict names
+    //   GPT-Neo h.N.attn.attention.{q,k,v,out}_proj / mlp.c_fc / mlp.c_proj          (HF:gpt_neo:84-87,302-303)
+    //   GPT-J   h.N.attn.{q,k,v,out}_proj (no biases) / mlp.fc_in / mlp.fc_out          (HF:gptj:98-101,368-369)
+    //   BLOOM   h.N.self_attention.{query_key_value,dense} / mlp.dense_h_to_4h / mlp.dense_4h_to_h,
+    //           input_layernorm / post_attention_layernorm                               (HF:bloom:197-198,320-322,351-354)
     const std::string attn = gptj ? "attn." : "attn.attention.";
-    const std::string fc1 = gptj ? "mlp.fc_in" : "mlp.c_fc", fc2 = gptj ? "mlp.fc_out" : "mlp.c_proj";
+    const std::string fc1 = bloom ? "mlp.dense_h_to_4h" : (gptj ? "mlp.fc_in" : "mlp.c_fc");
+    const std::string fc2 = bloom ? "mlp.dense_4h_to_h" : (gptj ? "mlp.fc_out" : "mlp.c_proj");
+    const std::string ln1 = bloom ? "input_layernorm" : "ln_1", ln2 = bloom ? "post_attention_layernorm" : "ln_2";
+    float* stage = nullptr;   // BLOOM: fp32 staging for the de-interleaved fused QKV weight
+    if (bloom) stage = (float*)dalloc((size_t)3 * dm * dm * 4);
     for (int i = 0; i < d->n_layers && st == SGPT_OK; ++i) {
         const std::string p = "h." + std::to_string(i) + ".";
         LayerW& l = m->L[i];
-        l.is_local = gptj ? 0 : (d->layer_is_local ? d->layer_is_local[i] : (i & 1));
-        l.ln1_g = copy_f32(p + "ln_1.weight", dm); l.ln1_b = copy_f32(p + "ln_1.bias", dm);
-        if (!gptj) {
-            l.ln2_g = copy_f32(p + "ln_2.weight", dm); l.ln2_b = copy_f32(p + "ln_2.bias", dm);
-            l.b_o = copy_f32(p + attn + "out_proj.bias", dm);
-        } else {
-            l.ln2_g = l.ln2_b = nullptr;
-            l.b_o = m->zero_bias;
-        }
+        l.is_local = (gptj || bloom) ? 0 : (d->layer_is_local ? d->layer_is_local[i] : (i & 1));
+        l.ln1_g = copy_f32(p + ln1 + ".weight", dm); l.ln1_b = copy_f32(p + ln1 + ".bias", dm);
+        if (!gptj) { l.ln2_g = copy_f32(p + ln2 + ".weight", dm); l.ln2_b = copy_f32(p + ln2 + ".bias", dm); }
+        else l.ln2_g = l.ln2_b = nullptr;
+        if (gptj) l.b_o = m->zero_bias;
+        else l.b_o = copy_f32(p + (bloom ? std::string("self_attention.dense.bias") : attn + "out_proj.bias"), dm);
         l.b_fc = copy_f32(p + fc1 + ".bias", ffn);
         l.b_proj = copy_f32(p + fc2 + ".bias", dm);
         l.w_qkv = dalloc((size_t)3 * dm * dm * esz);
@@ -245,10 +256,23 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         l.w_fc = dalloc((size_t)ffn * dm * esz);
         l.w_proj = dalloc((size_t)dm * ffn * esz);
         if (st != SGPT_OK) break;
-        pack_w(p + attn + "q_proj.weight", (int64_t)dm * dm, l.w_qkv, 0);
-        pack_w(p + attn + "k_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)dm * dm);
-        pack_w(p + attn + "v_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)2 * dm * dm);
-        pack_w(p + attn + "out_proj.weight", (int64_t)dm * dm, l.w_o, 0);
+        if (bloom) {
+            const float* wq = find(p + "self_attention.query_key_value.weight", (int64_t)3 * dm * dm);
+            const float* bq = find(p + "self_attention.query_key_value.bias", (int64_t)3 * dm);
+            l.b_qkv = (float*)dalloc((size_t)3 * dm * 4);
+            if (!wq || !bq || !l.b_qkv || !stage) break;
+            launch_qkv_deinterleave(wq, stage, H, dh, dm, 0);          // rows [h,3,dh] -> [q | k | v]
+            launch_qkv_deinterleave(bq, l.b_qkv, H, dh, 1, 0);
+            if (bf) launch_f32_to_bf16(stage, (int64_t)3 * dm * dm, l.w_qkv, 0);
+            else if (hipMemcpyAsync(l.w_qkv, stage, (size_t)3 * dm * dm * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess)
+                st = fail(c, SGPT_ERR_HIP, "memcpy qkv");
+            pack_w(p + "self_attention.dense.weight", (int64_t)dm * dm, l.w_o, 0);
+        } else {
+            pack_w(p + attn + "q_proj.weight", (int64_t)dm * dm, l.w_qkv, 0);
+            pack_w(p + attn + "k_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)dm * dm);
+            pack_w(p + attn + "v_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)2 * dm * dm);
+            pack_w(p + attn + "out_proj.weight", (int64_t)dm * dm, l.w_o, 0);
+        }
         pack_w(p + fc1 + ".weight", (int64_t)ffn * dm, l.w_fc, 0);
         pack_w(p + fc2 + ".weight", (int64_t)dm * ffn, l.w_proj, 0);
     }
@@ -318,6 +342,7 @@ sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, c
     }
     if (gptj) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz, s));
     launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, s);
+    if (m->emb_ln_g) launch_layernorm(x, m->emb_ln_g, m->emb_ln_b, x, SGPT_F32, T, dm, m->d.ln_eps, s);   // BLOOM :499
     for (int li = 0; li < n_layers_run; ++li) {
         const LayerW& l = m->L[li];
         launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
@@ -325,18 +350,19 @@ sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, c
         g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
         AttnArgs at{};
         at.seq_off = seq_off; at.B = B; at.H = H; at.dh = dh; at.window = l.is_local ? m->d.window : 0;
-        at.scale = m->d.attn_scale; at.max_alloc_len = max_alloc; at.ctx = ctx; at.ldo = dm;
+        at.scale = m->d.attn_scale; at.max_alloc_len = max_alloc; at.ctx = ctx; at.ldo = dm; at.alibi = m->alibi;
         if (bf) {
             // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]
-            g.W = l.w_qkv; g.N = 2 * dm; g.out = qkv; g.ldo = 2 * dm;
+            g.W = l.w_qkv; g.N = 2 * dm; g.out = qkv; g.ldo = 2 * dm; g.bias = l.b_qkv;            // bias: BLOOM only
             gemm(c, dt, EPI_STORE, SGPT_BF16, g, s);
             g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; g.N = dm; g.out = vt; g.ldo = T;
+            g.bias = l.b_qkv ? l.b_qkv + 2 * dm : nullptr;
             gemm(c, dt, EPI_VT, SGPT_BF16, g, s);
             if (gptj) launch_rope(qkv, SGPT_BF16, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
             at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
             launch_attn_bf16(at, s);
         } else {
-            g.W = l.w_qkv; g.N = 3 * dm; g.out = qkv; g.ldo = 3 * dm;
+            g.W = l.w_qkv; g.N = 3 * dm; g.out = qkv; g.ldo = 3 * dm; g.bias = l.b_qkv;
             gemm(c, dt, EPI_STORE, SGPT_F32, g, s);
             if (gptj) launch_rope(qkv, SGPT_F32, 3 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
             at.q = qkv; at.k = (float*)qkv + dm; at.v = (float*)qkv + 2 * dm; at.ldq = 3 * dm;

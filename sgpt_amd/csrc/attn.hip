@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs p) {
     for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -1e30f, l_run = 0.f;
     const int qi = q0 + fr;  // this lane's query (sequence-relative)
+    const float slope = p.alibi ? p.alibi[head] : 0.f;
 
     int j_lo = 0;
     if (p.window > 0) { j_lo = q0 - p.window + 1; j_lo = j_lo < 0 ? 0 : (j_lo & ~31); }
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int kj = j0 + nt * 16 + 4 * g + r;
                 const bool vis = (kj <= qi) && (p.window <= 0 || kj > qi - p.window);
-                const float v = vis ? s[nt][r] * p.scale : -INFINITY;
+                const float v = vis ? s[nt][r] * p.scale + slope * (float)kj : -INFINITY;
                 s[nt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
     for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -1e30f, l_run = 0.f;
     const int qi = q0 + fr;
+    const float slope = p.alibi ? p.alibi[head] : 0.f;
 
     int j_lo = 0;
     if (p.window > 0) { j_lo = qb0 - p.window + 1; j_lo = j_lo < 0 ? 0 : (j_lo & ~63); }
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int kj = j0 + nt * 16 + 4 * g + r;
                 const bool vis = (kj <= qi) && (p.window <= 0 || kj > qi - p.window);
-                const float v = vis ? s[nt][r] * p.scale : -INFINITY;
+                const float v = vis ? s[nt][r] * p.scale + slope * (float)kj : -INFINITY;
                 s[nt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
     int lo = 0;
     if (p.window > 0) { lo = qi - p.window + 1; lo = lo < 0 ? 0 : lo; }
     const int nkeys = qi - lo + 1;
+    const float slope = p.alibi ? p.alibi[head] : 0.f;
     float mx = -INFINITY;
     for (int jj = lane; jj < nkeys; jj += 64) {
         const float* kr = kb + (long)(s0 + lo + jj) * p.ldq;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
             a = fmaf(qs[wave][c], kv.x, a); a = fmaf(qs[wave][c + 1], kv.y, a);
             a = fmaf(qs[wave][c + 2], kv.z, a); a = fmaf(qs[wave][c + 3], kv.w, a);
         }
-        a *= p.scale;
+        a = a * p.scale + slope * (float)(lo + jj);
         sc[wave][jj] = a;
         mx = fmaxf(mx, a);
     }

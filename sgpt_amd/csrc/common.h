@@ -112,6 +112,7 @@ struct AttnArgs {
     int window;          // 0 = global causal
     float scale;
     int max_alloc_len;
+    const float* alibi;  // [H] ALiBi slopes (BLOOM) or null: score += slope_h * key_index (HF:bloom:45-89)
 };
 void launch_attn_bf16(const AttnArgs& a, hipStream_t s);
 void launch_attn_f32(const AttnArgs& a, hipStream_t s);
@@ -131,6 +132,8 @@ void launch_fill_f32(float* p, long n, float v, hipStream_t s);
 // GPT-J rotary embedding, in place on the q / k columns of the projection buffer
 void launch_rope(void* qk, int dtype, long ld, long k_off, const int* pos, const float* sin_t, const float* cos_t, int T,
                  int H, int dh, int rotary_dim, hipStream_t s);
+// BLOOM fused QKV rows [n_head, 3, head_dim] -> [q rows | k rows | v rows] (row_len floats per row; 1 for the bias)
+void launch_qkv_deinterleave(const float* src, float* dst, int H, int dh, long row_len, hipStream_t s);
 void launch_fill_rand(void* p, long n, int dtype, unsigned seed, float scale, hipStream_t s);
 
 // top-k: one block per query row over a virtual row = [scores(n) | prev(n_prev)]

@@ -240,6 +240,17 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ buf, long ld,
     }
 }
 
+// BLOOM stores the QKV projection fused and head-interleaved: row h*3*dh + which*dh + c (HF:bloom:214).
+// Re-order to row which*d + h*dh + c so the Q/K and V projections are the same contiguous blocks as for GPT-Neo.
+__global__ __launch_bounds__(256) void qkv_deinterleave_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                               int H, int dh, long row_len) {
+    const int drow = blockIdx.x;                       // destination row in [0, 3*H*dh)
+    const int d = H * dh;
+    const int which = drow / d, rem = drow - which * d, h = rem / dh, c = rem - h * dh;
+    const long srow = (long)h * 3 * dh + (long)which * dh + c;
+    for (long i = threadIdx.x; i < row_len; i += 256) dst[(long)drow * row_len + i] = src[srow * row_len + i];
+}
+
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, long numel,
                                                        bf16_t* __restrict__ out) {
     const long stride = (long)gridDim.x * 256;
@@ -341,4 +352,8 @@ void launch_rope(void* qk, int dtype, long ld, long k_off, const int* pos, const
         hipLaunchKernelGGL(rope_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)qk, ld, k_off, pos, sin_t, cos_t, T, H, dh, half);
     else
         hipLaunchKernelGGL(rope_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)qk, ld, k_off, pos, sin_t, cos_t, T, H, dh, half);
+}
+
+void launch_qkv_deinterleave(const float* src, float* dst, int H, int dh, long row_len, hipStream_t s) {
+    hipLaunchKernelGGL(qkv_deinterleave_kernel, dim3(3 * H * dh), dim3(256), 0, s, src, dst, H, dh, row_len);
 }

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 if (n >= N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const bool full = n + 3 < N;
-                if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
+                if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || (EPI == EPI_STORE && p.bias != nullptr)) {
                     // N is a multiple of 4 for every biased projection
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + wm * 64 + i * 16 + 4 * g;
                 if (m >= M) continue;  // M (token axis) is padded to a multiple of 128 by the caller
-                store4<OutT>(out + (long)n * p.ldo + m, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                const float bn = p.bias ? p.bias[n] : 0.f;   // BLOOM: V projection has a bias
+                store4<OutT>(out + (long)n * p.ldo + m, acc[i][j][0] + bn, acc[i][j][1] + bn, acc[i][j][2] + bn, acc[i][j][3] + bn);
             }
         }
     }
@@ -427,9 +428,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             constexpr int RS = 144;
             const int rrow = lane >> 3, rchunk = lane & 7;
             float4 bb[4];
-            if constexpr (EPI == EPI_BIAS_GELU) {
+            const bool has_bias = EPI == EPI_BIAS_GELU || p.bias != nullptr;   // plain store + bias: BLOOM Q/K projection
+            if (has_bias) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 16 + 4 * g);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -439,6 +444,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                     if constexpr (EPI == EPI_BIAS_GELU) {
                         v[0] = gelu_new_fast(v[0] + bb[j].x); v[1] = gelu_new_fast(v[1] + bb[j].y);
                         v[2] = gelu_new_fast(v[2] + bb[j].z); v[3] = gelu_new_fast(v[3] + bb[j].w);
+                    } else {
+                        v[0] += bb[j].x; v[1] += bb[j].y; v[2] += bb[j].z; v[3] += bb[j].w;
                     }
                     *reinterpret_cast<uint2_a*>(scr + fr * RS + (j * 16 + 4 * g) * 2) =
                         make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
@@ -495,10 +502,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             const int rrow = lane >> 4, rchunk = lane & 15;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                const float bn = p.bias ? p.bias[n0 + wn * 64 + j * 16 + fr] : 0.f;   // BLOOM: V projection bias
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     *reinterpret_cast<uint2_a*>(scr + fr * RS + (i * 16 + 4 * g) * 2) =
-                        make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
+                        make_uint2(pack_bf16x2(acc[i][j][0] + bn, acc[i][j][1] + bn), pack_bf16x2(acc[i][j][2] + bn, acc[i][j][3] + bn));
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
@@ -785,7 +793,8 @@ void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream
     const bool bf = dtype == 1, obf = out_dtype == 1;
     static const bool use256 = getenv("SGPT_GEMM128") == nullptr;
     static const bool use_p2 = getenv("SGPT_GEMM_P2") != nullptr;
-    if (bf && use_p2 && a.M % 256 == 0 && a.N % 128 == 0 && a.K % 32 == 0 && a.K >= 64 && a.m_valid == a.M) {
+    if (bf && use_p2 && a.M % 256 == 0 && a.N % 128 == 0 && a.K % 32 == 0 && a.K >= 64 && a.m_valid == a.M &&
+        !((epi == EPI_STORE || epi == EPI_VT) && a.bias != nullptr)) {
         if (epi == EPI_STORE && obf) return launch_p2<EPI_STORE, bf16_t, true>(a, s);
         if (epi == EPI_VT) return launch_p2<EPI_VT, bf16_t, false>(a, s);
         if (epi == EPI_BIAS_GELU) return launch_p2<EPI_BIAS_GELU, bf16_t, true>(a, s);

@@ -51,8 +51,13 @@ class SGPTConfig:
                        layer_norm_epsilon=c.get("layer_norm_epsilon", 1e-5), model_type="gptj",
                        rotary_dim=c.get("rotary_dim") or c["n_embd"] // c["n_head"], window_size=0,
                        attention_layers=["global"] * c["n_layer"])
+        if mt == "bloom":  # HF BloomConfig (HF:bloom/configuration_bloom.py): ALiBi, no position table
+            return cls(vocab_size=c["vocab_size"], max_position_embeddings=2048, hidden_size=c["hidden_size"],
+                       num_layers=c["n_layer"], num_heads=c["n_head"], intermediate_size=4 * c["hidden_size"],
+                       layer_norm_epsilon=c.get("layer_norm_epsilon", 1e-5), model_type="bloom", window_size=0,
+                       attention_layers=["global"] * c["n_layer"])
         if mt != "gpt_neo":
-            raise NotImplementedError(f"model_type {mt!r}: GPT-Neo and GPT-J are built; BLOOM is not yet")
+            raise NotImplementedError(f"model_type {mt!r}: GPT-Neo, GPT-J and BLOOM are the SGPT families")
         layers = c.get("attention_layers")
         if layers is None and c.get("attention_types"):
             layers = []
@@ -118,18 +123,22 @@ class SGPTModel:
         self.max_tokens_per_call = max_tokens_per_call
         lib = self.ctx.lib
         local = (C.c_uint8 * cfg.num_layers)(*[1 if a == "local" else 0 for a in cfg.attention_layers])
-        gptj = cfg.model_type == "gptj"
+        gptj, bloom = cfg.model_type == "gptj", cfg.model_type == "bloom"
         dh = cfg.hidden_size // cfg.num_heads
-        desc = ModelDesc(arch=_lib.SGPT_ARCH_GPTJ if gptj else _lib.SGPT_ARCH_GPTNEO, n_layers=cfg.num_layers,
+        arch = _lib.SGPT_ARCH_GPTJ if gptj else (_lib.SGPT_ARCH_BLOOM if bloom else _lib.SGPT_ARCH_GPTNEO)
+        desc = ModelDesc(arch=arch, n_layers=cfg.num_layers,
                          d_model=cfg.hidden_size, n_heads=cfg.num_heads, d_ffn=cfg.intermediate_size,
                          vocab=cfg.vocab_size, max_pos=cfg.max_position_embeddings, window=cfg.window_size,
                          ln_eps=cfg.layer_norm_epsilon,
-                         attn_scale=float(1.0 / np.sqrt(np.float32(dh))) if gptj else 1.0,   # HF:gptj:96,148 / HF:gpt_neo:110
+                         attn_scale=float(1.0 / np.sqrt(np.float32(dh))) if (gptj or bloom) else 1.0,   # HF:gptj:148, HF:bloom:186 / HF:gpt_neo:110
                          compute_dtype=SGPT_BF16 if dtype == "bf16" else SGPT_F32,
                          layer_is_local=C.cast(local, C.POINTER(C.c_uint8)), rotary_dim=cfg.rotary_dim if gptj else 0)
         if gptj:
             weights = dict(weights)
             weights["rotary.sin"], weights["rotary.cos"] = rotary_tables(cfg.max_position_embeddings, cfg.rotary_dim)
+        if bloom:
+            weights = dict(weights)
+            weights["alibi.slopes"] = alibi_slopes(cfg.num_heads)
         names, keep = [], []
         for k, v in weights.items():
             k2 = k[len("transformer."):] if k.startswith("transformer.") else k
@@ -243,6 +252,20 @@ class SGPTModel:
         _, hid = self.encode_packed(pb, layer_idx=layer_idx, return_hidden=True)
         off = pb.seq_off.cpu().tolist()
         return [hid[off[i]: off[i] + len(s)] for i, s in enumerate(seqs)]
+
+
+def alibi_slopes(n_head: int) -> np.ndarray:
+    """HF build_alibi_tensor slopes (HF:bloom/modeling_bloom.py:62-79) in float32."""
+    import math
+    f32 = np.float32
+    cp2 = 2 ** math.floor(math.log2(n_head))
+    base = f32(2 ** (-(2 ** -(math.log2(cp2) - 3))))
+    slopes = np.power(base, np.arange(1, 1 + cp2, dtype=np.int32).astype(f32)).astype(f32)
+    if cp2 != n_head:
+        extra_base = f32(2 ** (-(2 ** -(math.log2(2 * cp2) - 3))))
+        nrem = min(cp2, n_head - cp2)
+        slopes = np.concatenate([slopes, np.power(extra_base, np.arange(1, 1 + 2 * nrem, 2, dtype=np.int32).astype(f32)).astype(f32)])
+    return slopes.astype(f32)
 
 
 def rotary_tables(max_pos: int, dim: int):

@@ -104,6 +104,19 @@ def hf_model_gptj(cfg, w):
     return m
 
 
+def hf_model_bloom(cfg, w):
+    from transformers import BloomConfig, BloomModel
+    hc = BloomConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, n_layer=cfg.num_layers, n_head=cfg.num_heads,
+                     layer_norm_epsilon=cfg.layer_norm_epsilon, hidden_dropout=0.0, attention_dropout=0.0,
+                     apply_residual_connection_post_layernorm=False, pretraining_tp=1, slow_but_exact=False)
+    hc._attn_implementation = "eager"
+    m = BloomModel(hc).eval()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in w.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    return m
+
+
 def rand_seqs(rng, n, lo, hi, vocab):
     return [rng.integers(0, vocab, size=int(rng.integers(lo, hi + 1))).tolist() for _ in range(n)]
 
@@ -116,7 +129,11 @@ def check(name, got, want, tol):
 
 
 def encoder_case(tag, cfg_kw, seed, seqs, pad_side="right", std=0.02, store_hidden=False, Pooling=None, arch="gpt_neo"):
-    if arch == "gptj":
+    if arch == "bloom":
+        cfg = O.BloomConfig(**cfg_kw)
+        w = O.synth_weights_bloom(cfg, seed=seed, std=std)
+        model = hf_model_bloom(cfg, w)
+    elif arch == "gptj":
         cfg = O.GPTJConfig(**cfg_kw)
         w = O.synth_weights_gptj(cfg, seed=seed, std=std)
         model = hf_model_gptj(cfg, w)
@@ -222,6 +239,15 @@ def _gptj_cases(Pooling):
                  store_hidden=True, Pooling=Pooling, arch="gptj")
     encoder_case("tiny_gptj_left", tinyj, seed=31, seqs=rand_seqs(rng, 5, 2, 40, 211), pad_side="left", std=0.04,
                  store_hidden=True, Pooling=Pooling, arch="gptj")
+    # BLOOM family (sgpt-bloom-7b1, BASELINE config 5): ALiBi, embedding LayerNorm, fused interleaved QKV + biases.
+    # 6 heads exercises the non-power-of-two slope branch; BLOOM tokenizers pad LEFT (pooling weights depend on it).
+    tinyb = dict(vocab_size=211, hidden_size=384, n_layer=2, n_head=6)
+    rng = np.random.default_rng(400)
+    encoder_case("tiny_bloom_left", tinyb, seed=41, seqs=rand_seqs(rng, 7, 1, 70, 211), pad_side="left", std=0.04,
+                 store_hidden=True, Pooling=Pooling, arch="bloom")
+    tinyb2 = dict(vocab_size=211, hidden_size=256, n_layer=2, n_head=2)    # head_dim 128 (the 7b1 head size)
+    encoder_case("tiny_bloom_right", tinyb2, seed=42, seqs=rand_seqs(rng, 5, 2, 40, 211), std=0.04,
+                 store_hidden=True, Pooling=Pooling, arch="bloom")
 
 
 def _scoring_cases(U, ES):

@@ -28,6 +28,9 @@ def oracle_cfg_weights(cfg_kw, seed, std, bf16_linear=False):
     if "n_embd" in cfg_kw:      # GPT-J field names
         cfg = O.GPTJConfig(**cfg_kw)
         return cfg, O.synth_weights_gptj(cfg, seed=seed, std=std, bf16_linear=bf16_linear)
+    if "n_layer" in cfg_kw:     # BLOOM field names
+        cfg = O.BloomConfig(**cfg_kw)
+        return cfg, O.synth_weights_bloom(cfg, seed=seed, std=std, bf16_linear=bf16_linear)
     cfg = O.NeoConfig(**cfg_kw)
     return cfg, O.synth_weights(cfg, seed=seed, std=std, bf16_linear=bf16_linear)
 
@@ -40,6 +43,8 @@ def build_model(cfg_kw, seed, std, dtype):
         _, w = oracle_cfg_weights(cfg_kw, seed, std)
         if "n_embd" in cfg_kw:
             scfg = SGPTConfig.from_hf_dict(dict(cfg_kw, model_type="gptj"))
+        elif "n_layer" in cfg_kw:
+            scfg = SGPTConfig.from_hf_dict(dict(cfg_kw, model_type="bloom"))
         else:
             scfg = SGPTConfig(**cfg_kw)
         _models[key] = SGPTModel(scfg, w, device="cuda:0", dtype=dtype)

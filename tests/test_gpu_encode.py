@@ -19,7 +19,8 @@ TOL_BF16_ABS = 6e-2      # bf16 operands, 12 layers, O(1) activations; reported,
 TOL_BF16_COS = 0.999
 
 
-@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128", "tiny_gptj_right", "tiny_gptj_left"])
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128", "tiny_gptj_right", "tiny_gptj_left",
+                                 "tiny_bloom_left", "tiny_bloom_right"])
 def test_encode_fp32_tiny_golden(tag):
     fx, cfg_kw, seqs, pad_left, ids, mask = load_case(tag)
     m = build_model(cfg_kw, int(fx["seed"]), float(fx["std"]), "fp32")
@@ -70,7 +71,7 @@ def test_encode_fp32_cfg3_specb_window():
 
 
 @pytest.mark.parametrize("tag", ["tiny_right", "tiny_dh128", "cfg1_125m_32x64", "cfg3_125m_specb_s300", "tiny_gptj_right",
-                                 "tiny_gptj_left"])
+                                 "tiny_gptj_left", "tiny_bloom_left", "tiny_bloom_right"])
 def test_encode_bf16_vs_golden(tag):
     """bf16 MFMA operands (weights + GEMM/attention inputs), fp32 accumulate / residual / LN / softmax."""
     fx, cfg_kw, seqs, pad_left, ids, mask = load_case(tag)

@@ -15,7 +15,7 @@ from oracle import sgpt_oracle as O
 def load_case(golden_dir, tag):
     fx = np.load(os.path.join(golden_dir, f"{tag}.npz"))
     kw = ast.literal_eval(str(fx["cfg"]))
-    cfg = O.GPTJConfig(**kw) if "n_embd" in kw else O.NeoConfig(**kw)
+    cfg = O.GPTJConfig(**kw) if "n_embd" in kw else (O.BloomConfig(**kw) if "n_layer" in kw else O.NeoConfig(**kw))
     lens = fx["seq_lens"].tolist()
     ids, mask = fx["ids"].astype(np.int64), fx["mask"].astype(np.int64)
     side = str(fx["pad_side"])
@@ -23,10 +23,13 @@ def load_case(golden_dir, tag):
     return fx, cfg, seqs, ids, mask, side
 
 
-@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128", "tiny_gptj_right", "tiny_gptj_left"])
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128", "tiny_gptj_right", "tiny_gptj_left",
+                                 "tiny_bloom_left", "tiny_bloom_right"])
 def test_oracle_encoder_matches_hf_golden(golden_dir, tag):
     fx, cfg, seqs, ids, mask, side = load_case(golden_dir, tag)
-    if isinstance(cfg, O.GPTJConfig):
+    if isinstance(cfg, O.BloomConfig):
+        w = O.synth_weights_bloom(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    elif isinstance(cfg, O.GPTJConfig):
         w = O.synth_weights_gptj(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
     else:
         w = O.synth_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
