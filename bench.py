@@ -33,6 +33,7 @@ MODELS = {
     "1.3b": dict(vocab_size=50257, max_position_embeddings=2048, hidden_size=2048, num_layers=24, num_heads=16, window_size=256),
     "2.7b": dict(vocab_size=50257, max_position_embeddings=2048, hidden_size=2560, num_layers=32, num_heads=20, window_size=256),
     "5.8b": dict(model_type="gptj", vocab_size=50400, n_positions=2048, n_embd=4096, n_layer=28, n_head=16, rotary_dim=64),
+    "bloom-7b1": dict(model_type="bloom", vocab_size=250880, hidden_size=4096, n_layer=30, n_head=32),
 }
 
 
@@ -41,6 +42,19 @@ def device_random_weights(cfg, device, seed=1, std=0.02):
     round trip for a throughput measurement).  HF state-dict names; same scales as synthetic_weights."""
     g = torch.Generator(device=device).manual_seed(seed)
     d, ffn, gptj = cfg.hidden_size, cfg.intermediate_size, cfg.model_type == "gptj"
+    if cfg.model_type == "bloom":
+        w = {"word_embeddings.weight": torch.randn((cfg.vocab_size, d), generator=g, device=device) * std,
+             "word_embeddings_layernorm.weight": torch.ones(d, device=device), "word_embeddings_layernorm.bias": torch.zeros(d, device=device),
+             "ln_f.weight": torch.ones(d, device=device), "ln_f.bias": torch.zeros(d, device=device)}
+        for i in range(cfg.num_layers):
+            p = f"h.{i}."
+            for ln in ("input_layernorm", "post_attention_layernorm"):
+                w[p + ln + ".weight"], w[p + ln + ".bias"] = torch.ones(d, device=device), torch.zeros(d, device=device)
+            for name, shape in (("self_attention.query_key_value", (3 * d, d)), ("self_attention.dense", (d, d)),
+                                ("mlp.dense_h_to_4h", (ffn, d)), ("mlp.dense_4h_to_h", (d, ffn))):
+                w[p + name + ".weight"] = torch.randn(shape, generator=g, device=device) * std
+                w[p + name + ".bias"] = torch.randn(shape[0], generator=g, device=device) * std
+        return w
 
     def nrm(*shape, s=std, mean=0.0):
         return torch.randn(shape, generator=g, device=device, dtype=torch.float32) * s + mean
@@ -100,7 +114,7 @@ def main():
     from sgpt_amd import SGPTConfig, SGPTModel, get_context, synthetic_weights
     ctx = get_context(dev)
     mkw = MODELS[args.model]
-    cfg = SGPTConfig.from_hf_dict(mkw) if mkw.get("model_type") == "gptj" else SGPTConfig(**mkw)
+    cfg = SGPTConfig.from_hf_dict(mkw) if mkw.get("model_type") in ("gptj", "bloom") else SGPTConfig(**mkw)
     weights = synthetic_weights(cfg, seed=1) if args.model == "125m" else device_random_weights(cfg, dev)
     model = SGPTModel(cfg, weights, device=dev, dtype=args.dtype, max_tokens_per_call=args.call * args.seq)
     del weights

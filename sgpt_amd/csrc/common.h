@@ -69,11 +69,13 @@ __device__ __forceinline__ float gelu_new(float u) {
     return 0.5f * u * (1.0f + tanhf(t));
 }
 
-// bf16 path: 0.5u(1+tanh(t)) == u * sigmoid(2t); one v_exp_f32 + one v_rcp_f32 instead of tanhf
+// bf16 path: 0.5u(1+tanh(t)) == u * sigmoid(2t) = u / (1 + 2^(-2t*log2e)), with the constants folded:
+// 3 mul/fma + v_exp_f32 + add + v_rcp_f32 + mul (the `1/x` spelled __frcp_rn costs an 11-instruction IEEE divide).
 __device__ __forceinline__ float gelu_new_fast(float u) {
-    const float c2 = 2.0f * 0.7978845608028654f;
-    const float t2 = c2 * (u + 0.044715f * u * u * u);
-    return u * __frcp_rn(1.0f + __expf(-t2));
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const float k1 = k0 * 0.044715f;
+    const float z = u * __builtin_fmaf(u * u, k1, k0);
+    return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 
 // ---- launch descriptors shared between the .hip translation units and api.cpp ----
