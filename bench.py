@@ -93,7 +93,8 @@ def main():
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8 = e4m3fn weight storage (SURVEY 8d cfg5), bf16 arithmetic")
     ap.add_argument("--model", default="125m", choices=sorted(MODELS), help="SGPT size (default: the BASELINE metric's 125M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the queries/sec @ 1M-doc scoring leg")
@@ -120,7 +121,7 @@ def main():
     del weights
     torch.cuda.empty_cache()
     d, S, k1 = cfg.hidden_size, args.seq, args.topk + 1      # the reference keeps top_k+1 (exact_search.py:104)
-    score_dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    score_dt = torch.float32 if args.dtype == "fp32" else torch.bfloat16
 
     # ---- synthetic inputs, resident in HBM before the clock starts (ids ~ U{0..50255}) ----
     rng = np.random.default_rng(1000 + rank)
@@ -242,7 +243,7 @@ def main():
 
     # ---- roofline of the dominant kernel (the MFMA GEMM) from live hipEvent timings ----
     gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    peak = 157.3 if args.dtype == "fp32" else PEAK_BF16_TFLOPS
     # HBM bytes per launch from the committed PMC passes of this same command (profiles/, rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 corrections applied there); null if not collected
     traffic = None
@@ -252,7 +253,7 @@ def main():
             traffic = json.load(f).get("gemm_avg_hbm_bytes_per_launch")
     roofline = {"bound": "mfma",
                 "kernel": "gemm256_kernel (bf16 256x256x64 persistent LDS-DMA GEMM; the 5 projection launches per block)"
-                          if args.dtype == "bf16" else "gemm_kernel<float> (exact fp32 MFMA 128x128x32)",
+                          if args.dtype != "fp32" else "gemm_kernel<float> (exact fp32 MFMA 128x128x32)",
                 "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, avg over the 5 GEMM launch shapes)",
                 "algorithmic_flops_per_launch": round(gemm_flops / max(n_launch, 1), 1),

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SGPT_ABI_VERSION 1
+#define SGPT_ABI_VERSION 2
 
 typedef int sgpt_status;
 #define SGPT_OK 0
@@ -44,9 +44,9 @@ typedef int sgpt_status;
 typedef struct sgpt_ctx sgpt_ctx;
 typedef struct sgpt_model sgpt_model;
 
-enum { SGPT_F32 = 0, SGPT_BF16 = 1 };                      /* element types */
+enum { SGPT_F32 = 0, SGPT_BF16 = 1, SGPT_FP8W = 2 };       /* element types; FP8W: model compute_dtype only */
 enum { SGPT_ARCH_GPTNEO = 0, SGPT_ARCH_GPTJ = 1, SGPT_ARCH_BLOOM = 2 };
-enum { SGPT_POOL_WEIGHTEDMEAN = 0, SGPT_POOL_MEAN = 1, SGPT_POOL_LASTTOKEN = 2 };
+enum { SGPT_POOL_WEIGHTEDMEAN = 0, SGPT_POOL_MEAN = 1, SGPT_POOL_LASTTOKEN = 2, SGPT_POOL_LEARNTMEAN = 3 };
 enum { SGPT_COS = 0, SGPT_DOT = 1 };
 
 /* Model hyper-parameters = the fields of HF GPTNeoConfig the forward pass reads
@@ -63,7 +63,11 @@ typedef struct {
     float ln_eps;            /* 1e-5 */
     float attn_scale;        /* 1.0 for GPT-Neo (no 1/sqrt(dh), HF:gpt_neo:110); 1/sqrt(dh) for GPT-J (HF:gptj:148) and BLOOM (HF:bloom:186) */
     int32_t compute_dtype;   /* SGPT_BF16: bf16 MFMA operands, fp32 accumulate/residual/LN/softmax;
-                                SGPT_F32 : exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the parity gate */
+                                SGPT_F32 : exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the parity gate;
+                                SGPT_FP8W: the six matmul weights per block are STORED as OCP e4m3fn with one
+                                           power-of-two fp32 scale per output channel (the
+                                           reference loads sgpt-bloom-7b1 8-bit through bitsandbytes) and
+                                           de-quantised -- exactly -- to bf16 per block; arithmetic as SGPT_BF16 */
     const uint8_t* layer_is_local;  /* host, [n_layers]: 1 = sliding-window layer (HF:gpt_neo:66) */
     int32_t rotary_dim;      /* GPT-J: leading dims of every head that get rotary position embedding (64) */
 } sgpt_model_desc;
@@ -127,6 +131,23 @@ sgpt_status sgpt_encode(sgpt_model* model, const int32_t* ids, const int32_t* po
                         int32_t pool_mode, int32_t n_layers_run, int32_t apply_final_ln,
                         int32_t normalize, float* out, float* hidden_out, void* stream);
 
+/* All L+1 hidden states pooled in ONE forward: the `meanmean` / `lasttokenmean` methods
+ * (beir_dense_retriever.py:243-257, 284-301; useb_dense_retriever.py:219-302) average the pooled vector of
+ * every entry of `all_hidden_states`.  Entry i < L is the input of block i (raw residual stream), entry L is
+ * ln_f of the last block's output (HF:gpt_neo:475-505).  Same token layout as sgpt_encode.
+ *   out_layers device fp32[n_layers+1, B, d_model] (or NULL); normalize applies to every entry;
+ *   out_mean   device fp32[B, d_model] (or NULL): the average of the L+1 entries = the method's embedding. */
+sgpt_status sgpt_encode_layers(sgpt_model* model, const int32_t* ids, const int32_t* pos,
+                               const int32_t* seq_off, const int32_t* seq_len, const int32_t* pad_left,
+                               int32_t B, int32_t T_pad, int32_t max_alloc_len, int32_t pool_mode,
+                               int32_t normalize, float* out_layers, float* out_mean, void* stream);
+
+/* Trained position weights for SGPT_POOL_LEARNTMEAN: `position_weights` of
+ * models/WeightedMeanPooling.py:21-39 (the reference reads them from 1_WeightedMeanPooling/pytorch_model.bin,
+ * useb_dense_retriever.py:253-270).  Token t of a sequence is weighted by weights[pad_left + t]; the weight sum
+ * is clamped at 1e-9.  The n fp32 values are copied (device pointer); n must cover the longest padded sequence. */
+sgpt_status sgpt_model_set_pool_weights(sgpt_model* model, const float* weights, int32_t n);
+
 /* Stand-alone pooling over caller-supplied hidden states (USEB layer sweeps, parity tests).
  * Replaces Pooling.forward (sentence_transformers/models/Pooling.py:99-125,129-164) and
  * CustomEmbedder.embed_batcher's pooling branch (beir_dense_retriever.py:238-282).
@@ -134,6 +155,9 @@ sgpt_status sgpt_encode(sgpt_model* model, const int32_t* ids, const int32_t* po
  *   weights follow the padded index t+1; weight sum clamped at 1e-9 (Pooling.py:122). */
 sgpt_status sgpt_pool(sgpt_ctx* ctx, const void* hidden, int32_t hidden_dtype, const int32_t* mask,
                       int32_t B, int32_t S, int32_t d, int32_t pool_mode, float* out, void* stream);
+/* Same with per-position weights (SGPT_POOL_LEARNTMEAN): pos_weights device fp32[>= S]. */
+sgpt_status sgpt_pool_learnt(sgpt_ctx* ctx, const void* hidden, int32_t hidden_dtype, const int32_t* mask,
+                             int32_t B, int32_t S, int32_t d, const float* pos_weights, float* out, void* stream);
 
 /* Row-wise x / max(||x||_2, 1e-12): torch.nn.functional.normalize(p=2, dim=1)
  * (sentence_transformers/util.py:41-42, 66-70).  out may alias in when out_dtype == SGPT_F32. */
@@ -142,6 +166,15 @@ sgpt_status sgpt_l2_normalize(sgpt_ctx* ctx, const float* in, int64_t n, int32_t
 
 /* fp32 -> bf16 (RNE) element-wise; used to keep a corpus shard in HBM as bf16. */
 sgpt_status sgpt_f32_to_bf16(sgpt_ctx* ctx, const float* in, int64_t numel, void* out, void* stream);
+
+/* fp8 weight storage (SGPT_FP8W) building blocks, exported for parity tests and for callers that keep
+ * their own quantised checkpoints.  w device fp32[rows, cols] (cols % 4 == 0) -> codes uint8[rows, cols]
+ * (OCP e4m3fn, round-to-nearest-even) + scale fp32[rows], scale = the smallest power of two with
+ * max|w_row| / scale <= 448.  De-quantisation code * scale is exact in bf16 and in fp32. */
+sgpt_status sgpt_fp8_quantize_rows(sgpt_ctx* ctx, const float* w, int64_t rows, int64_t cols,
+                                   uint8_t* codes, float* scale, void* stream);
+sgpt_status sgpt_fp8_dequantize_rows(sgpt_ctx* ctx, const uint8_t* codes, const float* scale, int64_t rows,
+                                     int64_t cols, void* out, int32_t out_dtype, void* stream);
 
 /* -- a7: scoring ---------------------------------------------------------------------- */
 /* Replaces cos_sim / dot_score = torch.mm(a, b.T) (sentence_transformers/util.py:24-63;

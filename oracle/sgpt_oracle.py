@@ -433,7 +433,7 @@ def forward_any(w, cfg, ids, mask, output_hidden_states=False):
 # ----------------------------------------------------------------------------
 # a4/a5: pooling
 # ----------------------------------------------------------------------------
-def pool(hidden, attention_mask, mode: str = "weightedmean", clamp: bool = True):
+def pool(hidden, attention_mask, mode: str = "weightedmean", clamp: bool = True, position_weights=None):
     """Pooling.forward (sentence_transformers/models/Pooling.py:99-125 weightedmean/mean,
     129-164 lasttoken) and the raw-HF variants (beir_dense_retriever.py:238-242 mean,
     258-270 weightedmean, 271-282 lasttoken).
@@ -442,14 +442,18 @@ def pool(hidden, attention_mask, mode: str = "weightedmean", clamp: bool = True)
     1e-9 floor on the weight sum that only Pooling.py:122 has.
     lasttoken follows the raw path's ``len-1`` semantics = index of the last mask==1
     token (beir_dense_retriever.py:198,271-282), not ST's argmin bug (appendix A.8).
+    learntmean: w_t = position_weights[t] over the padded index, weight sum clamped at 1e-9
+    (models/WeightedMeanPooling.py:21-39; raw path useb_dense_retriever.py:253-270).
     """
     h = np.asarray(hidden, dtype=F32)
     m = np.asarray(attention_mask).astype(F32)
     B, S, d = h.shape
-    if mode in ("weightedmean", "mean"):
+    if mode in ("weightedmean", "mean", "learntmean"):
         wts = m.copy()
         if mode == "weightedmean":
             wts = wts * np.arange(1, S + 1, dtype=F32)[None, :]
+        if mode == "learntmean":
+            wts = wts * np.asarray(position_weights, dtype=F32)[None, :S]
         num = (h * wts[:, :, None]).sum(axis=1, dtype=F32)
         den = wts.sum(axis=1, dtype=F32)[:, None]
         if clamp:
@@ -459,6 +463,64 @@ def pool(hidden, attention_mask, mode: str = "weightedmean", clamp: bool = True)
         idx = np.array([int(np.nonzero(r)[0][-1]) if r.any() else 0 for r in m])
         return h[np.arange(B), idx].astype(F32)
     raise ValueError(f"unknown pooling mode {mode}")
+
+
+# ----------------------------------------------------------------------------
+# fp8 (OCP e4m3fn) weight storage with a power-of-two scale per output channel
+# ("fp8-e4m3fn weights, per-output-channel fp32 scales; the oracle uses the
+# de-quantised weights in fp32").  Pinned against torch.float8_e4m3fn (tests/golden/make_golden.py).
+# ----------------------------------------------------------------------------
+def fp8_scales(w):
+    """Per row: the smallest power of two s with max|w_row| / s <= 448 (e4m3fn max); 1 for an all-zero row."""
+    amax = np.abs(np.asarray(w, dtype=F32)).max(axis=1)
+    m, e = np.frexp(amax.astype(np.float64))          # amax = m * 2^e, 0.5 <= m < 1
+    # amax / 2^k <= 448 = 0.875 * 2^9  ->  k = e - 9 if m <= 0.875 else e - 8
+    k = np.where(m <= 0.875, e - 9, e - 8)
+    k = np.clip(k, -126, 127)
+    return np.where(amax > 0, np.ldexp(1.0, k), 1.0).astype(F32)
+
+
+def fp8_e4m3fn_encode(x):
+    """fp32 -> e4m3fn code (uint8), round-to-nearest-even, saturating at +-448."""
+    x = np.asarray(x, dtype=F32)
+    sign = (x.view(np.uint32) >> 24).astype(np.uint32) & 0x80
+    a = np.abs(x)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = u + 0x7FFFF + ((u >> 20) & 1)
+    normal = np.minimum((u >> 20).astype(np.int64) - (120 << 3), 0x7E)
+    sub = np.rint(a.astype(np.float64) * 512.0).astype(np.int64)
+    code = np.where(a < F32(0.015625), sub, normal)
+    code = np.where(a >= F32(464.0), 0x7E, code)
+    code = np.where(np.isnan(a), 0x7F, code)
+    return (sign | code.astype(np.uint32)).astype(np.uint8)
+
+
+def fp8_e4m3fn_decode(code):
+    c = np.asarray(code, dtype=np.uint8).astype(np.int64)
+    e, m = (c >> 3) & 15, c & 7
+    a = np.where(e > 0, np.ldexp((8 + m).astype(np.float64), e - 10), m * 2.0 ** -9)
+    return np.where(c & 0x80, -a, a).astype(F32)
+
+
+def fp8_quantize_rows(w):
+    """[rows, cols] fp32 -> (codes uint8, scale fp32[rows]); w / scale is exact (power of two)."""
+    w = np.asarray(w, dtype=F32)
+    s = fp8_scales(w)
+    return fp8_e4m3fn_encode(w / s[:, None]), s
+
+
+def fp8_dequantize_rows(codes, scale):
+    return (fp8_e4m3fn_decode(codes) * np.asarray(scale, dtype=F32)[:, None]).astype(F32)
+
+
+def fp8_roundtrip_weights(w: dict) -> dict:
+    """The weights a dtype='fp8' model computes with: every 2-D matmul weight of the blocks goes through
+    quantise -> de-quantise (rows = output channels); embeddings, LayerNorms and biases stay fp32."""
+    out = {}
+    for k, v in w.items():
+        is_block_matmul = k.startswith("h.") and k.endswith(".weight") and np.asarray(v).ndim == 2
+        out[k] = fp8_dequantize_rows(*fp8_quantize_rows(v)) if is_block_matmul else v
+    return out
 
 
 def pool_layers(all_hidden: Sequence[np.ndarray], attention_mask, mode: str):

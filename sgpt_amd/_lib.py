@@ -7,9 +7,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsgpt_hip.so")
 
-SGPT_F32, SGPT_BF16 = 0, 1
+SGPT_F32, SGPT_BF16, SGPT_FP8W = 0, 1, 2
+SGPT_ABI_VERSION = 2
 SGPT_ARCH_GPTNEO, SGPT_ARCH_GPTJ, SGPT_ARCH_BLOOM = 0, 1, 2
-POOL_MODES = {"weightedmean": 0, "mean": 1, "lasttoken": 2}
+POOL_MODES = {"weightedmean": 0, "mean": 1, "lasttoken": 2, "learntmean": 3}
 
 
 class ModelDesc(C.Structure):
@@ -35,6 +36,16 @@ SIGNATURES = {
     "sgpt_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgpt_encode_layers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "sgpt_model_set_pool_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "sgpt_pool_learnt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgpt_fp8_quantize_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "sgpt_fp8_dequantize_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                           C.c_int32, C.c_void_p]),
     "sgpt_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                             C.c_int32, C.c_void_p, C.c_void_p]),
     "sgpt_l2_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -75,7 +86,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.sgpt_abi_version() != 1:
+    if lib.sgpt_abi_version() != SGPT_ABI_VERSION:
         raise SgptHipError("libsgpt_hip.so ABI version mismatch: rebuild with `python -m sgpt_amd.build --force`")
     _lib = lib
     return lib

@@ -66,12 +66,9 @@ class CustomEmbedder:
         if self.method in SINGLE_LAYER_METHODS:
             return self.model.encode_ids(seqs, mode=self.method, normalize=normalize, layer_idx=self.layeridx)
         # meanmean / lasttokenmean (:243-257, 284-301): average of the per-layer pooled vectors over all
-        # L+1 hidden states (equal token counts per layer make the two formulations identical)
-        acc = None
-        for li in range(L + 1):
-            e = self.model.encode_ids(seqs, mode=ALL_LAYER_METHODS[self.method], layer_idx=li)
-            acc = e if acc is None else acc.add_(e)
-        acc.div_(L + 1)
+        # L+1 hidden states (equal token counts per layer make the two formulations identical) -- pooled on
+        # the way through ONE forward (sgpt_encode_layers) instead of copying L+1 hidden states to the host
+        acc = self.model.encode_ids_all_layers(seqs, mode=ALL_LAYER_METHODS[self.method])
         return get_context(self.model.device).l2_normalize(acc) if normalize else acc
 
     # -- reference surface -------------------------------------------------------------------
@@ -207,24 +204,27 @@ class DenseRetrievalExactSearch:
 
 
 class SentenceBERTBOSEOS:
-    """custommodels/sentence_bert_asym.py:21-79: the `--usest --specb` adapter.  The reference
-    prefixes "[SOS]" / "{SOS}" marker tokens that Transformer.tokenize_bos_eos then swaps for
-    the bracket ids and closes with the EOS bracket (Transformer.py:131-153); here the brackets
-    are added directly on the id lists (same ids, no marker round trip).  Inputs follow upstream
-    BEIR's DRES: List[str] queries, List[{"title","text"}] corpus."""
+    """custommodels/sentence_bert_asym.py:21-79: the `--usest --specb / --speca` adapter.  The reference
+    prefixes "[SOS]" / "{SOS}" marker tokens that Transformer.tokenize_bos_eos keeps (speca) or swaps for
+    the bracket ids (specb) and closes with the EOS marker / bracket (Transformer.py:131-153); here the
+    ids are added directly on the id lists (same ids, no marker round trip; the content is cut to
+    max_seq_length - 3 tokens exactly as the marker-inclusive truncation of :135 does).  speca uses four
+    ADDED vocabulary rows, so the checkpoint's embedding table must already hold them (the reference
+    resizes it, sentence_bert_asym.py:54-55).  Inputs follow upstream BEIR's DRES: List[str] queries,
+    List[{"title","text"}] corpus."""
 
     def __init__(self, model_path=None, sep: str = " ", speca=False, specb=False, model: Optional[SGPTModel] = None,
                  tokenizer=None, max_seq_length: int = 300, method: str = "weightedmean", dtype="bf16",
                  device="cuda:0", **kwargs):
-        if speca:
-            raise NotImplementedError("speca adds new vocabulary rows ([SOS]/[EOS]); only specb is on the hot path")
         self.sep = sep
-        self.specb = specb
-        if not specb:
+        self.speca, self.specb = speca, specb
+        if not (specb or speca):
             raise NameError("name 'sentences' is not defined")   # the reference fails the same way (appendix A.2)
         self.model = model if model is not None else SGPTModel.from_pretrained(model_path, device=device, dtype=dtype)
         tok = tokenizer if tokenizer is not None else load_tokenizer(model_path)
-        self.pipe = TextPipeline(tok, max_seq_length, specb=True)      # max_length = max_seq_length - 2 (Transformer.py:135)
+        self.pipe = TextPipeline(tok, max_seq_length, specb=specb and not speca, speca=speca, st_path=True)
+        if speca and max(self.pipe.bos_q + self.pipe.eos_q + self.pipe.bos_d + self.pipe.eos_d) >= self.model.cfg.vocab_size:
+            raise ValueError("speca: the checkpoint's embedding table has no rows for the added [SOS]/[EOS]/{SOS}/{EOS} ids")
         self.method = method
 
     def _encode(self, texts, is_query, convert_to_tensor=False, normalize_embeddings=False, **kwargs):
@@ -242,3 +242,42 @@ class SentenceBERTBOSEOS:
         sentences = [(doc["title"] + self.sep + doc["text"]).strip() if "title" in doc else doc["text"].strip()
                      for doc in corpus]
         return self._encode(sentences, False, **kwargs)
+
+
+class SentenceBERTAsym:
+    """custommodels/sentence_bert_asym.py:8-19: asymmetric two-tower model -- queries go through the `QRY`
+    Transformer, documents through the `DOCPOS` Transformer of models/Asym.py (train_bi-encoder_mnrl.py:139),
+    one shared weight-less Pooling.  Two SGPTModel weight sets on the same GPU, the same kernels."""
+
+    def __init__(self, model_path=None, sep: str = " ", query_model: Optional[SGPTModel] = None,
+                 doc_model: Optional[SGPTModel] = None, tokenizer=None, max_seq_length: int = 300,
+                 method: str = "weightedmean", dtype="bf16", device="cuda:0", **kwargs):
+        self.sep = sep
+        if query_model is None or doc_model is None:
+            from .formats import read_st_folder
+            spec = read_st_folder(model_path)
+            if not spec.asymmetric or "QRY" not in spec.transformer_dirs or "DOCPOS" not in spec.transformer_dirs:
+                raise ValueError(f"{model_path} is not an Asym model with QRY / DOCPOS towers")
+            query_model = SGPTModel.from_pretrained(spec.transformer_dirs["QRY"], device=device, dtype=dtype)
+            doc_model = SGPTModel.from_pretrained(spec.transformer_dirs["DOCPOS"], device=device, dtype=dtype)
+            method, max_seq_length = spec.pooling_mode, spec.max_seq_length or max_seq_length
+            tokenizer = tokenizer if tokenizer is not None else load_tokenizer(spec.transformer_dirs["QRY"])
+        self.query_model, self.doc_model = query_model, doc_model
+        self.pipe = TextPipeline(tokenizer, max_seq_length)
+        self.method = method
+
+    def _encode(self, model, texts, convert_to_tensor=False, normalize_embeddings=False, **kwargs):
+        seqs = self.pipe.batch([str(t).strip() for t in texts], True)
+        emb = model.encode_ids(seqs, mode=self.method, normalize=normalize_embeddings)
+        return emb if convert_to_tensor else emb.cpu().numpy()
+
+    def encode_queries(self, queries: List[str], batch_size: int = 16, **kwargs):
+        queries = [q[1] if isinstance(q, tuple) else q for q in queries]
+        return self._encode(self.query_model, queries, **kwargs)
+
+    def encode_corpus(self, corpus: List[Dict[str, str]], batch_size: int = 8, **kwargs):
+        corpus = [c[1] if isinstance(c, tuple) else c for c in corpus]
+        kwargs.pop("batch_num", None)
+        sentences = [(doc["title"] + self.sep + doc["text"]).strip() if "title" in doc else doc["text"].strip()
+                     for doc in corpus]
+        return self._encode(self.doc_model, sentences, **kwargs)

@@ -34,6 +34,8 @@ struct LayerW {
     void* w_proj = nullptr;  // [d, ffn]
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *b_o, *b_fc, *b_proj;
     float* b_qkv = nullptr;  // BLOOM: [3d] de-interleaved (q | k | v) projection bias
+    // SGPT_FP8W: w_* hold e4m3fn codes, s_* the per-output-channel power-of-two scales
+    float *s_qkv = nullptr, *s_o = nullptr, *s_fc = nullptr, *s_proj = nullptr;
     int is_local = 0;
 };
 
@@ -45,6 +47,8 @@ struct sgpt_model {
     float *rot_sin = nullptr, *rot_cos = nullptr;   // GPT-J rotary tables [max_pos, rotary_dim/2]
     float *emb_ln_g = nullptr, *emb_ln_b = nullptr, *alibi = nullptr;   // BLOOM: embedding LayerNorm, ALiBi slopes [H]
     float* zero_bias = nullptr;                      // [max(d, ffn)] zeros: bias-free projections (GPT-J out_proj)
+    float* pool_w = nullptr; int pool_w_n = 0;       // learntmean position weights (sgpt_model_set_pool_weights)
+    void* dq[4] = {nullptr, nullptr, nullptr, nullptr};   // SGPT_FP8W: bf16 scratch for the current block's qkv / o / fc / proj
     std::vector<void*> allocs;
 };
 
@@ -165,11 +169,12 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     const int dm = d->d_model, ffn = d->d_ffn, H = d->n_heads;
     if (dm % 128 || ffn % 128 || H <= 0 || dm % H) return fail(c, SGPT_ERR_INVALID, "d_model and d_ffn must be multiples of 128");
     const int dh = dm / H;
-    if (d->compute_dtype == SGPT_BF16 && dh != 64 && dh != 128 && dh != 256)
+    if (d->compute_dtype != SGPT_F32 && dh != 64 && dh != 128 && dh != 256)
         return fail(c, SGPT_ERR_INVALID, "bf16 attention supports head_dim 64, 128 or 256");
     if (dh > 256 || dh % 4) return fail(c, SGPT_ERR_INVALID, "head_dim must be <= 256 and a multiple of 4");
     if (dm > 4096) return fail(c, SGPT_ERR_INVALID, "d_model > 4096 not supported");
-    if (d->compute_dtype != SGPT_BF16 && d->compute_dtype != SGPT_F32) return fail(c, SGPT_ERR_INVALID, "bad compute_dtype");
+    if (d->compute_dtype != SGPT_BF16 && d->compute_dtype != SGPT_F32 && d->compute_dtype != SGPT_FP8W)
+        return fail(c, SGPT_ERR_INVALID, "bad compute_dtype");
     if (gptj && (d->rotary_dim <= 0 || d->rotary_dim > dh || d->rotary_dim % 2))
         return fail(c, SGPT_ERR_INVALID, "GPT-J needs an even rotary_dim in (0, head_dim]");
 
@@ -179,8 +184,9 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     m->ctx = c;
     m->d = *d;
     m->d.layer_is_local = nullptr;
+    const bool fp8 = d->compute_dtype == SGPT_FP8W;
     const bool bf = d->compute_dtype == SGPT_BF16;
-    const size_t esz = bf ? 2 : 4;
+    const size_t esz = fp8 ? 1 : (bf ? 2 : 4);
     sgpt_status st = SGPT_OK;
 
     auto find = [&](const std::string& name, int64_t numel) -> const float* {
@@ -203,13 +209,17 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         if (hipMemcpyAsync(dst, src, numel * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memcpy " + name);
         return dst;
     };
-    // matmul weight -> packed dtype at dst (element offset)
-    auto pack_w = [&](const std::string& name, int64_t numel, void* dst, int64_t off) {
-        const float* src = find(name, numel);
-        if (!src) return;
-        if (bf) launch_f32_to_bf16(src, numel, (bf16_t*)dst + off, 0);
+    // matmul weight [rows, cols] -> packed dtype at row `row_off` of dst (fp8: codes + one scale per row)
+    auto pack_rows = [&](const float* src, int64_t rows, int64_t cols, void* dst, int64_t row_off, float* scale) {
+        const int64_t off = row_off * cols, numel = rows * cols;
+        if (fp8) launch_fp8_quant_rows(src, rows, cols, (uint8_t*)dst + off, scale + row_off, 0);
+        else if (bf) launch_f32_to_bf16(src, numel, (bf16_t*)dst + off, 0);
         else if (hipMemcpyAsync((float*)dst + off, src, numel * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess)
-            st = fail(c, SGPT_ERR_HIP, "memcpy " + name);
+            st = fail(c, SGPT_ERR_HIP, "memcpy weight");
+    };
+    auto pack_w = [&](const std::string& name, int64_t rows, int64_t cols, void* dst, int64_t row_off, float* scale) {
+        const float* src = find(name, rows * cols);
+        if (src) pack_rows(src, rows, cols, dst, row_off, scale);
     };
 
     m->wte = copy_f32(bloom ? "word_embeddings.weight" : "wte.weight", (int64_t)d->vocab * dm);
@@ -255,6 +265,10 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         l.w_o = dalloc((size_t)dm * dm * esz);
         l.w_fc = dalloc((size_t)ffn * dm * esz);
         l.w_proj = dalloc((size_t)dm * ffn * esz);
+        if (fp8) {
+            l.s_qkv = (float*)dalloc((size_t)3 * dm * 4); l.s_o = (float*)dalloc((size_t)dm * 4);
+            l.s_fc = (float*)dalloc((size_t)ffn * 4); l.s_proj = (float*)dalloc((size_t)dm * 4);
+        }
         if (st != SGPT_OK) break;
         if (bloom) {
             const float* wq = find(p + "self_attention.query_key_value.weight", (int64_t)3 * dm * dm);
@@ -263,18 +277,20 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
             if (!wq || !bq || !l.b_qkv || !stage) break;
             launch_qkv_deinterleave(wq, stage, H, dh, dm, 0);          // rows [h,3,dh] -> [q | k | v]
             launch_qkv_deinterleave(bq, l.b_qkv, H, dh, 1, 0);
-            if (bf) launch_f32_to_bf16(stage, (int64_t)3 * dm * dm, l.w_qkv, 0);
-            else if (hipMemcpyAsync(l.w_qkv, stage, (size_t)3 * dm * dm * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess)
-                st = fail(c, SGPT_ERR_HIP, "memcpy qkv");
-            pack_w(p + "self_attention.dense.weight", (int64_t)dm * dm, l.w_o, 0);
+            pack_rows(stage, (int64_t)3 * dm, dm, l.w_qkv, 0, l.s_qkv);
+            pack_w(p + "self_attention.dense.weight", dm, dm, l.w_o, 0, l.s_o);
         } else {
-            pack_w(p + attn + "q_proj.weight", (int64_t)dm * dm, l.w_qkv, 0);
-            pack_w(p + attn + "k_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)dm * dm);
-            pack_w(p + attn + "v_proj.weight", (int64_t)dm * dm, l.w_qkv, (int64_t)2 * dm * dm);
-            pack_w(p + attn + "out_proj.weight", (int64_t)dm * dm, l.w_o, 0);
+            pack_w(p + attn + "q_proj.weight", dm, dm, l.w_qkv, 0, l.s_qkv);
+            pack_w(p + attn + "k_proj.weight", dm, dm, l.w_qkv, dm, l.s_qkv);
+            pack_w(p + attn + "v_proj.weight", dm, dm, l.w_qkv, (int64_t)2 * dm, l.s_qkv);
+            pack_w(p + attn + "out_proj.weight", dm, dm, l.w_o, 0, l.s_o);
         }
-        pack_w(p + fc1 + ".weight", (int64_t)ffn * dm, l.w_fc, 0);
-        pack_w(p + fc2 + ".weight", (int64_t)dm * ffn, l.w_proj, 0);
+        pack_w(p + fc1 + ".weight", ffn, dm, l.w_fc, 0, l.s_fc);
+        pack_w(p + fc2 + ".weight", dm, ffn, l.w_proj, 0, l.s_proj);
+    }
+    if (fp8 && st == SGPT_OK) {
+        m->dq[0] = dalloc((size_t)3 * dm * dm * 2); m->dq[1] = dalloc((size_t)dm * dm * 2);
+        m->dq[2] = dalloc((size_t)ffn * dm * 2); m->dq[3] = dalloc((size_t)dm * ffn * 2);
     }
     if (st == SGPT_OK && hipDeviceSynchronize() != hipSuccess) st = fail(c, SGPT_ERR_HIP, "sync after weight pack");
     if (st != SGPT_OK) { sgpt_model_free(m); return st; }
@@ -290,23 +306,33 @@ void sgpt_model_free(sgpt_model* m) {
     delete m;
 }
 
+}  // extern "C"
+
 // ------------------------------------------------------------------------------------------
-sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, const int32_t* seq_off,
-                        const int32_t* seq_len, const int32_t* pad_left, int32_t B, int32_t T, int32_t max_alloc,
-                        int32_t pool_mode, int32_t n_layers_run, int32_t apply_final_ln, int32_t normalize,
-                        float* out, float* hidden_out, void* stream) {
+// One forward over the packed token axis.  `layer_out` (fp32 [n_layers+1, B, d]) additionally receives the pooled
+// vector of every hidden state on the way (sgpt_encode_layers).
+static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t* pos, const int32_t* seq_off,
+                               const int32_t* seq_len, const int32_t* pad_left, int32_t B, int32_t T, int32_t max_alloc,
+                               int32_t pool_mode, int32_t n_layers_run, int32_t apply_final_ln, int32_t normalize,
+                               float* out, float* hidden_out, float* layer_out, float* layer_mean, void* stream) {
     if (!m) return SGPT_ERR_INVALID;
     sgpt_ctx* c = m->ctx;
     if (!ids || !pos || !seq_off || !seq_len || B <= 0 || T <= 0 || T % 128 || max_alloc <= 0 || max_alloc % 16)
         return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad token layout (T_pad % 128, max_alloc_len % 16)");
     if (n_layers_run < 0 || n_layers_run > m->d.n_layers) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: n_layers_run out of range");
-    if (pool_mode < 0 || pool_mode > 2) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad pool_mode");
+    if (pool_mode < 0 || pool_mode > 3) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad pool_mode");
+    if (pool_mode == SGPT_POOL_LEARNTMEAN && (out || layer_out || layer_mean)) {
+        if (!m->pool_w) return fail(c, SGPT_ERR_MISSING, "sgpt_encode: learntmean needs sgpt_model_set_pool_weights first");
+        if (!pad_left && max_alloc > m->pool_w_n)
+            return fail(c, SGPT_ERR_INVALID, "sgpt_encode: fewer learnt position weights than the longest sequence");
+    }
     if (max_alloc > 2048) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: sequence longer than 2048 tokens");
-    if (!out && !hidden_out) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: no output requested");
+    if (!out && !hidden_out && !layer_out && !layer_mean) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: no output requested");
     HIPC(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const int dm = m->d.d_model, ffn = m->d.d_ffn, H = m->d.n_heads, dh = dm / H;
-    const bool bf = m->d.compute_dtype == SGPT_BF16;
+    const bool fp8 = m->d.compute_dtype == SGPT_FP8W;
+    const bool bf = m->d.compute_dtype != SGPT_F32;
     const int dt = bf ? SGPT_BF16 : SGPT_F32;
     const size_t esz = bf ? 2 : 4;
     const size_t SLACK = 64;  // rows of zeroed slack behind buffers the attention key tiles may over-read
@@ -320,9 +346,11 @@ sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, c
     const size_t o_c = gptj ? carve((size_t)T * dm * esz) : o_a;         // GPT-J: ctx separate (ln_1 output feeds the MLP too)
     const size_t o_qkv = carve(((size_t)T + SLACK) * 3 * dm * esz);      // bf16: [T][2d] qk + V^T [d][T]; fp32: [T][3d]
     const size_t o_h = carve((size_t)T * ffn * esz);                     // MLP hidden
+    const size_t o_lp = (layer_mean && !layer_out) ? carve((size_t)(m->d.n_layers + 1) * B * dm * 4) : 0;
     sgpt_status st = ensure(c, &c->ws, &c->ws_bytes, off);
     if (st != SGPT_OK) return st;
     char* base = (char*)c->ws;
+    if (layer_mean && !layer_out) layer_out = (float*)(base + o_lp);     // per-layer pooled vectors, scratch
     float* x = (float*)(base + o_x);
     void* a = base + o_a;
     void* ctx = base + o_c;
@@ -344,7 +372,17 @@ sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, c
     launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, s);
     if (m->emb_ln_g) launch_layernorm(x, m->emb_ln_g, m->emb_ln_b, x, SGPT_F32, T, dm, m->d.ln_eps, s);   // BLOOM :499
     for (int li = 0; li < n_layers_run; ++li) {
-        const LayerW& l = m->L[li];
+        LayerW l = m->L[li];
+        if (layer_out)   // hidden_states[li] = input of block li (HF:gpt_neo:475-478)
+            launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, 0, pool_mode,
+                            normalize, m->pool_w, layer_out + (size_t)li * B * dm, s);
+        if (fp8) {  // this block's weights: e4m3fn codes * 2^k -> bf16, exact; <1 % of the block's time at T >= 16k
+            launch_fp8_dequant_rows(l.w_qkv, l.s_qkv, (long)3 * dm, dm, m->dq[0], SGPT_BF16, s);
+            launch_fp8_dequant_rows(l.w_o, l.s_o, dm, dm, m->dq[1], SGPT_BF16, s);
+            launch_fp8_dequant_rows(l.w_fc, l.s_fc, ffn, dm, m->dq[2], SGPT_BF16, s);
+            launch_fp8_dequant_rows(l.w_proj, l.s_proj, dm, ffn, m->dq[3], SGPT_BF16, s);
+            l.w_qkv = m->dq[0]; l.w_o = m->dq[1]; l.w_fc = m->dq[2]; l.w_proj = m->dq[3];
+        }
         launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
         GemmArgs g{};
         g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
@@ -385,8 +423,48 @@ sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, c
     }
     if (out)
         launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, apply_final_ln,
-                        pool_mode, normalize, out, s);
+                        pool_mode, normalize, m->pool_w, out, s);
+    if (layer_out)
+        launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, apply_final_ln,
+                        pool_mode, normalize, m->pool_w, layer_out + (size_t)n_layers_run * B * dm, s);
+    if (layer_mean) launch_mean_over_axis0(layer_out, n_layers_run + 1, (long)B * dm, layer_mean, s);
     HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+extern "C" {
+
+sgpt_status sgpt_encode(sgpt_model* m, const int32_t* ids, const int32_t* pos, const int32_t* seq_off,
+                        const int32_t* seq_len, const int32_t* pad_left, int32_t B, int32_t T, int32_t max_alloc,
+                        int32_t pool_mode, int32_t n_layers_run, int32_t apply_final_ln, int32_t normalize,
+                        float* out, float* hidden_out, void* stream) {
+    return encode_impl(m, ids, pos, seq_off, seq_len, pad_left, B, T, max_alloc, pool_mode, n_layers_run,
+                       apply_final_ln, normalize, out, hidden_out, nullptr, nullptr, stream);
+}
+
+sgpt_status sgpt_encode_layers(sgpt_model* m, const int32_t* ids, const int32_t* pos, const int32_t* seq_off,
+                               const int32_t* seq_len, const int32_t* pad_left, int32_t B, int32_t T, int32_t max_alloc,
+                               int32_t pool_mode, int32_t normalize, float* out_layers, float* out_mean, void* stream) {
+    if (!m) return SGPT_ERR_INVALID;
+    if (!out_layers && !out_mean) return fail(m->ctx, SGPT_ERR_INVALID, "sgpt_encode_layers: no output requested");
+    return encode_impl(m, ids, pos, seq_off, seq_len, pad_left, B, T, max_alloc, pool_mode, m->d.n_layers, 1, normalize,
+                       nullptr, nullptr, out_layers, out_mean, stream);
+}
+
+sgpt_status sgpt_model_set_pool_weights(sgpt_model* m, const float* w, int32_t n) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (!w || n <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_pool_weights: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());      // an in-flight encode may still read the previous table
+    if (n > m->pool_w_n) {
+        float* p = nullptr;
+        if (hipMalloc((void**)&p, (size_t)n * 4) != hipSuccess) return fail(c, SGPT_ERR_OOM, "hipMalloc pool weights failed");
+        m->allocs.push_back(p);           // the old, smaller table is released with the model
+        m->pool_w = p;
+    }
+    m->pool_w_n = n;
+    HIPC(c, hipMemcpy(m->pool_w, w, (size_t)n * 4, hipMemcpyDeviceToDevice));
     return SGPT_OK;
 }
 
@@ -395,7 +473,37 @@ sgpt_status sgpt_pool(sgpt_ctx* c, const void* hidden, int32_t dtype, const int3
     if (!c || !hidden || !mask || !out || B <= 0 || S <= 0 || d <= 0 || d % 4 || mode < 0 || mode > 2)
         return fail(c, SGPT_ERR_INVALID, "sgpt_pool: bad arguments (d % 4 == 0 required)");
     HIPC(c, hipSetDevice(c->device));
-    launch_pool(hidden, dtype, mask, B, S, d, mode, out, (hipStream_t)stream);
+    launch_pool(hidden, dtype, mask, B, S, d, mode, nullptr, out, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_pool_learnt(sgpt_ctx* c, const void* hidden, int32_t dtype, const int32_t* mask, int32_t B, int32_t S,
+                             int32_t d, const float* pos_weights, float* out, void* stream) {
+    if (!c || !hidden || !mask || !out || !pos_weights || B <= 0 || S <= 0 || d <= 0 || d % 4)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_pool_learnt: bad arguments (d % 4 == 0 required)");
+    HIPC(c, hipSetDevice(c->device));
+    launch_pool(hidden, dtype, mask, B, S, d, SGPT_POOL_LEARNTMEAN, pos_weights, out, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_fp8_quantize_rows(sgpt_ctx* c, const float* w, int64_t rows, int64_t cols, uint8_t* codes, float* scale,
+                                   void* stream) {
+    if (!c || !w || !codes || !scale || rows <= 0 || cols <= 0 || cols % 4)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_fp8_quantize_rows: bad arguments (cols % 4 == 0 required)");
+    HIPC(c, hipSetDevice(c->device));
+    launch_fp8_quant_rows(w, rows, cols, codes, scale, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_fp8_dequantize_rows(sgpt_ctx* c, const uint8_t* codes, const float* scale, int64_t rows, int64_t cols,
+                                     void* out, int32_t out_dtype, void* stream) {
+    if (!c || !codes || !scale || !out || rows <= 0 || cols <= 0 || cols % 4 || (out_dtype != SGPT_F32 && out_dtype != SGPT_BF16))
+        return fail(c, SGPT_ERR_INVALID, "sgpt_fp8_dequantize_rows: bad arguments (cols % 4 == 0 required)");
+    HIPC(c, hipSetDevice(c->device));
+    launch_fp8_dequant_rows(codes, scale, rows, cols, out, out_dtype, (hipStream_t)stream);
     HIPC(c, hipGetLastError());
     return SGPT_OK;
 }

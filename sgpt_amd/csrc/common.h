@@ -124,11 +124,17 @@ void launch_embed(const int* ids, const int* pos, const float* wte, const float*
 void launch_layernorm(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
                       float eps, hipStream_t s);
 void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,
-                     const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize, float* out,
-                     hipStream_t s);
-void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, int d, int mode, float* out,
-                 hipStream_t s);
+                     const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize,
+                     const float* pos_weights, float* out, hipStream_t s);
+void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, int d, int mode,
+                 const float* pos_weights, float* out, hipStream_t s);
+// fp8 e4m3fn weight storage, one power-of-two scale per row (output channel)
+void launch_fp8_quant_rows(const float* w, long rows, long cols, void* q, float* scale, hipStream_t s);
+void launch_fp8_dequant_rows(const void* q, const float* scale, long rows, long cols, void* out, int out_dtype,
+                             hipStream_t s);
 void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s);
+// out[i] = mean_j in[j][i], in fp32 [n0][n] (layer average of the meanmean / lasttokenmean methods)
+void launch_mean_over_axis0(const float* in, int n0, long n, float* out, hipStream_t s);
 void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s);
 void launch_fill_f32(float* p, long n, float v, hipStream_t s);
 // GPT-J rotary embedding, in place on the q / k columns of the projection buffer

@@ -96,13 +96,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // weightedmean: sum_t (P+t+1) * h_t / clamp(sum_t (P+t+1), 1e-9), P = pad_left
 //   (Pooling.py:99-125; beir_dense_retriever.py:258-270; weights follow the PADDED index)
 // mean: Pooling.py:117-125 / beir_dense_retriever.py:238-242;  lasttoken: :271-282 (index len-1)
+// learntmean (mode 3): w_t = position_weights[P+t], clamp 1e-9 (WeightedMeanPooling.py:21-39)
 template <int NV>
 __global__ __launch_bounds__(256) void lnf_pool_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                        const float* __restrict__ b, const int* __restrict__ seq_off,
                                                        const int* __restrict__ seq_len,
                                                        const int* __restrict__ pad_left, int d, float eps,
                                                        int apply_ln, int mode, int normalize,
-                                                       float* __restrict__ out) {
+                                                       const float* __restrict__ pw, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][d] + 8
     const int sq = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -117,7 +118,9 @@ __global__ __launch_bounds__(256) void lnf_pool_kernel(const float* __restrict__
         RowLN<NV> r;
         r.load(x + (long)(s0 + t) * d, d, lane);
         if (apply_ln) r.normalize(g, b, d, eps, lane);
-        const float w = mode == 0 ? (float)(P + t + 1) : 1.0f;
+        // mode 3 (learntmean): trained per-position weights, indexed like the padded position
+        // (WeightedMeanPooling.py:21-39; useb_dense_retriever.py:253-270)
+        const float w = mode == 0 ? (float)(P + t + 1) : (mode == 3 ? pw[P + t] : 1.0f);
         den += w;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -166,7 +169,7 @@ template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void pool_kernel(const T* __restrict__ h, const int* __restrict__ mask, int S, int d,
-                                                   int mode, float* __restrict__ out) {
+                                                   int mode, const float* __restrict__ pw, float* __restrict__ out) {
     const int bq = blockIdx.x;
     const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
     if (c >= d) return;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const T* __restrict__ h, cons
         float den = 0.f;
 #pragma unroll 4
         for (int t = 0; t < S; ++t) {
-            const float w = mb[t] != 0 ? (mode == 0 ? (float)(t + 1) : 1.0f) : 0.0f;
+            const float w = mb[t] != 0 ? (mode == 0 ? (float)(t + 1) : (mode == 3 ? pw[t] : 1.0f)) : 0.0f;
             const float4 v = load4<T>(hb + (long)t * d);
             den += w;
             acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
@@ -251,10 +254,81 @@ __global__ __launch_bounds__(256) void qkv_deinterleave_kernel(const float* __re
     for (long i = threadIdx.x; i < row_len; i += 256) dst[(long)drow * row_len + i] = src[srow * row_len + i];
 }
 
+// ---- fp8 (OCP e4m3fn) weight storage with one power-of-two fp32 scale per output channel (row) ----
+// scale[r] = smallest 2^k with amax_r / 2^k <= 448; code = RNE(w / scale) in e4m3fn.  Dividing by a power of
+// two is exact, and code * scale is exactly representable in bf16 (4 significant bits), so the bf16 MFMA path
+// runs on precisely the de-quantised weights the oracle uses in fp32.  Software encode/decode: load-time and
+// once-per-layer work, and independent of any hardware conversion / saturation mode.
+__device__ __forceinline__ uint32_t e4m3fn_encode(float x) {
+    const uint32_t sign = (__float_as_uint(x) >> 24) & 0x80u;
+    const float a = fabsf(x);
+    if (!(a < 464.f)) return sign | (a != a ? 0x7fu : 0x7eu);        // saturate to 448; NaN stays NaN
+    if (a < 0.015625f) return sign | (uint32_t)rintf(a * 512.f);      // subnormals: multiples of 2^-9 (8 -> min normal)
+    uint32_t u = __float_as_uint(a);
+    u += 0x7ffffu + ((u >> 20) & 1u);                                 // RNE to 3 mantissa bits
+    u >>= 20;
+    const uint32_t code = u - (120u << 3);                            // re-bias 127 -> 7
+    return sign | (code > 0x7eu ? 0x7eu : code);
+}
+__device__ __forceinline__ float e4m3fn_decode(uint32_t c) {
+    const uint32_t e = (c >> 3) & 15u, m = c & 7u;
+    const float a = e ? __uint_as_float(((e + 120u) << 23) | (m << 20)) : (float)m * 0.001953125f;
+    return (c & 0x80u) ? -a : a;
+}
+
+// one wave per row: amax -> scale, then encode
+__global__ __launch_bounds__(256) void fp8_quant_rows_kernel(const float* __restrict__ w, long rows, long cols,
+                                                             uint8_t* __restrict__ q, float* __restrict__ scale) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* wr = w + row * cols;
+    float amax = 0.f;
+    for (long c = lane; c < cols; c += 64) amax = fmaxf(amax, fabsf(wr[c]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    float sc = 1.0f;
+    if (amax > 0.f && amax < 3.0e38f) {
+        const uint32_t u = __float_as_uint(amax);
+        const int e = (int)((u >> 23) & 0xffu) - 127;                 // amax = m * 2^e, 1 <= m < 2 (subnormal amax: e = -127)
+        const uint32_t frac = u & 0x7fffffu;
+        int k = e - (frac > 0x600000u ? 7 : 8);                       // m <= 1.75 -> 2^(e-8), else 2^(e-7)
+        k = k < -126 ? -126 : (k > 127 ? 127 : k);
+        sc = __uint_as_float((uint32_t)(k + 127) << 23);
+    }
+    if (lane == 0) scale[row] = sc;
+    const float inv = 1.0f / sc;                                      // exact: power of two
+    for (long c = lane; c < cols; c += 64) q[row * cols + c] = (uint8_t)e4m3fn_encode(wr[c] * inv);
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void fp8_dequant_rows_kernel(const uint8_t* __restrict__ q, const float* __restrict__ scale,
+                                                               long rows, long cols, OutT* __restrict__ out) {
+    // cols % 4 == 0: each thread decodes 4 codes of one row
+    const long n4 = rows * cols / 4, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const uint32_t u = reinterpret_cast<const uint32_t*>(q)[i];
+        const float sc = scale[i * 4 / cols];
+        const float v0 = e4m3fn_decode(u & 0xffu) * sc, v1 = e4m3fn_decode((u >> 8) & 0xffu) * sc;
+        const float v2 = e4m3fn_decode((u >> 16) & 0xffu) * sc, v3 = e4m3fn_decode(u >> 24) * sc;
+        if constexpr (sizeof(OutT) == 4) reinterpret_cast<float4*>(out)[i] = make_float4(v0, v1, v2, v3);
+        else reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+    }
+}
+
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, long numel,
                                                        bf16_t* __restrict__ out) {
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += stride) out[i] = f32_to_bf16(in[i]);
+}
+
+__global__ __launch_bounds__(256) void mean_axis0_kernel(const float* __restrict__ in, int n0, long n,
+                                                         float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int j = 0; j < n0; ++j) acc += in[(long)j * n + i];
+    out[i] = acc / (float)n0;
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n, float v) {
@@ -300,12 +374,12 @@ void launch_layernorm(const float* x, const float* g, const float* b, void* out,
 }
 
 void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,
-                     const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize, float* out,
-                     hipStream_t s) {
+                     const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize,
+                     const float* pos_weights, float* out, hipStream_t s) {
     const size_t sm = (size_t)(4 * d + 8) * sizeof(float);
 #define LP_CASE(NV)                                                                                              \
     hipLaunchKernelGGL((lnf_pool_kernel<NV>), dim3(B), dim3(256), sm, s, x, g, b, seq_off, seq_len, pad_left, d, \
-                       eps, apply_ln, mode, normalize, out);
+                       eps, apply_ln, mode, normalize, pos_weights, out);
     const int nv = (d + 255) / 256;
     if (nv <= 1) { LP_CASE(1) } else if (nv <= 2) { LP_CASE(2) } else if (nv <= 3) { LP_CASE(3) }
     else if (nv <= 4) { LP_CASE(4) } else if (nv <= 8) { LP_CASE(8) } else if (nv <= 10) { LP_CASE(10) }
@@ -313,13 +387,33 @@ void launch_lnf_pool(const float* x, const float* g, const float* b, const int* 
 #undef LP_CASE
 }
 
-void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, int d, int mode, float* out,
-                 hipStream_t s) {
+void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, int d, int mode,
+                 const float* pos_weights, float* out, hipStream_t s) {
     dim3 grid(B, (d / 4 + 255) / 256);
     if (dtype == 1)
-        hipLaunchKernelGGL(pool_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)hidden, mask, S, d, mode, out);
+        hipLaunchKernelGGL(pool_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)hidden, mask, S, d, mode, pos_weights, out);
     else
-        hipLaunchKernelGGL(pool_kernel<float>, grid, dim3(256), 0, s, (const float*)hidden, mask, S, d, mode, out);
+        hipLaunchKernelGGL(pool_kernel<float>, grid, dim3(256), 0, s, (const float*)hidden, mask, S, d, mode, pos_weights, out);
+}
+
+void launch_fp8_quant_rows(const float* w, long rows, long cols, void* q, float* scale, hipStream_t s) {
+    hipLaunchKernelGGL(fp8_quant_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, w, rows, cols,
+                       (uint8_t*)q, scale);
+}
+
+void launch_fp8_dequant_rows(const void* q, const float* scale, long rows, long cols, void* out, int out_dtype,
+                             hipStream_t s) {
+    const int grid = cap_grid((rows * cols / 4 + 255) / 256);
+    if (out_dtype == 1)
+        hipLaunchKernelGGL(fp8_dequant_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const uint8_t*)q, scale, rows,
+                           cols, (bf16_t*)out);
+    else
+        hipLaunchKernelGGL(fp8_dequant_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const uint8_t*)q, scale, rows,
+                           cols, (float*)out);
+}
+
+void launch_mean_over_axis0(const float* in, int n0, long n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(mean_axis0_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n0, n, out);
 }
 
 void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s) {

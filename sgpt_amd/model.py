@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F32
+from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F32, SGPT_FP8W
 from .runtime import Context, get_context, _p, _stream_ptr
 
 ALIGN = 16         # sequence starts on the packed token axis (MFMA 16-row tiles; V^T 8-byte loads)
@@ -82,6 +82,7 @@ class PackedBatch:
     T_pad: int
     max_alloc: int
     n_tokens: int  # real tokens (for throughput accounting)
+    max_pos: int = 0  # largest position id (pad_left + len - 1): bounds the learntmean weight table
 
 
 def pack_host(seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None):
@@ -106,7 +107,8 @@ def pack_host(seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] =
     ids[rows] = flat
     pos[rows] = (within + np.repeat(pl.astype(np.int64), lens)).astype(np.int32)
     return dict(ids=ids, pos=pos, seq_off=off.astype(np.int32), seq_len=lens.astype(np.int32), pad_left=pl,
-                B=B, T_pad=T_pad, max_alloc=int(alloc.max()), n_tokens=int(lens.sum()))
+                B=B, T_pad=T_pad, max_alloc=int(alloc.max()), n_tokens=int(lens.sum()),
+                max_pos=int((lens + pl.astype(np.int64)).max()) - 1)
 
 
 class SGPTModel:
@@ -114,8 +116,9 @@ class SGPTModel:
 
     def __init__(self, cfg: SGPTConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device=None,
                  dtype: str = "bf16", ctx: Optional[Context] = None, max_tokens_per_call: int = 32768):
-        if dtype not in ("bf16", "fp32"):
-            raise ValueError("dtype must be 'bf16' (MFMA bf16 operands) or 'fp32' (exact fp32 MFMA)")
+        if dtype not in ("bf16", "fp32", "fp8"):
+            raise ValueError("dtype must be 'bf16' (MFMA bf16 operands), 'fp32' (exact fp32 MFMA) or "
+                             "'fp8' (e4m3fn weight storage, bf16 arithmetic)")
         self.cfg = cfg
         self.ctx = ctx or get_context(device)
         self.device = self.ctx.device
@@ -131,7 +134,7 @@ class SGPTModel:
                          vocab=cfg.vocab_size, max_pos=cfg.max_position_embeddings, window=cfg.window_size,
                          ln_eps=cfg.layer_norm_epsilon,
                          attn_scale=float(1.0 / np.sqrt(np.float32(dh))) if (gptj or bloom) else 1.0,   # HF:gptj:148, HF:bloom:186 / HF:gpt_neo:110
-                         compute_dtype=SGPT_BF16 if dtype == "bf16" else SGPT_F32,
+                         compute_dtype={"bf16": SGPT_BF16, "fp32": SGPT_F32, "fp8": SGPT_FP8W}[dtype],
                          layer_is_local=C.cast(local, C.POINTER(C.c_uint8)), rotary_dim=cfg.rotary_dim if gptj else 0)
         if gptj:
             weights = dict(weights)
@@ -142,6 +145,8 @@ class SGPTModel:
         names, keep = [], []
         for k, v in weights.items():
             k2 = k[len("transformer."):] if k.startswith("transformer.") else k
+            if k2 == "position_weights":          # learntmean table riding along with the weights
+                continue
             if (k2.endswith("attn.attention.bias") or k2.endswith("attn.bias") or k2.endswith("masked_bias")
                     or k2.endswith("embed_positions") or k2.startswith("lm_head")):
                 continue
@@ -156,6 +161,18 @@ class SGPTModel:
                    "sgpt_model_load")
         self.handle = h
         del keep  # the library now owns packed copies
+        self.position_weights = None
+        if "position_weights" in weights:
+            self.set_position_weights(weights["position_weights"])
+
+    def set_position_weights(self, w) -> None:
+        """Trained `position_weights` of models/WeightedMeanPooling.py:16-19 for method 'learntmean'
+        (the reference reads 1_WeightedMeanPooling/pytorch_model.bin, useb_dense_retriever.py:253-257)."""
+        t = w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w))
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        _lib.check(self.ctx.handle, self.ctx.lib.sgpt_model_set_pool_weights(self.handle, _p(t), t.numel()),
+                   "sgpt_model_set_pool_weights")
+        self.position_weights = t
 
     def close(self):
         if getattr(self, "handle", None):
@@ -179,7 +196,11 @@ class SGPTModel:
             sd = load_file(st)
         else:
             sd = torch.load(os.path.join(root, "pytorch_model.bin"), map_location="cpu")
-        return cls(cfg, sd, **kw)
+        model = cls(cfg, sd, **kw)
+        wmp = os.path.join(path, "1_WeightedMeanPooling", "pytorch_model.bin")
+        if os.path.exists(wmp):
+            model.set_position_weights(torch.load(wmp, map_location="cpu")["position_weights"])
+        return model
 
     # ---- packing ----
     def pack(self, seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None) -> PackedBatch:
@@ -188,7 +209,7 @@ class SGPTModel:
             raise ValueError("sequence longer than max_position_embeddings")
         dev = lambda a: torch.from_numpy(a).to(self.device, non_blocking=False)  # noqa: E731
         return PackedBatch(dev(h["ids"]), dev(h["pos"]), dev(h["seq_off"]), dev(h["seq_len"]), dev(h["pad_left"]),
-                           h["B"], h["T_pad"], h["max_alloc"], h["n_tokens"])
+                           h["B"], h["T_pad"], h["max_alloc"], h["n_tokens"], h["max_pos"])
 
     # ---- one C call: forward + pool ----
     def encode_packed(self, pb: PackedBatch, mode: str = "weightedmean", normalize: bool = False,
@@ -202,6 +223,7 @@ class SGPTModel:
         if not 0 <= li <= L:
             raise ValueError(f"Layer Idx {layer_idx} is larger than the {L + 1} hidden states")
         n_run, final_ln = (L, 1) if li == L else (li, 0)
+        self._check_learnt(mode, pb)
         d = self.cfg.hidden_size
         if out is None:
             out = torch.empty((pb.B, d), dtype=torch.float32, device=self.device)
@@ -212,6 +234,31 @@ class SGPTModel:
                                       _stream_ptr(self.device))
         _lib.check(self.ctx.handle, st, "sgpt_encode")
         return (out, hidden) if return_hidden else out
+
+    def _check_learnt(self, mode: str, pb: PackedBatch) -> None:
+        if mode != "learntmean":
+            return
+        if self.position_weights is None:
+            raise ValueError("method 'learntmean' needs trained position weights (1_WeightedMeanPooling)")
+        if pb.max_pos >= self.position_weights.numel():
+            raise ValueError("fewer learnt position weights than the longest padded sequence")
+
+    def encode_packed_layers(self, pb: PackedBatch, mode: str = "mean", normalize: bool = False,
+                             per_layer: bool = False):
+        """All L+1 hidden states pooled in ONE forward (the `meanmean` / `lasttokenmean` loops of
+        beir_dense_retriever.py:243-257, 284-301).  -> fp32[B, d] layer average, or with per_layer=True
+        (fp32[L+1, B, d], fp32[B, d])."""
+        if mode not in POOL_MODES:
+            raise ValueError(f"unknown pooling mode {mode}")
+        self._check_learnt(mode, pb)
+        d, L1 = self.cfg.hidden_size, self.cfg.num_layers + 1
+        layers = torch.empty((L1, pb.B, d), dtype=torch.float32, device=self.device) if per_layer else None
+        mean = torch.empty((pb.B, d), dtype=torch.float32, device=self.device)
+        st = self.ctx.lib.sgpt_encode_layers(self.handle, _p(pb.ids), _p(pb.pos), _p(pb.seq_off), _p(pb.seq_len),
+                                             _p(pb.pad_left), pb.B, pb.T_pad, pb.max_alloc, POOL_MODES[mode],
+                                             1 if normalize else 0, _p(layers), _p(mean), _stream_ptr(self.device))
+        _lib.check(self.ctx.handle, st, "sgpt_encode_layers")
+        return (layers, mean) if per_layer else mean
 
     def plan_batches(self, lens: np.ndarray, max_sentences: Optional[int] = None) -> List[np.ndarray]:
         """Length-sorted (longest first, SentenceTransformer.py:148-149 / exact_search.py:66-71)
@@ -227,6 +274,22 @@ class SGPTModel:
             tok += int(a)
         out.append(order[start:])
         return out
+
+    def encode_ids_all_layers(self, seqs: Sequence[Sequence[int]], mode: str = "mean",
+                              pad_left: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """n token lists -> fp32[n,d]: the per-layer pooled vectors of all L+1 hidden states, averaged
+        (`meanmean` with mode='mean', `lasttokenmean` with mode='lasttoken'), one forward per batch."""
+        n = len(seqs)
+        if n == 0:
+            return torch.empty((0, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
+        lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
+        if (lens <= 0).any():
+            raise ValueError("Empty items should be cleaned prior to running")
+        res = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
+        for sel in self.plan_batches(lens):
+            pb = self.pack([seqs[i] for i in sel], None if pad_left is None else [pad_left[i] for i in sel])
+            res[torch.from_numpy(sel).to(self.device)] = self.encode_packed_layers(pb, mode)
+        return res
 
     def encode_ids(self, seqs: Sequence[Sequence[int]], mode: str = "weightedmean", normalize: bool = False,
                    layer_idx: int = -1, pad_left: Optional[Sequence[int]] = None,

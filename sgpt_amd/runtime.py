@@ -65,7 +65,9 @@ class Context:
         return a.to(device=self.device, dtype=torch.float32).contiguous()
 
     # ---- a4: stand-alone pooling ----
-    def pool(self, hidden: torch.Tensor, mask: torch.Tensor, mode: str = "weightedmean") -> torch.Tensor:
+    def pool(self, hidden: torch.Tensor, mask: torch.Tensor, mode: str = "weightedmean",
+             position_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """mode 'learntmean' takes `position_weights` (WeightedMeanPooling.py:21-39), indexed by the padded position."""
         if mode not in POOL_MODES:
             raise ValueError(f"unknown pooling mode {mode}")
         hidden = hidden.to(self.device)
@@ -76,6 +78,13 @@ class Context:
         m = mask.to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty((B, d), dtype=torch.float32, device=self.device)
         dt = SGPT_BF16 if hidden.dtype == torch.bfloat16 else SGPT_F32
+        if mode == "learntmean":
+            if position_weights is None or position_weights.numel() < S:
+                raise ValueError("learntmean needs position_weights covering the sequence length")
+            pw = position_weights.to(device=self.device, dtype=torch.float32).contiguous()
+            self._chk(self.lib.sgpt_pool_learnt(self.handle, _p(hidden), dt, _p(m), B, S, d, _p(pw), _p(out),
+                                                _stream_ptr(self.device)), "sgpt_pool_learnt")
+            return out
         self._chk(self.lib.sgpt_pool(self.handle, _p(hidden), dt, _p(m), B, S, d, POOL_MODES[mode], _p(out),
                                      _stream_ptr(self.device)), "sgpt_pool")
         return out
@@ -95,6 +104,26 @@ class Context:
         out = torch.empty(x.shape, dtype=torch.bfloat16, device=self.device)
         self._chk(self.lib.sgpt_f32_to_bf16(self.handle, _p(x), x.numel(), _p(out), _stream_ptr(self.device)),
                   "sgpt_f32_to_bf16")
+        return out
+
+    # ---- fp8 (e4m3fn, power-of-two per-row scales) weight storage: building blocks of dtype="fp8" models ----
+    def fp8_quantize_rows(self, w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        w = w.to(device=self.device, dtype=torch.float32).contiguous()
+        rows, cols = w.shape
+        codes = torch.empty((rows, cols), dtype=torch.uint8, device=self.device)
+        scale = torch.empty((rows,), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.sgpt_fp8_quantize_rows(self.handle, _p(w), rows, cols, _p(codes), _p(scale),
+                                                  _stream_ptr(self.device)), "sgpt_fp8_quantize_rows")
+        return codes, scale
+
+    def fp8_dequantize_rows(self, codes: torch.Tensor, scale: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+        codes = codes.to(device=self.device, dtype=torch.uint8).contiguous()
+        scale = scale.to(device=self.device, dtype=torch.float32).contiguous()
+        rows, cols = codes.shape
+        out = torch.empty((rows, cols), dtype=out_dtype, device=self.device)
+        self._chk(self.lib.sgpt_fp8_dequantize_rows(self.handle, _p(codes), _p(scale), rows, cols, _p(out),
+                                                    SGPT_BF16 if out_dtype == torch.bfloat16 else SGPT_F32,
+                                                    _stream_ptr(self.device)), "sgpt_fp8_dequantize_rows")
         return out
 
     def _operand(self, x: torch.Tensor, dtype) -> torch.Tensor:

@@ -36,13 +36,31 @@ class SentenceTransformerSGPT:
     (the assembly of training_nli_v2.py:85-123 / modules.json)."""
 
     def __init__(self, model: SGPTModel, tokenizer, max_seq_length: int = 300, pooling_mode: str = "weightedmean",
-                 specb: bool = False):
+                 specb: bool = False, normalize: bool = False):
         self.model = model
         self.tokenizer = tokenizer
         self.max_seq_length = max_seq_length
         self.pooling_mode = pooling_mode
         self.specb = specb
+        self.normalize = normalize          # a Normalize module in modules.json (models/Normalize.py)
         self.pipe = TextPipeline(tokenizer, max_seq_length, specb=specb)
+
+    @classmethod
+    def from_pretrained(cls, path: str, tokenizer=None, device=None, dtype: str = "bf16", specb: bool = False,
+                        **model_kw) -> "SentenceTransformerSGPT":
+        """SentenceTransformer(model_path) for an SGPT folder (SentenceTransformer._load_sbert_model, :903-936):
+        modules.json -> Transformer weights, Pooling / WeightedMeanPooling mode, optional Normalize."""
+        from .formats import read_st_folder
+        from .tokenization import load_tokenizer
+        spec = read_st_folder(path)
+        if spec.asymmetric:
+            raise ValueError("asymmetric (Asym) folders load through sgpt_amd.beir.SentenceBERTAsym")
+        model = SGPTModel.from_pretrained(spec.transformer_dirs[""], device=device, dtype=dtype, **model_kw)
+        if spec.position_weights_file:
+            model.set_position_weights(torch.load(spec.position_weights_file, map_location="cpu")["position_weights"])
+        tok = tokenizer if tokenizer is not None else load_tokenizer(spec.transformer_dirs[""])
+        return cls(model, tok, max_seq_length=spec.max_seq_length or model.cfg.max_position_embeddings,
+                   pooling_mode=spec.pooling_mode, specb=specb, normalize=spec.normalize)
 
     def get_sentence_embedding_dimension(self) -> int:
         return self.model.cfg.hidden_size
@@ -53,6 +71,7 @@ class SentenceTransformerSGPT:
                num_proc=None, is_query: bool = True):
         if convert_to_tensor:
             convert_to_numpy = False
+        normalize_embeddings = normalize_embeddings or self.normalize
         input_was_string = False
         if isinstance(sentences, str) or not hasattr(sentences, "__len__"):     # :143-146
             sentences = [sentences]

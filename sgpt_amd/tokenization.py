@@ -9,6 +9,7 @@ from typing import List, Optional, Sequence
 
 SPECB_QUE_BOS, SPECB_QUE_EOS = "[", "]"     # beir_dense_retriever.py:100-104
 SPECB_DOC_BOS, SPECB_DOC_EOS = "{", "}"
+SPECA_TOKENS = ["[SOS]", "[EOS]", "{SOS}", "{EOS}"]   # sentence_bert_asym.py:52-53: added vocabulary rows
 
 
 class SyntheticTokenizer:
@@ -22,12 +23,28 @@ class SyntheticTokenizer:
         self.vocab_size = vocab_size
         self.eos_token_id = min(50256, vocab_size - 1)
         self.pad_token_id = self.eos_token_id
+        self.added = {}
+
+    def __len__(self):
+        return self.vocab_size + len(self.added)
+
+    def add_tokens(self, tokens: Sequence[str], special_tokens: bool = False) -> int:
+        """HF add_tokens: new ids are appended after the base vocabulary (the model's embedding is resized to match,
+        sentence_bert_asym.py:36-37,54-55)."""
+        new = [t for t in tokens if t not in self.added]
+        for t in new:
+            self.added[t] = self.vocab_size + len(self.added)
+        return len(new)
 
     def tokenize(self, text: str) -> List[str]:
+        if self.added:
+            pat = "|".join(re.escape(t) for t in sorted(self.added, key=len, reverse=True))
+            return re.findall(pat + r"|\w+|[^\w\s]", text)
         return re.findall(r"\w+|[^\w\s]", text)
 
     def convert_tokens_to_ids(self, tokens: Sequence[str]) -> List[int]:
-        return [self._FIXED[t] if t in self._FIXED else zlib.crc32(t.encode()) % (self.vocab_size - 1) for t in tokens]
+        return [self.added[t] if t in self.added else self._FIXED[t] if t in self._FIXED
+                else zlib.crc32(t.encode()) % (self.vocab_size - 1) for t in tokens]
 
     def encode(self, text: str, add_special_tokens: bool = False) -> List[int]:
         return self.convert_tokens_to_ids(self.tokenize(text))
@@ -43,22 +60,40 @@ def load_tokenizer(model_name_or_path: str):
 
 
 class TextPipeline:
-    """text -> truncated id list (+ brackets)."""
+    """text -> truncated id list (+ brackets).
 
-    def __init__(self, tokenizer, max_token_len: int, specb: bool = False):
+    specb: `[`..`]` around queries, `{`..`}` around documents, existing vocabulary ids.
+    speca: `[SOS]`..`[EOS]` / `{SOS}`..`{EOS}`, ids ADDED to the vocabulary (the checkpoint carries the extra
+           embedding rows); only on the sentence-transformers path, as in the reference (beir_dense_retriever.py:415-416).
+    st_path: the marker travels inside the text through the tokenizer call of Transformer.tokenize_bos_eos
+           (Transformer.py:131-135, `max_length = max_seq_length - 2` INCLUDING the marker), so the content is cut to
+           max_seq_length - 3 tokens; the raw-HF path (beir_dense_retriever.py:134-136,172-191) cuts the content to
+           max_seq_length - 2 and adds both brackets afterwards."""
+
+    def __init__(self, tokenizer, max_token_len: int, specb: bool = False, speca: bool = False, st_path: bool = False):
+        if speca and specb:
+            raise ValueError("speca and specb are mutually exclusive")
         self.tok = tokenizer
-        self.specb = specb
-        self.max_token_len = max_token_len - 2 if specb else max_token_len   # :134-136
+        self.specb, self.speca, self.st_path = specb, speca, st_path
+        bracketed = specb or speca
+        self.max_token_len = max_token_len - (3 if st_path else 2) if bracketed else max_token_len   # :134-136
         if specb:
             self.bos_q = list(tokenizer.encode(SPECB_QUE_BOS))
             self.eos_q = list(tokenizer.encode(SPECB_QUE_EOS))
             self.bos_d = list(tokenizer.encode(SPECB_DOC_BOS))
             self.eos_d = list(tokenizer.encode(SPECB_DOC_EOS))
+        if speca:
+            tokenizer.add_tokens(SPECA_TOKENS, special_tokens=True)             # sentence_bert_asym.py:52-54
+            enc = [list(tokenizer.encode(t, add_special_tokens=False)) for t in SPECA_TOKENS]
+            if any(len(e) != 1 for e in enc):
+                raise ValueError("speca markers must be single added tokens of the tokenizer")
+            self.bos_q, self.eos_q, self.bos_d, self.eos_d = enc
         self.docs_truncated = 0
         self.toks_truncated = 0
 
     def ids(self, txt: str, is_query: bool) -> List[int]:
-        txt = txt.replace("\n", " ")                                           # :169
+        if not self.st_path:                                                    # the ST path hands the text to the
+            txt = txt.replace("\n", " ")                                       # tokenizer untouched; raw path: :169
         tokens = self.tok.convert_tokens_to_ids(self.tok.tokenize(txt))        # :172-173
         n = len(tokens)
         if n > self.max_token_len:
@@ -67,7 +102,7 @@ class TextPipeline:
         elif n == 0:
             raise ValueError("Empty items should be cleaned prior to running")  # :180-181
         tokens = list(tokens[: self.max_token_len])
-        if self.specb:                                                          # :186-191
+        if self.specb or self.speca:                                            # :186-191
             tokens = (self.bos_q + tokens + self.eos_q) if is_query else (self.bos_d + tokens + self.eos_d)
         return tokens
 

@@ -12,11 +12,12 @@ from .tokenization import TextPipeline
 
 class CustomEmbedder:
     """useb_dense_retriever.py:76-309: encode(sentences, ...) -> list of lists; same pooling
-    methods as the BEIR embedder (learntmean needs trained position weights: not built)."""
+    methods as the BEIR embedder plus `learntmean` (:253-270: trained position weights, read from
+    <model>/1_WeightedMeanPooling by SGPTModel.from_pretrained or set with model.set_position_weights)."""
 
     def __init__(self, model: SGPTModel, tokenizer, layeridx: int = -1, method: str = "weightedmean",
                  specb: bool = False, maxseqlen: Optional[int] = None):
-        if method not in SINGLE_LAYER_METHODS and method not in ALL_LAYER_METHODS:
+        if method not in SINGLE_LAYER_METHODS and method not in ALL_LAYER_METHODS and method != "learntmean":
             raise ValueError(f"unknown method {method}")
         self.model = model
         self.layeridx = layeridx
@@ -26,13 +27,9 @@ class CustomEmbedder:
     def encode_device(self, sentences: List[str], is_query: bool = True) -> torch.Tensor:
         seqs = self.pipe.batch(sentences, is_query)
         L = self.model.cfg.num_layers
-        if self.method in SINGLE_LAYER_METHODS:
+        if self.method in SINGLE_LAYER_METHODS or self.method == "learntmean":
             return self.model.encode_ids(seqs, mode=self.method, layer_idx=self.layeridx)
-        acc = None
-        for li in range(L + 1):
-            e = self.model.encode_ids(seqs, mode=ALL_LAYER_METHODS[self.method], layer_idx=li)
-            acc = e if acc is None else acc.add_(e)
-        return acc.div_(L + 1)
+        return self.model.encode_ids_all_layers(seqs, mode=ALL_LAYER_METHODS[self.method])
 
     def encode(self, sentences, **kwargs):
         return self.encode_device(list(sentences)).cpu().tolist()

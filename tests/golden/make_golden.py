@@ -200,6 +200,10 @@ def main():
     ES = load_ref_exact_search(U)
 
     # ---------------- encoder + pooling ----------------
+    if os.environ.get("GOLDEN_ONLY_EXTRAS"):
+        _extras_cases()
+        _tokenize_cases()
+        return
     if only_j:
         _gptj_cases(Pooling)
         return
@@ -226,6 +230,8 @@ def main():
     encoder_case("cfg3_125m_specb_s300", O.SGPT_125M, seed=2, seqs=docs + qs, Pooling=Pooling)
 
     _gptj_cases(Pooling)
+    _extras_cases()
+    _tokenize_cases()
 
     # ---------------- scoring / top-k (reference util.py + exact_search.py) ----------------
     _scoring_cases(U, ES)
@@ -248,6 +254,137 @@ def _gptj_cases(Pooling):
     tinyb2 = dict(vocab_size=211, hidden_size=256, n_layer=2, n_head=2)    # head_dim 128 (the 7b1 head size)
     encoder_case("tiny_bloom_right", tinyb2, seed=42, seqs=rand_seqs(rng, 5, 2, 40, 211), std=0.04,
                  store_hidden=True, Pooling=Pooling, arch="bloom")
+
+
+def _extras_cases():
+    """learntmean pooling vs the reference's WeightedMeanPooling.py + the raw USEB formula;
+    fp8 e4m3fn weight codes vs torch.float8_e4m3fn."""
+    WMP = load_file_module("ref_wmp", f"{ST}/models/WeightedMeanPooling.py")
+    rng = np.random.default_rng(900)
+    B, S, d = 6, 37, 64
+    h = rng.standard_normal((B, S, d)).astype(np.float32)
+    lens = [37, 1, 20, 5, 36, 11]
+    mask = np.zeros((B, S), dtype=np.int64)
+    for b, n in enumerate(lens):                          # rows 0-2 right padded, rows 3-5 left padded
+        if b < 3:
+            mask[b, :n] = 1
+        else:
+            mask[b, S - n:] = 1
+    pw = rng.uniform(0.05, 3.0, size=48).astype(np.float32)
+    mod = WMP.WeightedMeanPooling(d, num_positions=47, position_weights=torch.nn.Parameter(torch.from_numpy(pw.copy())))
+    ref = mod({"token_embeddings": torch.from_numpy(h), "attention_mask": torch.from_numpy(mask)})["sentence_embedding"].numpy()
+    # raw path, useb_dense_retriever.py:253-270 (no clamp)
+    ime = torch.from_numpy(mask).unsqueeze(-1).expand(B, S, d).float()
+    wts = torch.from_numpy(pw)[:S].unsqueeze(0).unsqueeze(-1).expand(B, S, d)
+    raw = (torch.sum(torch.from_numpy(h) * ime * wts, dim=1) / torch.sum(ime * wts, dim=1)).numpy()
+    got = O.pool(h, mask, "learntmean", position_weights=pw)
+    check("learntmean WeightedMeanPooling.py", got, ref, 2e-6)
+    check("learntmean raw USEB path", got, raw, 2e-6)
+
+    # fp8: rows with magnitudes over 11 orders, an all-zero row, a row whose amax sits on a scale boundary
+    w = (rng.standard_normal((48, 128)) * np.exp(rng.uniform(-12, 4, size=(48, 1)))).astype(np.float32)
+    w[5] = 0.0
+    w[6, 0] = np.float32(448 * 2.0 ** -4); w[6, 1:] *= 1e-3
+    w[7, 0] = np.float32(449 * 2.0 ** -4)
+    w[8, ::3] *= 1e-4                                         # subnormal codes
+    codes, scale = O.fp8_quantize_rows(w)
+    x = torch.from_numpy(w / scale[:, None])
+    assert float(x.abs().max()) <= 448.0
+    t8 = x.to(torch.float8_e4m3fn)
+    assert np.array_equal(t8.view(torch.uint8).numpy(), codes), "oracle e4m3fn encode != torch.float8_e4m3fn"
+    deq = O.fp8_dequantize_rows(codes, scale)
+    assert np.array_equal(deq, t8.float().numpy() * scale[:, None]), "oracle e4m3fn decode != torch"
+    assert np.array_equal(torch.from_numpy(deq).to(torch.bfloat16).float().numpy(), deq), "dequantised weight not exact in bf16"
+    assert np.all(np.log2(scale) == np.round(np.log2(scale)))
+    print(f"  oracle-vs-torch fp8 e4m3fn: {codes.size} codes bit-identical; scales 2^{int(np.log2(scale.min()))}..2^{int(np.log2(scale.max()))}")
+    np.savez_compressed(os.path.join(HERE, "extras.npz"), lm_hidden=h, lm_mask=mask.astype(np.int32), lm_pw=pw, lm_ref=ref,
+                        fp8_w=w, fp8_codes=codes, fp8_scale=scale, fp8_deq=deq)
+    print("wrote extras.npz")
+
+
+TOK_WORDS = ["[UNK]", "[", "]", "{", "}", "what", "is", "the", "capital", "of", "france", "paris", "?", "and", "more",
+             "words", "here", "a", "b", "c", "d", "e", "city", "river", "seine", "."]
+
+
+def make_word_tokenizer(words=TOK_WORDS):
+    """A real HF fast tokenizer built offline (no vocabulary files exist in this image): word-level over whitespace /
+    punctuation.  Shared with tests/test_host_logic.py through the fixture's stored word list."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    tk = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok = PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="[UNK]", eos_token="[UNK]")
+    tok.pad_token = tok.eos_token
+    return tok
+
+
+def _tokenize_cases():
+    """Token ids of the reference's two tokenisation legs on the same texts:
+    (1) sentence-transformers path: Transformer.tokenize -> tokenize_bos_eos (Transformer.py:90-153) configured as
+        SentenceBERTBOSEOS.__init__ does for specb and speca (sentence_bert_asym.py:33-63), fed the "[SOS]" / "{SOS}"
+        prefixed texts of its encode_queries / encode_corpus (:67-79);
+    (2) raw-HF path: the per-text loop of CustomEmbedder.embed (beir_dense_retriever.py:167-191), restated call for call
+        with the same tokenizer methods."""
+    import json
+    TR = load_file_module("ref_transformer", f"{ST}/models/Transformer.py")
+    queries = ["what is the capital of france ?", "paris", "a b c d e a b c d e a b c d e", "what is\nthe river"]
+    docs = [{"title": "paris", "text": "paris is the capital of france . the river seine is here ."},
+            {"title": "", "text": "a b c"}, {"title": "more words", "text": "and more words here and more words here and more"}]
+    doc_texts = [(d["title"] + " " + d["text"]).strip() for d in docs]
+    out = {"words": TOK_WORDS, "queries": queries, "docs": docs, "cases": []}
+    for mode in ("specb", "speca"):
+        for max_seq_length in (8, 12, 300):
+            tok = make_word_tokenizer()
+            me = types.SimpleNamespace(tokenizer=tok, max_seq_length=max_seq_length, do_lower_case=False, replace_bos=False,
+                                       bos_spec_token_q=None, eos_spec_token_q=None, bos_spec_token_d=None,
+                                       eos_spec_token_d=None, bos_spec_token_q_rep=None, bos_spec_token_d_rep=None)
+            enc1 = lambda t: tok.encode(t, add_special_tokens=False)[0]  # noqa: E731
+            if mode == "specb":                                   # sentence_bert_asym.py:33-50
+                tok.add_tokens(["[SOS]", "{SOS}"], special_tokens=True)
+                me.bos_spec_token_q, me.bos_spec_token_d = enc1("[SOS]"), enc1("{SOS}")
+                me.bos_spec_token_q_rep, me.eos_spec_token_q = enc1("["), enc1("]")
+                me.bos_spec_token_d_rep, me.eos_spec_token_d = enc1("{"), enc1("}")
+                me.replace_bos = True
+            else:                                                 # :52-63
+                tok.add_tokens(["[SOS]", "[EOS]", "{SOS}", "{EOS}"], special_tokens=True)
+                me.bos_spec_token_q, me.eos_spec_token_q = enc1("[SOS]"), enc1("[EOS]")
+                me.bos_spec_token_d, me.eos_spec_token_d = enc1("{SOS}"), enc1("{EOS}")
+            me.tokenize_bos_eos = types.MethodType(TR.Transformer.tokenize_bos_eos, me)
+
+            def run(texts):
+                feats = TR.Transformer.tokenize(me, texts)
+                ids, mask = feats["input_ids"].tolist(), feats["attention_mask"].tolist()
+                return [[t for t, m in zip(r, mr) if m] for r, mr in zip(ids, mask)]
+            q_ids = run(["[SOS]" + q for q in queries])
+            d_ids = run([("{SOS}" + d["title"] + " " + d["text"]).strip() if "title" in d else "{SOS}" + d["text"].strip()
+                         for d in docs])
+            out["cases"].append({"path": "st", "mode": mode, "max_seq_length": max_seq_length, "vocab_len": len(tok),
+                                 "query_ids": q_ids, "doc_ids": d_ids})
+    # raw-HF path, specb on/off
+    for specb in (False, True):
+        for maxseqlen in (8, 300):
+            tok = make_word_tokenizer()
+            max_token_len = maxseqlen - 2 if specb else maxseqlen              # :134-136
+            bos_q, eos_q = tok.encode("["), tok.encode("]")                      # :146-150 (add_special_tokens default)
+            bos_d, eos_d = tok.encode("{"), tok.encode("}")
+
+            def raw(texts, is_query):
+                res = []
+                for txt in texts:
+                    txt = txt.replace("\n", " ")
+                    tokens = tok.convert_tokens_to_ids(tok.tokenize(txt))
+                    # :182-184 prepare_for_model(add_special_tokens=True): GPT tokenizers add none (Transformer.py:119-120),
+                    # and transformers 5.x dropped the method from fast tokenizers -> identity
+                    ids = list(tokens[:max_token_len])
+                    if specb:
+                        ids = (bos_q + ids + eos_q) if is_query else (bos_d + ids + eos_d)
+                    res.append(list(ids))
+                return res
+            out["cases"].append({"path": "raw", "mode": "specb" if specb else "none", "max_seq_length": maxseqlen,
+                                 "vocab_len": len(tok), "query_ids": raw(queries, True), "doc_ids": raw(doc_texts, False)})
+    with open(os.path.join(HERE, "tokenize.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"wrote tokenize.json ({len(out['cases'])} cases from the reference's Transformer.tokenize / embed loop)")
 
 
 def _scoring_cases(U, ES):

@@ -181,3 +181,75 @@ def test_encode_larger_gptneo_shapes_vs_oracle(name, shape):
     err, cosmin = maxabs(gb, want), float(row_cos(gb, want).min())
     print(f"SGPT-{name} width bf16: max|emb - oracle| = {err:.3e}, min row cosine = {cosmin:.6f}")
     assert np.isfinite(gb).all() and err < TOL_BF16_ABS and cosmin > TOL_BF16_COS
+
+
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_gptj_left", "tiny_bloom_left"])
+def test_encode_layers_single_pass(tag):
+    """sgpt_encode_layers: every entry of all_hidden_states pooled on the way through ONE forward, and their
+    average = the meanmean / lasttokenmean methods (beir_dense_retriever.py:243-257, 284-301)."""
+    fx, cfg_kw, seqs, pad_left, ids, mask = load_case(tag)
+    seed, std = int(fx["seed"]), float(fx["std"])
+    m = build_model(cfg_kw, seed, std, "fp32")
+    from helpers import oracle_cfg_weights
+    cfg, w = oracle_cfg_weights(cfg_kw, seed, std)
+    _, hs = O.forward_any(w, cfg, ids, mask, output_hidden_states=True)
+    pb = m.pack(seqs, pad_left)
+    for mode, method in (("mean", "meanmean"), ("lasttoken", "lasttokenmean")):
+        layers, mean = m.encode_packed_layers(pb, mode, per_layer=True)
+        layers, mean = layers.cpu().numpy(), mean.cpu().numpy()
+        assert layers.shape == (cfg.num_layers + 1, len(seqs), cfg.hidden_size)
+        for li, h in enumerate(hs):
+            assert maxabs(layers[li], O.pool(h, mask, mode)) < TOL_FP32, (tag, mode, li)
+        assert maxabs(mean, O.pool_layers(hs, mask, method)) < TOL_FP32
+        # mean-only call (scratch per-layer buffer inside the library) and the batched host entry agree
+        assert maxabs(m.encode_packed_layers(pb, mode).cpu().numpy(), mean) == 0.0
+        assert maxabs(m.encode_ids_all_layers(seqs, mode=mode, pad_left=pad_left).cpu().numpy(), mean) < 1e-6
+    # weightedmean over layers too (not a reference method, same machinery): entry L equals sgpt_encode
+    layers, _ = m.encode_packed_layers(pb, "weightedmean", per_layer=True)
+    assert maxabs(layers[-1].cpu().numpy(), fx["emb_weightedmean"]) < TOL_FP32
+
+
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left"])
+def test_encode_learntmean(tag):
+    """method 'learntmean' (useb_dense_retriever.py:253-270; WeightedMeanPooling.py:21-39): trained per-position
+    weights indexed by the padded position, fused into the final-LN pooling kernel."""
+    fx, cfg_kw, seqs, pad_left, ids, mask = load_case(tag)
+    seed, std = int(fx["seed"]), float(fx["std"])
+    m = build_model(cfg_kw, seed, std, "fp32")
+    pw = np.random.default_rng(5).uniform(0.05, 3.0, size=ids.shape[1] + 3).astype(np.float32)
+    with pytest.raises(ValueError):
+        m.position_weights = None
+        m.encode_ids(seqs, mode="learntmean", pad_left=pad_left)
+    m.set_position_weights(pw)
+    got = m.encode_ids(seqs, mode="learntmean", pad_left=pad_left).cpu().numpy()
+    want = O.pool(fx["last_hidden"], mask, "learntmean", position_weights=pw)
+    assert maxabs(got, want) < TOL_FP32
+    # an all-ones table is plain mean pooling
+    m.set_position_weights(np.ones(ids.shape[1], dtype=np.float32))
+    assert maxabs(m.encode_ids(seqs, mode="learntmean", pad_left=pad_left).cpu().numpy(), fx["emb_mean"]) < TOL_FP32
+    # a table shorter than the longest padded sequence is rejected, not over-read
+    m.set_position_weights(np.ones(ids.shape[1] - 1, dtype=np.float32))
+    with pytest.raises(ValueError):
+        m.encode_ids(seqs, mode="learntmean", pad_left=pad_left)
+
+
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_gptj_right", "tiny_bloom_left", "cfg1_125m_32x64"])
+def test_encode_fp8_weights(tag):
+    """dtype='fp8' (SURVEY 8d cfg5): block matmul weights stored as e4m3fn codes + power-of-two per-row scales,
+    de-quantised exactly to bf16 per block.  The oracle runs fp32 on the same de-quantised weights (8c), so what
+    is left is the bf16 activation rounding: the bf16 budget applies."""
+    fx, cfg_kw, seqs, pad_left, ids, mask = load_case(tag)
+    seed, std = int(fx["seed"]), float(fx["std"])
+    from helpers import oracle_cfg_weights
+    cfg, w = oracle_cfg_weights(cfg_kw, seed, std)
+    wq = O.fp8_roundtrip_weights(w)
+    assert any(not np.array_equal(wq[k], w[k]) for k in w)          # quantisation is live
+    last = O.forward_any(wq, cfg, ids, mask)
+    want = O.pool(last, mask, "weightedmean")
+    m8 = build_model(cfg_kw, seed, std, "fp8")
+    got = m8.encode_ids(seqs, mode="weightedmean", pad_left=pad_left).cpu().numpy()
+    err, cosmin = maxabs(got, want), float(row_cos(got, want).min())
+    print(f"{tag} fp8 weights: max|emb - oracle(dequantised)| = {err:.3e}, min row cosine = {cosmin:.6f}")
+    assert np.isfinite(got).all() and err < TOL_BF16_ABS and cosmin > TOL_BF16_COS
+    # and it is NOT the un-quantised model: the fp8 rounding of the weights is visible against the fp32 golden
+    assert maxabs(got, fx["emb_weightedmean"]) > maxabs(got, want)

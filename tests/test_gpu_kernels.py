@@ -1,5 +1,7 @@
 """-m gpu: each HIP kernel through the C ABI against the numpy oracle (small sizes) and against a
 plain PyTorch fp32 reference of the same op on the GPU (large sizes)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -213,3 +215,40 @@ def test_score_topk_running_merge_equals_single_pass(ctx):
     assert torch.equal(run[0], v1) and torch.equal(run[1], i1)
     v3, i3, n3 = ctx.score_topk(q, c[:5].contiguous(), k)           # fewer docs than k
     assert n3 == 5 and (i3[:, 5:] == -1).all() and torch.isinf(v3[:, 5:]).all()
+
+
+def test_pool_learntmean_golden(ctx):
+    """sgpt_pool_learnt vs the reference's WeightedMeanPooling.py output (tests/golden/extras.npz)."""
+    fx = np.load(os.path.join(GOLDEN, "extras.npz"))
+    h, mask, pw = torch.from_numpy(fx["lm_hidden"]), torch.from_numpy(fx["lm_mask"]), torch.from_numpy(fx["lm_pw"])
+    got = ctx.pool(h, mask, "learntmean", position_weights=pw).cpu().numpy()
+    assert np.max(np.abs(got - fx["lm_ref"])) < 1e-5
+    assert np.max(np.abs(got - O.pool(fx["lm_hidden"], fx["lm_mask"], "learntmean", position_weights=fx["lm_pw"]))) < 1e-5
+    with pytest.raises(ValueError):
+        ctx.pool(h, mask, "learntmean", position_weights=pw[:10])
+
+
+def test_fp8_weight_codes_bit_exact(ctx):
+    """sgpt_fp8_quantize_rows / dequantize_rows: e4m3fn codes, power-of-two scales and de-quantised values are
+    bit-identical to the oracle (itself bit-identical to torch.float8_e4m3fn, see make_golden.py)."""
+    fx = np.load(os.path.join(GOLDEN, "extras.npz"))
+    codes, scale = ctx.fp8_quantize_rows(torch.from_numpy(fx["fp8_w"]))
+    assert np.array_equal(scale.cpu().numpy(), fx["fp8_scale"])
+    assert np.array_equal(codes.cpu().numpy(), fx["fp8_codes"])
+    deq = ctx.fp8_dequantize_rows(codes, scale).cpu().numpy()
+    assert np.array_equal(deq, fx["fp8_deq"])
+    deq16 = ctx.fp8_dequantize_rows(codes, scale, out_dtype=torch.bfloat16).float().cpu().numpy()
+    assert np.array_equal(deq16, fx["fp8_deq"])                     # exact in bf16
+    # all 256 codes decode like the oracle (NaN codes 0x7f / 0xff aside)
+    allc = torch.arange(256, dtype=torch.uint8).reshape(1, 256)
+    one = torch.ones(1)
+    got = ctx.fp8_dequantize_rows(allc, one).cpu().numpy()[0]
+    want = O.fp8_e4m3fn_decode(np.arange(256, dtype=np.uint8))
+    keep = (np.arange(256) & 0x7F) != 0x7F
+    assert np.array_equal(got[keep], want[keep])
+    # a larger random matrix against the oracle
+    rng = np.random.default_rng(3)
+    w = (rng.standard_normal((300, 512)) * np.exp(rng.uniform(-6, 2, size=(300, 1)))).astype(np.float32)
+    c2, s2 = ctx.fp8_quantize_rows(torch.from_numpy(w))
+    oc, os_ = O.fp8_quantize_rows(w)
+    assert np.array_equal(c2.cpu().numpy(), oc) and np.array_equal(s2.cpu().numpy(), os_)

@@ -204,3 +204,74 @@ def test_encode_multi_process_matches_single_process():
     finally:
         stop_multi_process_pool(pool)
     assert emb.shape == single.shape and np.abs(emb - single).max() < 1e-3
+
+
+def _hf_cfg(cfg_kw):
+    return {"model_type": "gpt_neo", "vocab_size": cfg_kw["vocab_size"],
+            "max_position_embeddings": cfg_kw["max_position_embeddings"], "hidden_size": cfg_kw["hidden_size"],
+            "num_layers": cfg_kw["num_layers"], "num_heads": cfg_kw["num_heads"], "window_size": cfg_kw["window_size"],
+            "attention_types": [[["global", "local"], cfg_kw["num_layers"] // 2]]}
+
+
+def test_st_folder_from_pretrained_roundtrip(tmp_path):
+    """A sentence-transformers folder (modules.json, 1_Pooling / 1_WeightedMeanPooling, 2_Normalize;
+    SentenceTransformer.py:389-430, 903-936) written to disk and loaded back runs the same pipeline."""
+    from sgpt_amd import formats
+    from sgpt_amd.st import SentenceTransformerSGPT
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    fx, cfg_kw, seqs, pad_left, ids, mask = load_case("tiny_right")
+    cfg = O.NeoConfig(**cfg_kw)
+    w = O.synth_weights(cfg, seed=int(fx["seed"]), std=float(fx["std"]))
+    tok = SyntheticTokenizer(cfg_kw["vocab_size"])
+    texts = ["alpha beta gamma", "delta", "what is the capital of france ? paris of course"]
+    tseqs = [tok.convert_tokens_to_ids(tok.tokenize(t)) for t in texts]
+    p = str(tmp_path / "st_wm")
+    formats.write_st_folder(p, _hf_cfg(cfg_kw), {"transformer." + k: v for k, v in w.items()}, pooling_mode="weightedmean",
+                            max_seq_length=40, normalize=True)
+    st = SentenceTransformerSGPT.from_pretrained(p, tokenizer=tok, device="cuda:0", dtype="fp32")
+    assert (st.pooling_mode, st.normalize, st.max_seq_length) == ("weightedmean", True, 40)
+    got = st.encode(texts)
+    assert maxabs(got, O.encode(w, cfg, tseqs, normalize_embeddings=True)) < 1e-3
+    # learntmean folder
+    pw = np.random.default_rng(1).uniform(0.1, 2.0, size=41).astype(np.float32)
+    p2 = str(tmp_path / "st_learnt")
+    formats.write_st_folder(p2, _hf_cfg(cfg_kw), w, pooling_mode="learntmean", max_seq_length=40, position_weights=pw)
+    st2 = SentenceTransformerSGPT.from_pretrained(p2, tokenizer=tok, device="cuda:0", dtype="fp32")
+    assert st2.pooling_mode == "learntmean" and not st2.normalize
+    tids, tmask = O.pad_batch(tseqs, pad_id=cfg.vocab_size - 1)
+    last = O.forward_any(w, cfg, tids, tmask)
+    assert maxabs(st2.encode(texts), O.pool(last, tmask, "learntmean", position_weights=pw)) < 1e-3
+
+
+def test_asym_two_tower_and_speca_adapters():
+    """SentenceBERTAsym: queries through the QRY tower, documents through the DOCPOS tower (sentence_bert_asym.py:8-19).
+    SentenceBERTBOSEOS(speca=True): four ADDED vocabulary rows as markers (:52-63), marker-inclusive truncation."""
+    from sgpt_amd import SGPTConfig, SGPTModel
+    from sgpt_amd.beir import SentenceBERTAsym, SentenceBERTBOSEOS
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    kw = dict(vocab_size=215, max_position_embeddings=96, hidden_size=128, num_layers=2, num_heads=2, window_size=8)
+    cfg = O.NeoConfig(**kw)
+    wq, wd = O.synth_weights(cfg, seed=71, std=0.08), O.synth_weights(cfg, seed=72, std=0.08)
+    mq = SGPTModel(SGPTConfig(**kw), wq, device="cuda:0", dtype="fp32")
+    md = SGPTModel(SGPTConfig(**kw), wd, device="cuda:0", dtype="fp32")
+    tok = SyntheticTokenizer(211)
+    queries = ["what is the capital of france ?", "river"]
+    docs = [{"title": "paris", "text": "paris is the capital of france"}, {"title": "", "text": "the seine is a river"}]
+    dtexts = [(d["title"] + " " + d["text"]).strip() for d in docs]
+    ids = lambda t: tok.convert_tokens_to_ids(tok.tokenize(t))  # noqa: E731
+    asym = SentenceBERTAsym(query_model=mq, doc_model=md, tokenizer=tok, max_seq_length=64)
+    assert maxabs(asym.encode_queries(queries), O.encode(wq, cfg, [ids(q) for q in queries])) < 1e-3
+    assert maxabs(asym.encode_corpus(docs), O.encode(wd, cfg, [ids(t) for t in dtexts])) < 1e-3
+    assert maxabs(asym.encode_corpus(docs), O.encode(wq, cfg, [ids(t) for t in dtexts])) > 1e-2   # really the other tower
+    # speca: ids 211..214 are the added [SOS] [EOS] {SOS} {EOS}; max_seq_length 8 -> 5 content tokens + 2 markers
+    sa = SentenceBERTBOSEOS(speca=True, model=mq, tokenizer=SyntheticTokenizer(211), max_seq_length=8)
+    want_q = [[211] + ids(q)[:5] + [212] for q in queries]
+    want_d = [[213] + ids(t)[:5] + [214] for t in dtexts]
+    assert sa.pipe.batch(queries, True) == want_q and sa.pipe.batch(dtexts, False) == want_d
+    assert maxabs(sa.encode_queries(queries), O.encode(wq, cfg, want_q)) < 1e-3
+    assert maxabs(sa.encode_corpus(docs), O.encode(wq, cfg, want_d)) < 1e-3
+    with pytest.raises(ValueError):     # a checkpoint without the four extra embedding rows
+        small = SGPTModel(SGPTConfig(**dict(kw, vocab_size=211)), O.synth_weights(O.NeoConfig(**dict(kw, vocab_size=211)), seed=1),
+                          device="cuda:0", dtype="fp32")
+        SentenceBERTBOSEOS(speca=True, model=small, tokenizer=SyntheticTokenizer(211), max_seq_length=8)
+    mq.close(); md.close()

@@ -23,7 +23,8 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in sgpt_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
     assert set(_lib.SIGNATURES) == declared
-    assert lib.sgpt_abi_version() == 1
+    m = re.search(r"#define SGPT_ABI_VERSION (\d+)", hdr)
+    assert lib.sgpt_abi_version() == int(m.group(1)) == _lib.SGPT_ABI_VERSION
     # struct layout mirrors the header
     assert ctypes.sizeof(_lib.ModelDesc) == 64 and ctypes.sizeof(_lib.TensorView) == 24
 
@@ -109,3 +110,118 @@ def test_shard_sizes_match_reference_formula():
     for n, w in [(10, 4), (7, 8), (1000, 8), (5, 1)]:
         ref = [n // w + (1 if r < n % w else 0) for r in range(w)]
         assert shard_sizes(n, w) == ref and sum(ref) == n
+
+
+def _word_tokenizer(words):
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    tk = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok = PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="[UNK]", eos_token="[UNK]")
+    tok.pad_token = tok.eos_token
+    return tok
+
+
+def test_text_pipeline_matches_reference_tokenisation_golden():
+    """tests/golden/tokenize.json holds the ids produced by the reference's own Transformer.tokenize /
+    tokenize_bos_eos (sentence-transformers path, specb and speca) and by the raw-HF per-text loop, on a real
+    HF fast tokenizer built offline; TextPipeline must reproduce them id for id, including the marker-inclusive
+    truncation of the ST path (content cut to max_seq_length - 3) vs max_seq_length - 2 on the raw path."""
+    import json
+    from sgpt_amd.tokenization import TextPipeline
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "tokenize.json")))
+    doc_texts = [(d["title"] + " " + d["text"]).strip() for d in fx["docs"]]
+    assert len(fx["cases"]) == 10
+    for case in fx["cases"]:
+        tok = _word_tokenizer(fx["words"])
+        pipe = TextPipeline(tok, case["max_seq_length"], specb=case["mode"] == "specb", speca=case["mode"] == "speca",
+                            st_path=case["path"] == "st")
+        strip = (lambda t: str(t).strip()) if case["path"] == "st" else (lambda t: t)
+        assert pipe.batch([strip(q) for q in fx["queries"]], True) == case["query_ids"], case
+        assert pipe.batch([strip(t) for t in doc_texts], False) == case["doc_ids"], case
+        if case["mode"] == "speca":
+            assert len(tok) == case["vocab_len"]        # four added rows, same ids as the reference's add_tokens
+
+
+def test_st_folder_formats_roundtrip(tmp_path):
+    """modules.json / 1_Pooling / 1_WeightedMeanPooling / 2_Normalize / Asym layouts (SentenceTransformer.py:389-430,
+    903-936; Pooling.py:172-185; Asym.py:62-122) read back into the pipeline description."""
+    import json
+    import torch
+    from sgpt_amd import formats
+    cfg = {"model_type": "gpt_neo", "hidden_size": 128, "num_layers": 1, "num_heads": 2, "vocab_size": 50,
+           "max_position_embeddings": 32, "attention_types": [[["global"], 1]]}
+    sd = {"wte.weight": np.zeros((50, 128), np.float32)}
+    p1 = str(tmp_path / "sym")
+    formats.write_st_folder(p1, cfg, sd, pooling_mode="weightedmean", max_seq_length=75, normalize=True)
+    mods = json.load(open(os.path.join(p1, "modules.json")))
+    assert [m["type"].rsplit(".", 1)[-1] for m in mods] == ["Transformer", "Pooling", "Normalize"]
+    assert mods[0]["path"] == "" and mods[1]["path"] == "1_Pooling"
+    pc = json.load(open(os.path.join(p1, "1_Pooling", "config.json")))
+    assert pc["pooling_mode_weightedmean_tokens"] is True and pc["pooling_mode_mean_tokens"] is False
+    spec = formats.read_st_folder(p1)
+    assert spec.transformer_dirs == {"": os.path.join(p1, "")} and not spec.asymmetric
+    assert (spec.max_seq_length, spec.pooling_mode, spec.normalize) == (75, "weightedmean", True)
+    # the reference's own Pooling.load accepts the written config (loaded from its file when the tree is present)
+    ref_pool = "/root/" + "reference/biencoder/nli_msmarco/sentence-transformers/sentence_transformers/models/Pooling.py"
+    if os.path.exists(ref_pool):
+        import importlib.util
+        sp = importlib.util.spec_from_file_location("ref_pooling_fmt", ref_pool)
+        mod = importlib.util.module_from_spec(sp)
+        sp.loader.exec_module(mod)
+        rp = mod.Pooling.load(os.path.join(p1, "1_Pooling"))
+        assert rp.pooling_mode_weightedmean_tokens and rp.get_sentence_embedding_dimension() == 128
+    # learntmean
+    p2 = str(tmp_path / "learnt")
+    pw = np.linspace(0.5, 2.0, 33).astype(np.float32)
+    formats.write_st_folder(p2, cfg, sd, pooling_mode="learntmean", position_weights=pw)
+    spec = formats.read_st_folder(p2)
+    assert spec.pooling_mode == "learntmean" and not spec.normalize
+    assert np.array_equal(torch.load(spec.position_weights_file)["position_weights"].numpy(), pw)
+    # plain HF folder -> mean pooling (the reference's fallback)
+    p3 = str(tmp_path / "hf")
+    os.makedirs(p3)
+    json.dump(cfg, open(os.path.join(p3, "config.json"), "w"))
+    assert formats.read_st_folder(p3).pooling_mode == "mean"
+    # Asym: [Asym{QRY:[T1], DOCPOS:[T2], DOCNEG:[T2]}, Pooling]
+    p4 = str(tmp_path / "asym")
+    os.makedirs(os.path.join(p4, "0_Asym", "111_Transformer"))
+    os.makedirs(os.path.join(p4, "0_Asym", "222_Transformer"))
+    os.makedirs(os.path.join(p4, "1_Pooling"))
+    for t in ("111_Transformer", "222_Transformer"):
+        json.dump({"max_seq_length": 300, "do_lower_case": False},
+                  open(os.path.join(p4, "0_Asym", t, "sentence_bert_config.json"), "w"))
+    json.dump({"types": {"111_Transformer": "sentence_transformers.models.Transformer",
+                         "222_Transformer": "sentence_transformers.models.Transformer"},
+               "structure": {"QRY": ["111_Transformer"], "DOCPOS": ["222_Transformer"], "DOCNEG": ["222_Transformer"]},
+               "parameters": {"allow_empty_key": False}}, open(os.path.join(p4, "0_Asym", "config.json"), "w"))
+    json.dump(dict(pc, pooling_mode_weightedmean_tokens=False, pooling_mode_mean_tokens=True),
+              open(os.path.join(p4, "1_Pooling", "config.json"), "w"))
+    json.dump([{"idx": 0, "name": "0", "path": "0_Asym", "type": "sentence_transformers.models.Asym"},
+               {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}],
+              open(os.path.join(p4, "modules.json"), "w"))
+    spec = formats.read_st_folder(p4)
+    assert spec.asymmetric and spec.pooling_mode == "mean" and spec.max_seq_length == 300
+    assert spec.transformer_dirs["QRY"].endswith("111_Transformer") and spec.transformer_dirs["DOCPOS"].endswith("222_Transformer")
+    # unsupported pieces fail loudly
+    json.dump(dict(pc, pooling_mode_cls_token=True), open(os.path.join(p4, "1_Pooling", "config.json"), "w"))
+    with pytest.raises(NotImplementedError):
+        formats.read_st_folder(p4)
+
+
+def test_embedding_cache_and_results_json_formats(tmp_path):
+    """`{id: ndarray}` pickle (beir_dense_retriever.py:306-348) and results JSON (:439-441)."""
+    import json
+    import pickle
+    from sgpt_amd import formats
+    ids = ["d3", "d1", "d2"]
+    emb = np.arange(12, dtype=np.float32).reshape(3, 4)
+    path = str(tmp_path / "embeddings" / "m" / "weightedmean" / "scifact_corpus0.pickle")
+    formats.save_embedding_cache(path, ids, emb)
+    raw = pickle.load(open(path, "rb"))
+    assert set(raw) == set(ids) and np.array_equal(raw["d1"], emb[1])
+    assert np.array_equal(formats.load_embedding_cache(path, ["d1", "d3"]), emb[[1, 0]])
+    res = {"q1": {"d1": np.float32(0.5), "d2": 0.25}, "q2": {}}
+    rp = str(tmp_path / "results.json")
+    formats.save_results_json(rp, res)
+    assert json.load(open(rp)) == {"q1": {"d1": 0.5, "d2": 0.25}, "q2": {}} == formats.load_results_json(rp)

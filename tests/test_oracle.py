@@ -11,6 +11,8 @@ import pytest
 
 from oracle import sgpt_oracle as O
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 
 def load_case(golden_dir, tag):
     fx = np.load(os.path.join(golden_dir, f"{tag}.npz"))
@@ -139,3 +141,27 @@ def test_bf16_round_matches_torch():
     a = np.random.default_rng(4).standard_normal(10000).astype(np.float32) * 3
     want = torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
     assert (O.bf16_round(a) == want).all()
+
+
+def test_extras_golden_learntmean_and_fp8():
+    """learntmean pooling vs the reference's WeightedMeanPooling.py output; fp8 e4m3fn codes / power-of-two
+    scales vs the fixture that make_golden.py checked bit for bit against torch.float8_e4m3fn."""
+    fx = np.load(os.path.join(GOLDEN, "extras.npz"))
+    got = O.pool(fx["lm_hidden"], fx["lm_mask"], "learntmean", position_weights=fx["lm_pw"])
+    assert np.max(np.abs(got - fx["lm_ref"])) < 2e-6
+    codes, scale = O.fp8_quantize_rows(fx["fp8_w"])
+    assert np.array_equal(codes, fx["fp8_codes"]) and np.array_equal(scale, fx["fp8_scale"])
+    assert np.array_equal(O.fp8_dequantize_rows(codes, scale), fx["fp8_deq"])
+    # properties: scales are powers of two, |w/scale| <= 448, relative error of normal codes <= 2^-4
+    assert np.all(np.log2(scale) == np.round(np.log2(scale)))
+    x = fx["fp8_w"] / scale[:, None]
+    assert np.abs(x).max() <= 448.0
+    deq = fx["fp8_deq"] / scale[:, None]
+    normal = np.abs(x) >= 2.0 ** -6
+    assert np.all(np.abs(deq - x)[normal] <= np.abs(x)[normal] * 2.0 ** -4)
+    assert np.all(np.abs(deq - x)[~normal] <= 2.0 ** -10)
+    # torch cross-check when float8 is available in this torch build
+    import torch
+    if hasattr(torch, "float8_e4m3fn"):
+        t8 = torch.from_numpy(x.astype(np.float32)).to(torch.float8_e4m3fn)
+        assert np.array_equal(t8.view(torch.uint8).numpy(), codes)
