@@ -6,5 +6,5 @@ keep the reference's encode_queries / encode_corpus / encode / semb_fn / cos_sim
 surface (biencoder/beir, biencoder/useb of Muennighoff/sgpt)."""
 __version__ = "0.1.0"
 
-from .model import SGPTConfig, SGPTModel, synthetic_weights  # noqa: F401
+from .model import EncodeGraph, SGPTConfig, SGPTModel, synthetic_weights  # noqa: F401
 from .runtime import Context, get_context  # noqa: F401

@@ -317,6 +317,45 @@ class SGPTModel:
         return [hid[off[i]: off[i] + len(s)] for i, s in enumerate(seqs)]
 
 
+class EncodeGraph:
+    """One sgpt_encode call captured as a hipGraph (via torch.cuda.CUDAGraph: every kernel and memset of the call
+    is issued on the capturing stream, nothing else) and replayed for new token ids of the same packed-layout
+    bucket (B, T_pad, max_alloc).  A 12-block forward is ~110 launches; for the small batches of the USEB
+    evaluators (21-32 sentences, useb/evaluators/base.py:33) and for query encoding the launches cost more than
+    the kernels, so replay removes most of the latency.  The workspace is sized by a warm-up call before capture
+    (hipMalloc is not capturable)."""
+
+    def __init__(self, model: "SGPTModel", seqs: Sequence[Sequence[int]], mode: str = "weightedmean",
+                 normalize: bool = False, layer_idx: int = -1, pad_left: Optional[Sequence[int]] = None):
+        self.model, self.mode, self.normalize, self.layer_idx = model, mode, normalize, layer_idx
+        self.pb = model.pack(seqs, pad_left)
+        self.out = torch.empty((self.pb.B, model.cfg.hidden_size), dtype=torch.float32, device=model.device)
+        model.encode_packed(self.pb, mode, normalize, layer_idx, out=self.out)       # warm-up outside capture
+        torch.cuda.synchronize(model.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            model.encode_packed(self.pb, mode, normalize, layer_idx, out=self.out)
+
+    @property
+    def bucket(self):
+        return (self.pb.B, self.pb.T_pad, self.pb.max_alloc)
+
+    def replay(self, seqs: Optional[Sequence[Sequence[int]]] = None,
+               pad_left: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """Re-run on new sentences whose packed layout falls in the same bucket (None: same inputs again).
+        The returned tensor is the graph's static output buffer."""
+        if seqs is not None:
+            h = pack_host(seqs, pad_left)
+            if (h["B"], h["T_pad"], h["max_alloc"]) != self.bucket:
+                raise ValueError(f"packed layout {(h['B'], h['T_pad'], h['max_alloc'])} is not this graph's bucket {self.bucket}")
+            for name in ("ids", "pos", "seq_off", "seq_len", "pad_left"):
+                getattr(self.pb, name).copy_(torch.from_numpy(h[name]), non_blocking=False)
+            self.pb.max_pos = h["max_pos"]
+            self.model._check_learnt(self.mode, self.pb)
+        self.graph.replay()
+        return self.out
+
+
 def alibi_slopes(n_head: int) -> np.ndarray:
     """HF build_alibi_tensor slopes (HF:bloom/modeling_bloom.py:62-79) in float32."""
     import math

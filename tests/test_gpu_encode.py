@@ -253,3 +253,38 @@ def test_encode_fp8_weights(tag):
     assert np.isfinite(got).all() and err < TOL_BF16_ABS and cosmin > TOL_BF16_COS
     # and it is NOT the un-quantised model: the fp8 rounding of the weights is visible against the fp32 golden
     assert maxabs(got, fx["emb_weightedmean"]) > maxabs(got, want)
+
+
+def test_encode_graph_capture_and_replay():
+    """sgpt_encode is stream-pure (no hidden sync / allocation once the workspace is sized), so one call captures
+    into a hipGraph; replay on new ids of the same layout bucket equals the eager call bit for bit."""
+    import time
+    from sgpt_amd import EncodeGraph
+    fx, cfg_kw, *_ = load_case("cfg1_125m_32x64")
+    m = build_model(cfg_kw, int(fx["seed"]), float(fx["std"]), "bf16")
+    rng = np.random.default_rng(11)
+    lens = rng.integers(4, 33, size=32)
+    mk = lambda: [rng.integers(0, 50256, size=int(n)).tolist() for n in lens]  # noqa: E731
+    a, b = mk(), mk()
+    g = EncodeGraph(m, a, normalize=True)
+    assert np.array_equal(g.replay().cpu().numpy(), m.encode_packed(m.pack(a), normalize=True).cpu().numpy())
+    got_b = g.replay(b).cpu().numpy()
+    assert np.array_equal(got_b, m.encode_packed(m.pack(b), normalize=True).cpu().numpy())
+    assert not np.array_equal(got_b, m.encode_packed(m.pack(a), normalize=True).cpu().numpy())
+    with pytest.raises(ValueError):
+        g.replay(a[:-1])
+    # latency of a 32-query batch: eager launches vs graph replay (reported, not asserted beyond sanity)
+    pb = m.pack(a)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(20):
+        m.encode_packed(pb, normalize=True)
+    torch.cuda.synchronize()
+    eager = (time.perf_counter() - t) / 20
+    t = time.perf_counter()
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    graph = (time.perf_counter() - t) / 20
+    print(f"32-query batch (<=32 tokens): eager {eager * 1e3:.3f} ms, hipGraph replay {graph * 1e3:.3f} ms")
+    assert graph < eager * 1.5

@@ -225,3 +225,15 @@ def test_embedding_cache_and_results_json_formats(tmp_path):
     rp = str(tmp_path / "results.json")
     formats.save_results_json(rp, res)
     assert json.load(open(rp)) == {"q1": {"d1": 0.5, "d2": 0.25}, "q2": {}} == formats.load_results_json(rp)
+
+
+def test_library_is_not_older_than_its_sources():
+    """A stale in-tree .so (sources edited, `python -m sgpt_amd.build` not re-run) would travel to the GPU box and
+    run old kernels behind a new ctypes prototype; catch it on the CPU."""
+    from sgpt_amd import _lib
+    so = os.path.getmtime(_lib.LIB_PATH)
+    srcs = [os.path.join(ROOT, "include", "sgpt_hip.h")]
+    csrc = os.path.join(ROOT, "sgpt_amd", "csrc")
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    stale = [os.path.basename(s) for s in srcs if os.path.getmtime(s) > so + 1.0]
+    assert not stale, f"libsgpt_hip.so is older than {stale}: run `python -m sgpt_amd.build`"
