@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsgpt_hip.so")
+LIB_PATH = os.environ.get("SGPT_HIP_LIB") or os.path.join(HERE, "lib", "libsgpt_hip.so")   # env: A/B builds of the same ABI
 
 SGPT_F32, SGPT_BF16, SGPT_FP8W = 0, 1, 2
 SGPT_ABI_VERSION = 2

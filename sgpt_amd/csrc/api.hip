@@ -567,53 +567,116 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     else { chunk = chunk / 256 * 256; if (chunk < 256) chunk = 256; }
     if (chunk > 131072) chunk = 131072;
     if (chunk > N) chunk = (long)align_up((size_t)N, 4);
-    const size_t sc_bytes = align_up((size_t)nq * chunk * 4, 256);
-    const size_t tv_bytes = align_up((size_t)nq * k * 4, 256), ti_bytes = align_up((size_t)nq * k * 8, 256);
     // bf16 fast path: the 256x256 LDS-DMA GEMM needs the query rows padded to a multiple of 256 (zero rows,
     // never stored) and d % 64 == 0; chunks that are multiples of 256 documents take it, the ragged tail and
     // fp32 go through the 128^2 kernel.
     const bool fast = dtype == SGPT_BF16 && d % 64 == 0;
     const int nq_pad = (nq + 255) / 256 * 256;
+    // Threshold-filtered chunks (after the first): see EPI_SCORE_FILTER.  Candidate capacity per query and chunk;
+    // the doubling schedule below keeps the expected count at ~k.
+    static const bool classic_only = getenv("SGPT_SCORE_CLASSIC") != nullptr;
+    const int cap = k <= 64 ? 256 : 4 * k;
+    const bool filt = fast && !classic_only && k <= 256 && chunk % 256 == 0 && N >= 2 * chunk;
+
+    const size_t sc_bytes = align_up((size_t)nq * chunk * 4, 256);
+    const size_t tv_bytes = align_up((size_t)nq * k * 4, 256), ti_bytes = align_up((size_t)nq * k * 8, 256);
     const size_t qp_bytes = fast ? align_up((size_t)nq_pad * d * 2, 256) : 0;
-    st = ensure(c, &c->ws2, &c->ws2_bytes, sc_bytes + 2 * (tv_bytes + ti_bytes) + qp_bytes);
+    const size_t cv_bytes = filt ? align_up((size_t)nq * cap * 4, 256) : 0, ci_bytes = filt ? align_up((size_t)nq * cap * 8, 256) : 0;
+    const size_t cc_bytes = filt ? align_up((size_t)(nq_pad + 1) * 4, 256) : 0;        // counters + overflow flag
+    st = ensure(c, &c->ws2, &c->ws2_bytes,
+                sc_bytes + 3 * (tv_bytes + ti_bytes) + qp_bytes + cv_bytes + ci_bytes + cc_bytes);
     if (st != SGPT_OK) return st;
     char* base = (char*)c->ws2;
-    void* qpad = nullptr;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p_ = base + off; off += bytes; return p_; };
+    float* sc = (float*)take(sc_bytes);
+    float* tv[2]; int64_t* ti[2];
+    tv[0] = (float*)take(tv_bytes); tv[1] = (float*)take(tv_bytes);
+    ti[0] = (int64_t*)take(ti_bytes); ti[1] = (int64_t*)take(ti_bytes);
+    float* sav_v = (float*)take(tv_bytes); int64_t* sav_i = (int64_t*)take(ti_bytes);   // incoming running best (fallback)
+    void* qpad = fast ? take(qp_bytes) : nullptr;
+    float* cand_v = filt ? (float*)take(cv_bytes) : nullptr;
+    long long* cand_i = filt ? (long long*)take(ci_bytes) : nullptr;
+    int* cand_cnt = filt ? (int*)take(cc_bytes) : nullptr;
+    int* flag = filt ? cand_cnt + nq_pad : nullptr;
     if (fast) {
-        qpad = base + sc_bytes + 2 * (tv_bytes + ti_bytes);
         HIPC(c, hipMemsetAsync(qpad, 0, (size_t)nq_pad * d * 2, s));
         HIPC(c, hipMemcpyAsync(qpad, q, (size_t)nq * d * 2, hipMemcpyDeviceToDevice, s));
     }
-    float* sc = (float*)base;
-    float* tv[2] = {(float*)(base + sc_bytes), (float*)(base + sc_bytes + tv_bytes)};
-    int64_t* ti[2] = {(int64_t*)(base + sc_bytes + 2 * tv_bytes), (int64_t*)(base + sc_bytes + 2 * tv_bytes + ti_bytes)};
     const size_t esz = dtype == SGPT_BF16 ? 2 : 4;
 
-    const float* pv = n_run > 0 ? run_val : nullptr;
-    const int64_t* pi = n_run > 0 ? run_idx : nullptr;
-    int have = n_run;
-    int cur = 0;
-    for (long c0 = 0; c0 < N; c0 += chunk) {
-        const long nc = (N - c0) < chunk ? (N - c0) : chunk;
-        GemmArgs g{};
-        g.A = q; g.lda = d; g.M = nq; g.m_valid = nq; g.K = d;
-        g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = d; g.N = (int)nc;
-        g.out = sc; g.ldo = chunk;
-        if (fast && nc % 256 == 0) { g.A = qpad; g.M = nq_pad; }
-        gemm(c, dtype, EPI_SCORE, SGPT_F32, g, s);
-        const bool last = c0 + nc >= N;
-        float* ov = last ? run_val : tv[cur];
-        int64_t* oi = last ? run_idx : ti[cur];
-        if (last && pv == run_val) {  // in/out alias on a single-chunk call: stage through the ping-pong buffer
-            launch_topk_select(sc, chunk, nc, idx_base + c0, pv, pi, have, k, nq, k, 0, nullptr, tv[cur], ti[cur], s);
-            HIPC(c, hipMemcpyAsync(run_val, tv[cur], (size_t)nq * k * 4, hipMemcpyDeviceToDevice, s));
-            HIPC(c, hipMemcpyAsync(run_idx, ti[cur], (size_t)nq * k * 8, hipMemcpyDeviceToDevice, s));
-        } else {
-            launch_topk_select(sc, chunk, nc, idx_base + c0, pv, pi, have, k, nq, k, 0, nullptr, ov, oi, s);
+    // Materialise-and-select over documents [lo, hi): the reference's chunk loop (exact_search.py:96-132).
+    // (pv, pi, have) = running best going in; the last chunk writes (fin_v, fin_i), earlier ones ping-pong.
+    auto classic = [&](long lo, long hi, const float* pv, const int64_t* pi, int have, float* fin_v, int64_t* fin_i,
+                       const int* pred) -> sgpt_status {
+        int cur = (pv == tv[0]) ? 1 : 0;
+        for (long c0 = lo; c0 < hi; c0 += chunk) {
+            const long nc = (hi - c0) < chunk ? (hi - c0) : chunk;
+            GemmArgs g{};
+            g.A = q; g.lda = d; g.M = nq; g.m_valid = nq; g.K = d; g.pred = pred;
+            g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = d; g.N = (int)nc;
+            g.out = sc; g.ldo = chunk;
+            if (fast && nc % 256 == 0) { g.A = qpad; g.M = nq_pad; }
+            gemm(c, dtype, EPI_SCORE, SGPT_F32, g, s);
+            const bool last = c0 + nc >= hi;
+            if (last && pv == fin_v) {  // in/out alias on a single-chunk call: stage through the ping-pong buffer
+                launch_topk_select(sc, chunk, nc, idx_base + c0, pv, pi, have, k, nq, k, 0, nullptr, tv[cur], ti[cur], s, pred);
+                HIPC(c, hipMemcpyAsync(fin_v, tv[cur], (size_t)nq * k * 4, hipMemcpyDeviceToDevice, s));
+                HIPC(c, hipMemcpyAsync(fin_i, ti[cur], (size_t)nq * k * 8, hipMemcpyDeviceToDevice, s));
+            } else {
+                launch_topk_select(sc, chunk, nc, idx_base + c0, pv, pi, have, k, nq, k, 0, nullptr,
+                                   last ? fin_v : tv[cur], last ? fin_i : ti[cur], s, pred);
+            }
+            pv = tv[cur]; pi = ti[cur];
+            have = k;  // unused tail slots carry idx = -1 and are ignored by the next merge
+            cur ^= 1;
         }
-        pv = tv[cur]; pi = ti[cur];
-        have = k;  // unused tail slots carry idx = -1 and are ignored by the next merge
-        cur ^= 1;
+        return SGPT_OK;
+    };
+
+    const float* pv0 = n_run > 0 ? run_val : nullptr;
+    const int64_t* pi0 = n_run > 0 ? run_idx : nullptr;
+    if (!filt) {
+        st = classic(0, N, pv0, pi0, n_run, run_val, run_idx, nullptr);
+        if (st != SGPT_OK) return st;
+    } else {
+        HIPC(c, hipMemsetAsync(cand_cnt, 0, (size_t)(nq_pad + 1) * 4, s));
+        if (n_run > 0) {
+            HIPC(c, hipMemcpyAsync(sav_v, run_val, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, s));
+            HIPC(c, hipMemcpyAsync(sav_i, run_idx, (size_t)nq * k * 8, hipMemcpyDeviceToDevice, s));
+        }
+        // first chunk: materialise + select -> the initial thresholds
+        st = classic(0, chunk, pv0, pi0, n_run, tv[0], ti[0], nullptr);
+        if (st != SGPT_OK) return st;
+        int cur = 0;
+        long seen = chunk;
+        const long n256 = N / 256 * 256;
+        // doubling schedule: a filtered chunk is as long as everything seen before it, so a query expects ~k
+        // survivors per chunk (k * len / seen) whatever N is; 1 M documents = 1 + 5 launches instead of 31
+        while (n256 - seen >= 256) {
+            long len = seen < (n256 - seen) ? seen : (n256 - seen);
+            if (len > (1L << 19)) len = 1L << 19;
+            if (len >= unit) len = len / unit * unit;
+            GemmArgs g{};
+            g.A = qpad; g.lda = d; g.M = nq_pad; g.m_valid = nq; g.K = d;
+            g.W = (const char*)corpus + (size_t)seen * d * esz; g.ldw = d; g.N = (int)len;
+            g.thr = tv[cur] + (k - 1); g.thr_ld = k;
+            g.cand_val = cand_v; g.cand_idx = cand_i; g.cand_cnt = cand_cnt; g.cand_cap = cap; g.idx_base = idx_base + seen;
+            gemm(c, dtype, EPI_SCORE_FILTER, SGPT_F32, g, s);
+            seen += len;
+            const bool fin = seen >= N;
+            launch_cand_merge(tv[cur], ti[cur], cand_v, (const int64_t*)cand_i, cand_cnt, cap, nq, k,
+                              fin ? run_val : tv[cur ^ 1], fin ? run_idx : ti[cur ^ 1], flag, s);
+            cur ^= 1;
+        }
+        if (seen < N) {   // ragged tail (< 256 documents): materialise + select
+            st = classic(seen, N, tv[cur], ti[cur], k, run_val, run_idx, nullptr);
+            if (st != SGPT_OK) return st;
+        }
+        // A candidate list overflowed (adversarial document order / mass of equal scores): recompute the whole call
+        // the classic way.  Sync-free: the launches are predicated on the device flag and exit at once when it is 0.
+        st = classic(0, N, n_run > 0 ? sav_v : nullptr, n_run > 0 ? sav_i : nullptr, n_run, run_val, run_idx, flag);
+        if (st != SGPT_OK) return st;
     }
     if (n_out) { const int64_t tot = (int64_t)n_run + N; *n_out = (int32_t)(tot < k ? tot : k); }
     HIPC(c, hipGetLastError());

@@ -86,6 +86,8 @@ enum GemmEpi {
     EPI_SCORE = 3,        // out[m][n] = isnan(acc) ? -1 : acc        (fp32)
     EPI_VT = 4,           // out[n][m] = acc  (transposed store, bf16: V^T for the attention B-operand)
     EPI_NONE = 5,         // micro-benchmark only: no stores (accumulators kept live)
+    EPI_SCORE_FILTER = 6, // scorer, chunks after the first: append (score, index) of every score > thr[m] to a
+                          // per-query candidate list instead of materialising the score tile
 };
 
 struct GemmArgs {
@@ -98,6 +100,15 @@ struct GemmArgs {
     long lda, ldw, ldo;
     int m_valid;        // rows >= m_valid are computed from clamped reads and not stored
     int skew;           // persistent kernel: start-up stagger (shader cycles per phase), see gemm256_kernel
+    const int* pred;    // device flag or null: the kernel exits at once when *pred == 0 (sync-free fallback launches)
+    // EPI_SCORE_FILTER
+    const float* thr;   // per-query threshold thr[m * thr_ld] (the running k-th best score; -inf = keep all)
+    long thr_ld;
+    float* cand_val;    // [M][cand_cap]
+    long long* cand_idx;
+    int* cand_cnt;      // [M] appended so far (may exceed cand_cap: overflow, detected by the merge)
+    int cand_cap;
+    long idx_base;      // global index of W row 0
     long long* dbg;     // optional s_memtime stamps of workgroup 0 / wave 0 (micro-benchmark diagnostics)
 };
 
@@ -147,4 +158,10 @@ void launch_fill_rand(void* p, long n, int dtype, unsigned seed, float scale, hi
 // top-k: one block per query row over a virtual row = [scores(n) | prev(n_prev)]
 void launch_topk_select(const float* scores, long ld, long n, long idx_base, const float* prev_val,
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
-                        const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s);
+                        const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s,
+                        const int* pred = nullptr);
+// k best of {running top-k} U {candidate list of the filtered score GEMM}; resets cnt[q], raises *overflow when a
+// list was longer than cap (candidates were dropped: the caller's predicated fallback recomputes)
+void launch_cand_merge(const float* run_val, const int64_t* run_idx, const float* cand_val, const int64_t* cand_idx,
+                       int* cand_cnt, int cap, int nq, int k, float* out_val, int64_t* out_idx, int* overflow,
+                       hipStream_t s);

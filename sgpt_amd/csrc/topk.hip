@@ -103,7 +103,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                                                                 const float* prev_val, const int64_t* prev_idx,
                                                                 int n_prev, long prev_ld, int k, int nan_to_m1,
                                                                 const int64_t* exclude_idx, float* out_val,
-                                                                int64_t* out_idx) {
+                                                                int64_t* out_idx, const int* pred) {
+    if (pred && *pred == 0) return;   // predicated fallback launch that is not needed
     __shared__ unsigned hist[256];
     __shared__ unsigned sh_prefix, sh_krem, sh_cnt;
     __shared__ float s_val[TK_SORT_MAX];
@@ -287,11 +288,61 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
     }
 }
 
+// Merge of the filtered scorer: one workgroup per query sorts {running top-k} U {<= cap appended candidates}
+// (k + cap <= TK_SORT_MAX) and keeps the k best (descending score, ties by ascending index).  The candidate list
+// holds every score of the chunk that beat the running k-th best, so the result equals the full-row selection.
+__global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __restrict__ run_val,
+                                                               const int64_t* __restrict__ run_idx,
+                                                               const float* __restrict__ cand_val,
+                                                               const int64_t* __restrict__ cand_idx,
+                                                               int* __restrict__ cand_cnt, int cap, int k,
+                                                               float* __restrict__ out_val, int64_t* __restrict__ out_idx,
+                                                               int* __restrict__ overflow) {
+    __shared__ float s_val[TK_SORT_MAX];
+    __shared__ int64_t s_idx[TK_SORT_MAX];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const int raw = cand_cnt[q];
+    const int cnt = raw < cap ? raw : cap;
+    const int n = k + cnt;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = t; i < np2; i += TK_THREADS) {
+        float v = -INFINITY;
+        int64_t id = 0x7fffffffffffffffLL;
+        if (i < k) {
+            const int64_t r = run_idx[(long)q * k + i];
+            if (r >= 0) { v = run_val[(long)q * k + i]; id = r; }
+        } else if (i < n) {
+            v = cand_val[(long)q * cap + (i - k)];
+            id = cand_idx[(long)q * cap + (i - k)];
+        }
+        s_val[i] = v; s_idx[i] = id;
+    }
+    __syncthreads();
+    if (t == 0) {
+        cand_cnt[q] = 0;                       // ready for the next filtered chunk
+        if (raw > cap) atomicOr(overflow, 1);
+    }
+    bitonic_desc<true>(s_val, s_idx, np2, t);
+    for (int i = t; i < k; i += TK_THREADS) {
+        const bool ok = s_idx[i] != 0x7fffffffffffffffLL;
+        out_val[(long)q * k + i] = ok ? s_val[i] : -INFINITY;
+        out_idx[(long)q * k + i] = ok ? s_idx[i] : -1;
+    }
+}
+
 }  // namespace
 
 void launch_topk_select(const float* scores, long ld, long n, long idx_base, const float* prev_val,
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
-                        const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s) {
+                        const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s, const int* pred) {
     hipLaunchKernelGGL(topk_select_kernel, dim3(nq), dim3(TK_THREADS), 0, s, scores, ld, n, idx_base, prev_val,
-                       prev_idx, n_prev, prev_ld, k, nan_to_m1, exclude_idx, out_val, out_idx);
+                       prev_idx, n_prev, prev_ld, k, nan_to_m1, exclude_idx, out_val, out_idx, pred);
+}
+
+void launch_cand_merge(const float* run_val, const int64_t* run_idx, const float* cand_val, const int64_t* cand_idx,
+                       int* cand_cnt, int cap, int nq, int k, float* out_val, int64_t* out_idx, int* overflow,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(cand_merge_kernel, dim3(nq), dim3(TK_THREADS), 0, s, run_val, run_idx, cand_val, cand_idx, cand_cnt,
+                       cap, k, out_val, out_idx, overflow);
 }

@@ -252,3 +252,59 @@ def test_fp8_weight_codes_bit_exact(ctx):
     c2, s2 = ctx.fp8_quantize_rows(torch.from_numpy(w))
     oc, os_ = O.fp8_quantize_rows(w)
     assert np.array_equal(c2.cpu().numpy(), oc) and np.array_equal(s2.cpu().numpy(), os_)
+
+
+def _sliced_classic(ctx, q, c, k, step, idx_base=0, run=None):
+    """The same search as a sequence of calls short enough to take the materialise-and-select path."""
+    for s in range(0, c.shape[0], step):
+        v, i, n = ctx.score_topk(q, c[s:s + step], k, idx_base=idx_base + s, run=run)
+        run = (v, i, n)
+    return run
+
+
+@pytest.mark.parametrize("case", ["random", "ascending", "ties", "running"])
+def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case):
+    """Long corpora take the threshold-filtered path (EPI_SCORE_FILTER: chunks after the first only append scores
+    above the running k-th best; doubling chunk schedule; predicated classic fallback on candidate overflow).
+    It must return exactly what the materialise-and-select chunk loop returns -- same values, same indices,
+    same tie order -- including when every document beats the threshold (ascending scores -> overflow -> the
+    sync-free fallback) and under massive ties."""
+    nq, d, k = 2048, 64, 10                      # nq = 2048 -> 16 384-document chunks; N >= 32 768 takes the filtered path
+    g = torch.Generator(device="cpu").manual_seed(3)
+    q = torch.randn(nq, d, generator=g)
+    if case == "random":
+        N = 100_003                              # ragged tail: 100 003 = 390 * 256 + 163
+        c = torch.randn(N, d, generator=g)
+    elif case == "ascending":
+        N = 65_536                               # every query's score grows with the document index
+        u = torch.randn(d, generator=g)
+        q = q.abs() * u.sign()                   # <q, u> > 0 for all queries
+        c = (torch.arange(1, N + 1).float() / N)[:, None] * u[None, :]
+    elif case == "ties":
+        N = 81_920
+        c = torch.randn(1024, d, generator=g).repeat(N // 1024, 1)    # every score occurs 80 times
+    else:
+        N = 70_000
+        c = torch.randn(N, d, generator=g)
+    q, c = q.cuda().to(torch.bfloat16), c.cuda().to(torch.bfloat16)
+    run = None
+    base = 0
+    if case == "running":                        # incoming running best + global index base
+        prev = torch.randn(5000, d, generator=torch.Generator(device="cpu").manual_seed(9)).cuda().to(torch.bfloat16) * 1.5
+        v0, i0, n0 = ctx.score_topk(q, prev, k, idx_base=0)
+        run, base = (v0.clone(), i0.clone(), n0), 5000
+        val, idx, n = ctx.score_topk(q, c, k, idx_base=base, run=(v0, i0, n0))
+    else:
+        val, idx, n = ctx.score_topk(q, c, k, idx_base=base)
+    wv, wi, wn = _sliced_classic(ctx, q, c, k, 16384, idx_base=base, run=run)
+    assert n == wn == k
+    assert torch.equal(val, wv) and torch.equal(idx, wi), case
+    # and both agree with a plain fp32 product of the bf16 operands
+    full = q.float() @ c.float().T
+    tv, tidx = torch.topk(full, k, dim=1)
+    if case != "running":
+        assert torch.max(torch.abs(val - tv)).item() < 1e-3 * max(1.0, float(tv.abs().max()))
+    if case == "ties":
+        assert (idx < 1024).all()                # lowest index among equal scores
+    if case == "ascending":              # (bf16 rounds neighbouring documents to equal scores: ties ascend by index)
+        assert (idx >= N - 64).all() and (val[:, :-1] >= val[:, 1:]).all()
