@@ -578,7 +578,14 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     const int cap = k <= 64 ? 256 : 4 * k;
     const bool filt = fast && !classic_only && k <= 256 && chunk % 256 == 0 && N >= 2 * chunk;
 
-    const size_t sc_bytes = align_up((size_t)nq * chunk * 4, 256);
+    // the (rare) fallback recomputes with fewer, larger launches: its score tile may leave the Infinity Cache
+    long fchunk = chunk;
+    if (filt) {
+        fchunk = (long)(((size_t)1 << 30) / ((size_t)nq * 4)) / 256 * 256;
+        if (fchunk > 131072) fchunk = 131072;
+        if (fchunk < chunk) fchunk = chunk;
+    }
+    const size_t sc_bytes = align_up((size_t)nq * fchunk * 4, 256);
     const size_t tv_bytes = align_up((size_t)nq * k * 4, 256), ti_bytes = align_up((size_t)nq * k * 8, 256);
     const size_t qp_bytes = fast ? align_up((size_t)nq_pad * d * 2, 256) : 0;
     const size_t cv_bytes = filt ? align_up((size_t)nq * cap * 4, 256) : 0, ci_bytes = filt ? align_up((size_t)nq * cap * 8, 256) : 0;
@@ -608,7 +615,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // Materialise-and-select over documents [lo, hi): the reference's chunk loop (exact_search.py:96-132).
     // (pv, pi, have) = running best going in; the last chunk writes (fin_v, fin_i), earlier ones ping-pong.
     auto classic = [&](long lo, long hi, const float* pv, const int64_t* pi, int have, float* fin_v, int64_t* fin_i,
-                       const int* pred) -> sgpt_status {
+                       const int* pred, long chunk) -> sgpt_status {
         int cur = (pv == tv[0]) ? 1 : 0;
         for (long c0 = lo; c0 < hi; c0 += chunk) {
             const long nc = (hi - c0) < chunk ? (hi - c0) : chunk;
@@ -637,7 +644,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     const float* pv0 = n_run > 0 ? run_val : nullptr;
     const int64_t* pi0 = n_run > 0 ? run_idx : nullptr;
     if (!filt) {
-        st = classic(0, N, pv0, pi0, n_run, run_val, run_idx, nullptr);
+        st = classic(0, N, pv0, pi0, n_run, run_val, run_idx, nullptr, chunk);
         if (st != SGPT_OK) return st;
     } else {
         HIPC(c, hipMemsetAsync(cand_cnt, 0, (size_t)(nq_pad + 1) * 4, s));
@@ -646,7 +653,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             HIPC(c, hipMemcpyAsync(sav_i, run_idx, (size_t)nq * k * 8, hipMemcpyDeviceToDevice, s));
         }
         // first chunk: materialise + select -> the initial thresholds
-        st = classic(0, chunk, pv0, pi0, n_run, tv[0], ti[0], nullptr);
+        st = classic(0, chunk, pv0, pi0, n_run, tv[0], ti[0], nullptr, chunk);
         if (st != SGPT_OK) return st;
         int cur = 0;
         long seen = chunk;
@@ -670,12 +677,14 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             cur ^= 1;
         }
         if (seen < N) {   // ragged tail (< 256 documents): materialise + select
-            st = classic(seen, N, tv[cur], ti[cur], k, run_val, run_idx, nullptr);
+            st = classic(seen, N, tv[cur], ti[cur], k, run_val, run_idx, nullptr, chunk);
             if (st != SGPT_OK) return st;
         }
         // A candidate list overflowed (adversarial document order / mass of equal scores): recompute the whole call
         // the classic way.  Sync-free: the launches are predicated on the device flag and exit at once when it is 0.
-        st = classic(0, N, n_run > 0 ? sav_v : nullptr, n_run > 0 ? sav_i : nullptr, n_run, run_val, run_idx, flag);
+        static const bool no_fallback = getenv("SGPT_SCORE_NOFALLBACK") != nullptr;   // timing experiments ONLY: unsafe
+        if (!no_fallback)
+            st = classic(0, N, n_run > 0 ? sav_v : nullptr, n_run > 0 ? sav_i : nullptr, n_run, run_val, run_idx, flag, fchunk);
         if (st != SGPT_OK) return st;
     }
     if (n_out) { const int64_t tot = (int64_t)n_run + N; *n_out = (int32_t)(tot < k ? tot : k); }

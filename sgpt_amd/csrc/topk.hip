@@ -106,7 +106,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                                                                 int64_t* out_idx, const int* pred) {
     if (pred && *pred == 0) return;   // predicated fallback launch that is not needed
     __shared__ unsigned hist[256];
-    __shared__ unsigned sh_prefix, sh_krem, sh_cnt;
+    __shared__ unsigned sh_prefix, sh_krem, sh_cnt, sh_cnt2;
     __shared__ float s_val[TK_SORT_MAX];
     __shared__ int64_t s_idx[TK_SORT_MAX];
 
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                 }
                 sh_prefix = prefix | ((unsigned)dsel << shift);
                 sh_krem = krem - acc;
+                sh_cnt2 = hist[dsel];            // after the last pass: number of elements equal to the threshold
             }
             __syncthreads();
             prefix = sh_prefix;
@@ -249,25 +250,55 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                 if (in_lds) { s_val[slot] = v; s_idx[slot] = r.idx(i); } else { ov[slot] = v; oi[slot] = r.idx(i); }
             }
         }
-        // ---- ties at the threshold: the krem lowest positions, in parallel ----
-        // thread t owns the contiguous range [t*per, (t+1)*per): count, exclusive scan, emit
-        const long per = (total + TK_THREADS - 1) / TK_THREADS;
-        const long lo = (long)t * per, hi = (lo + per) < total ? (lo + per) : total;
-        unsigned mine = 0;
-        for (long i = lo; i < hi; ++i) mine += f2key(r.val(i)) == thr ? 1u : 0u;
-        hist[t] = mine;
+        // ---- ties at the threshold: the krem LOWEST INDICES among the equal scores ----
+        // (Position in the virtual row is not index order: the previous-best leg sits behind the chunk leg but
+        // holds earlier documents, and a cross-rank merge has no order at all.)  If the row holds exactly krem
+        // such elements they are all taken; otherwise a second radix select, over the 64-bit index of the tied
+        // elements (8 passes of 8 bits, ascending), finds the krem-th smallest index.  Indices are unique in a row.
         __syncthreads();
-        if (t == 0) {
-            unsigned run = 0;
-            for (int q = 0; q < TK_THREADS; ++q) { const unsigned c = hist[q]; hist[q] = run; run += c; }
+        const unsigned n_tie = sh_cnt2;
+        unsigned long long cutoff = ~0ull;
+        if (n_tie > krem) {
+            unsigned long long pfx = 0;
+            unsigned rem = krem;
+            for (int pass = 0; pass < 8; ++pass) {
+                const int shift = 56 - 8 * pass;
+                hist[t] = 0;
+                __syncthreads();
+                const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+                for (long i0 = 0; i0 < total; i0 += TK_THREADS) {
+                    const long i = i0 + t;
+                    const bool act = i < total;
+                    const bool tie = act && f2key(r.val(act ? i : 0)) == thr;
+                    const unsigned long long key = (unsigned long long)r.idx(act ? i : 0);
+                    hist_add(hist, tie && (key & himask) == pfx, (unsigned)(key >> shift) & 0xff, lane);
+                }
+                __syncthreads();
+                if (t == 0) {
+                    unsigned acc = 0;
+                    int dsel = 255;
+                    for (int dgt = 0; dgt < 256; ++dgt) {
+                        const unsigned cdg = hist[dgt];
+                        if (acc + cdg >= rem) { dsel = dgt; break; }
+                        acc += cdg;
+                    }
+                    sh_prefix = (unsigned)dsel;
+                    sh_krem = rem - acc;
+                }
+                __syncthreads();
+                pfx |= (unsigned long long)sh_prefix << shift;
+                rem = sh_krem;
+                __syncthreads();
+            }
+            cutoff = pfx;
         }
-        __syncthreads();
-        unsigned off = hist[t];
-        for (long i = lo; i < hi && off < krem; ++i) {
+        for (long i = t; i < total; i += TK_THREADS) {
             const float v = r.val(i);
-            if (f2key(v) == thr) {
-                const unsigned slot = n_gt + off++;
-                if (in_lds) { s_val[slot] = v; s_idx[slot] = r.idx(i); } else { ov[slot] = v; oi[slot] = r.idx(i); }
+            if (f2key(v) == thr && (unsigned long long)r.idx(i) <= cutoff) {
+                const unsigned slot = atomicAdd(&sh_cnt, 1u);       // continues behind the n_gt gathered elements
+                if (slot < (unsigned)k) {
+                    if (in_lds) { s_val[slot] = v; s_idx[slot] = r.idx(i); } else { ov[slot] = v; oi[slot] = r.idx(i); }
+                }
             }
         }
         n_sorted = kk;

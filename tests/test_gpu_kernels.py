@@ -305,6 +305,33 @@ def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case):
     if case != "running":
         assert torch.max(torch.abs(val - tv)).item() < 1e-3 * max(1.0, float(tv.abs().max()))
     if case == "ties":
-        assert (idx < 1024).all()                # lowest index among equal scores
+        # the best document's 80 copies tie: its ten lowest indices p, p + 1024, ..., p + 9 * 1024
+        assert torch.equal(idx, idx[:, :1] + 1024 * torch.arange(k, device=idx.device)[None, :]) and (idx[:, 0] < 1024).all()
     if case == "ascending":              # (bf16 rounds neighbouring documents to equal scores: ties ascend by index)
         assert (idx >= N - 64).all() and (val[:, :-1] >= val[:, 1:]).all()
+
+
+def test_topk_ties_take_lowest_indices_in_every_path(ctx):
+    """Equal scores at the k-th place: the lowest INDICES win, whatever the position in the candidate row --
+    shuffled (score, index) lists in a merge (radix path, second radix select over the indices), the
+    previous-best leg of a running merge, and a row of identical scores."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    nq, m, k = 7, 300, 10
+    idx = torch.stack([torch.randperm(5000, generator=g)[:m] for _ in range(nq)]).to(torch.int64)
+    val = torch.full((nq, m), 0.5)
+    val[:, :3] = 2.0                                             # three clear winners, then a 297-way tie for 7 places
+    ov, oi = ctx.topk_merge(val.cuda(), idx.cuda(), k)
+    for r in range(nq):
+        want = sorted(idx[r, :3].tolist()) + sorted(idx[r, 3:].tolist())[:7]
+        assert oi[r].cpu().tolist() == want
+        assert ov[r].cpu().tolist() == [2.0] * 3 + [0.5] * 7
+    # identical scores in a plain row: indices 0..k-1
+    v2, i2 = ctx.topk(torch.full((3, 3000), 1.25).cuda(), 16)
+    assert (i2.cpu() == torch.arange(16)).all() and (v2 == 1.25).all()
+    # running merge: previous best (earlier documents) ties with every score of a later, long chunk
+    d = 64
+    c = torch.ones(20000, d).to(torch.bfloat16).cuda()
+    q = torch.ones(5, d).to(torch.bfloat16).cuda()
+    v, i, n = ctx.score_topk(q, c[:6000], 8, idx_base=0)
+    v, i, n = ctx.score_topk(q, c[6000:], 8, idx_base=6000, run=(v, i, n))
+    assert (i.cpu() == torch.arange(8)).all()
