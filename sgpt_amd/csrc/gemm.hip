@@ -36,7 +36,7 @@ constexpr bool RESID_NT = SGPT_RESID_NT != 0;
 #endif
 constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 #ifndef SGPT_RESID_PF
-#define SGPT_RESID_PF 2      // residual-epilogue prefetch distance in rounds (16 VGPRs per round in flight)
+#define SGPT_RESID_PF 0      // residual-epilogue prefetch distance in rounds (16 VGPRs each); 0, 1, 2 measured equal, 3 spills
 #endif
 constexpr int RESID_PF = SGPT_RESID_PF;
 constexpr int BM = 128, BN = 128, CH = 8;  // CH = 16-byte chunks per row per k-step
@@ -506,10 +506,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             }
         } else if constexpr (SWAP) {
             // fp32 row-major (+bias +residual): 16 rows x 256 B per round, LDS row stride 272 B.
-            // Each wave walks its 128x64 sub-tile in 8 rounds.  The residual loads of round i+RESID_PF are issued
-            // before round i is processed: a start-up stagger sweep showed the epilogue is NOT chip-wide HBM-bound
-            // (no phase offset helps) but latency-bound -- with the loads issued at the top of their own round every
-            // round pays one full HBM/MALL round trip (8 x ~2.5 us per tile).
+            // Each wave walks its 128x64 sub-tile in 8 rounds; the residual loads of round i+RESID_PF can be issued
+            // before round i is processed.  Measured (scripts/gemm_bench.py): prefetch distance 0, 1, 2 -> 275 / 274 /
+            // 273 us for the out-projection, and a start-up stagger of the workgroups changes nothing either: the
+            // kernel's time is the SUM of its MFMA phase (115 us) and the read-modify-write of x at the rate a plain
+            // streaming RMW kernel reaches (scripts/micro/rmw_bench.hip: 154 us, 5.2 TB/s) -- while the epilogues of
+            // other CUs saturate HBM, the k-loops' operand DMA queues behind them and stalls (k-steps of 3.3-10 k
+            // ticks instead of 2.7 k), so the two phases do not overlap however they are offset.
             constexpr int RS = 272;
             constexpr int PF = EPI == EPI_BIAS_RESID ? RESID_PF : 0;
             const int rrow = lane >> 4, rchunk = lane & 15;
