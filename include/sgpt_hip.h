@@ -195,7 +195,12 @@ sgpt_status sgpt_scores(sgpt_ctx* ctx, const void* a, const void* b, int32_t dty
  *   run_val device fp32[nq,k], run_idx device int64[nq,k]: in = running best (first n_run
  *           columns valid), out = new running best, sorted by descending score
  *           (ties: ascending index); unused tail = (-inf, -1).
- *   returns through *n_out (host) the number of valid columns = min(k, n_run + N). */
+ *   returns through *n_out (host) the number of valid columns = min(k, n_run + N).
+ * Long corpora (bf16, d % 64 == 0, k <= 256, N >= two chunks): only the first chunk's scores are materialised;
+ * later chunks double in length and their GEMM epilogue appends just the scores above the query's running k-th
+ * best to a candidate list that a small merge kernel folds into the running top-k.  The result is identical to
+ * the materialised loop; a candidate-list overflow raises a device flag on which a materialised recomputation of
+ * the call is predicated (its kernels exit at once otherwise), so the call stays asynchronous on `stream`. */
 sgpt_status sgpt_score_topk(sgpt_ctx* ctx, const void* q, const void* corpus, int32_t dtype,
                             int32_t nq, int64_t N, int32_t d, int32_t k, int64_t idx_base,
                             float* run_val, int64_t* run_idx, int32_t n_run, int32_t* n_out,
