@@ -39,7 +39,7 @@ constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 #define SGPT_RESID_PF 0      // residual-epilogue prefetch distance in rounds (16 VGPRs each); 0, 1, 2 measured equal, 3 spills
 #endif
 constexpr int RESID_PF = SGPT_RESID_PF;
-constexpr int BM = 128, BN = 128, CH = 8;  // CH = 16-byte chunks per row per k-step
+constexpr int CH = 8;  // 16-byte chunks per row per k-step
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<bf16_t> { static constexpr int EPC = 8; };
@@ -76,8 +76,13 @@ template <typename OutT> __device__ __forceinline__ void store1(OutT* p, float a
 template <> __device__ __forceinline__ void store1<float>(float* p, float a) { *p = a; }
 template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float a) { *p = f32_to_bf16(a); }
 
-template <typename T, int EPI, typename OutT, bool SWAP>
+// NI = 16-row MFMA fragments per wave and dimension: 4 -> 128x128 tile (64x64 per wave), 2 -> 64x64 tile (32x32 per wave)
+// for problems too small to fill the chip with larger tiles.  Every GEMM kernel in this file feeds each output element the
+// same sequence of v_mfma_f32_16x16x32_bf16 operations (k ascending, same k-slot mapping) and the same epilogue
+// arithmetic, so the choice of kernel / tile never changes a bit of the result (batch invariance of the embeddings).
+template <typename T, int EPI, typename OutT, bool SWAP, int NI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+    constexpr int BM = 32 * NI, BN = 32 * NI;
     if (p.pred != nullptr && *p.pred == 0) return;   // predicated (fallback) launch that is not needed
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = CH * EPC;
@@ -106,28 +111,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const T* __restrict__ Ag = static_cast<const T*>(p.A);
     const T* __restrict__ Wg = static_cast<const T*>(p.W);
 
-    long arow[4], wrow[4];
+    long arow[NI], wrow[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         int ra = m0 + lr + 32 * i; ra = ra < M ? ra : M - 1;
         int rw = n0 + lr + 32 * i; rw = rw < N ? rw : N - 1;
         arow[i] = (long)ra * p.lda;
         wrow[i] = (long)rw * p.ldw;
     }
 
-    uint4 ra_[4], rw_[4];
+    uint4 ra_[NI], rw_[NI];
     auto gload = [&](int kt) {
         const int kc = kt * BK + lc * EPC;
         if (kt * BK + BK <= K) {  // block-uniform: full k-step (every encoder GEMM)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 ra_[i] = *reinterpret_cast<const uint4*>(Ag + arow[i] + kc);
                 rw_[i] = *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc);
             }
         } else {  // K tail (scoring with d not a multiple of the k-step): zero-fill chunks past K
             const bool ok = kc < K;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 ra_[i] = ok ? *reinterpret_cast<const uint4*>(Ag + arow[i] + kc) : make_uint4(0, 0, 0, 0);
                 rw_[i] = ok ? *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc) : make_uint4(0, 0, 0, 0);
             }
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int row = lr + 32 * i;
             const int off = row * CH + (lc ^ (row & 7));
             lds[buf][0][off] = ra_[i];
@@ -147,30 +152,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, g = lane >> 4;
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 af[4], wf[4];
+            uint4 af[NI], wf[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + fr;
+            for (int i = 0; i < NI; ++i) {
+                const int row = wm * (16 * NI) + i * 16 + fr;
                 af[i] = lds[buf][0][row * CH + ((4 * ks + g) ^ (row & 7))];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + fr;
+            for (int j = 0; j < NI; ++j) {
+                const int row = wn * (16 * NI) + j * 16 + fr;
                 wf[j] = lds[buf][1][row * CH + ((4 * ks + g) ^ (row & 7))];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma<T, SWAP>(acc[i][j], af[i], wf[j]);
+                for (int j = 0; j < NI; ++j) mma<T, SWAP>(acc[i][j], af[i], wf[j]);
         }
     };
 
@@ -192,16 +197,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     if constexpr (SWAP) {
         // lane: m = .. + fr ; n = .. + 4g + r  -> 4 consecutive n, row-major vector store
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + fr;
+        for (int i = 0; i < NI; ++i) {
+            const int m = m0 + wm * (16 * NI) + i * 16 + fr;
             if (m >= mv) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + 4 * g;
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * (16 * NI) + j * 16 + 4 * g;
                 if (n >= N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const bool full = n + 3 < N;
-                if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || (EPI == EPI_STORE && p.bias != nullptr)) {
+                if constexpr (EPI == EPI_BIAS_RESID) {
+                    // acc + (bias + resid): the association of gemm256_kernel's epilogue, bit for bit
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
+                    v[0] += bb.x + rr.x; v[1] += bb.y + rr.y; v[2] += bb.z + rr.z; v[3] += bb.w + rr.w;
+                } else if (EPI == EPI_BIAS_GELU || (EPI == EPI_STORE && p.bias != nullptr)) {
                     // N is a multiple of 4 for every biased projection
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -209,10 +219,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = sizeof(T) == 2 ? gelu_new_fast(v[r]) : gelu_new(v[r]);
-                }
-                if constexpr (EPI == EPI_BIAS_RESID) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
-                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                 }
                 if constexpr (EPI == EPI_SCORE) {
 #pragma unroll
@@ -232,12 +238,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         // lane: m = .. + 4g + r ; n = .. + fr  -> 4 consecutive m: transposed store out[n][m..m+3]
         static_assert(SWAP || EPI == EPI_VT, "non-swapped orientation is only used for the V^T store");
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fr;
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * (16 * NI) + j * 16 + fr;
             if (n >= N) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 64 + i * 16 + 4 * g;
+            for (int i = 0; i < NI; ++i) {
+                const int m = m0 + wm * (16 * NI) + i * 16 + 4 * g;
                 if (m >= M) continue;  // M (token axis) is padded to a multiple of 128 by the caller
                 const float bn = p.bias ? p.bias[n] : 0.f;   // BLOOM: V projection has a bias
                 store4<OutT>(out + (long)n * p.ldo + m, acc[i][j][0] + bn, acc[i][j][1] + bn, acc[i][j][2] + bn, acc[i][j][3] + bn);
@@ -1121,11 +1127,17 @@ void launch_p2(const GemmArgs& a, hipStream_t s) {
 
 template <typename T, int EPI, typename OutT, bool SWAP>
 void launch(const GemmArgs& a, hipStream_t s) {
-    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
+    // 64x64 tiles when 128x128 ones would leave most of the 256 CUs idle (short query batches, USEB's 21-32 sentence
+    // calls: M = 1024 x N = 768 is 48 tiles of 128^2 but 192 of 64^2)
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const bool small = t128 < 192;
+    const int B = small ? 64 : 128;
+    const int MT = (a.M + B - 1) / B, NT = (a.N + B - 1) / B;
     const int mt_per_xcd = (MT + 7) / 8;
     const int bands = (mt_per_xcd + 7) / 8;
     const int grid = 8 * bands * 8 * NT;
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP>), dim3(grid), dim3(256), 0, s, a);
+    if (small) hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 2>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 4>), dim3(grid), dim3(256), 0, s, a);
 }
 
 }  // namespace
@@ -1158,10 +1170,9 @@ void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream
     if (bf && use256 && epi == EPI_SCORE && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0)
         return launch256<EPI_SCORE, float, true>(a, s);   // scorer: query rows padded to 256 by the caller (m_valid < M)
     // Small problems (short query batches, USEB's 21-32 sentence calls): fewer than half a wave of 256x256 tiles
-    // leaves most of the 256 CUs idle, and the 128x128 kernel's 4x tile count is 13 % faster end to end there
-    // (32 queries: 2.32 -> 2.01 ms).  OPT-IN (SGPT_SMALL_TILE=1) because choosing the kernel by batch size breaks
-    // the bit-level batch invariance of the embeddings (the two kernels round differently: 2.6e-4 on unit vectors).
-    static const bool small_tiles = getenv("SGPT_SMALL_TILE") != nullptr;
+    // leaves most of the 256 CUs idle; the register-staged kernel's 128x128 / 64x64 tiles fill the chip instead.
+    // Bit-identical results (see gemm_kernel), so the embeddings stay batch-invariant.  SGPT_NO_SMALL_TILE=1: A/B.
+    static const bool small_tiles = getenv("SGPT_NO_SMALL_TILE") == nullptr;
     const bool few = small_tiles && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
     if (bf && use256 && !few && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.m_valid == a.M) {
         if (epi == EPI_STORE && obf) return launch256<EPI_STORE, bf16_t, true>(a, s);
