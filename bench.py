@@ -83,6 +83,38 @@ def flops_per_sentence(S, L=12, d=768):
     return L * 24 * S * d * d + 2 * L * d * S * (S + 1)
 
 
+def hf_cpu_baseline(ocfg, ow, sample, port_emb):
+    """HF GPTNeoModel (fp32, eager attention, eval) on the host cores over the same bounded sample."""
+    from transformers import GPTNeoConfig, GPTNeoModel
+    hc = GPTNeoConfig(vocab_size=ocfg.vocab_size, max_position_embeddings=ocfg.max_position_embeddings,
+                      hidden_size=ocfg.hidden_size, num_layers=ocfg.num_layers, num_heads=ocfg.num_heads,
+                      intermediate_size=ocfg.intermediate_size, window_size=ocfg.window_size,
+                      attention_types=[[["global", "local"], ocfg.num_layers // 2]],
+                      layer_norm_epsilon=ocfg.layer_norm_epsilon, attention_dropout=0.0, resid_dropout=0.0,
+                      embed_dropout=0.0)
+    hc._attn_implementation = "eager"
+    hf = GPTNeoModel(hc).eval()
+    hf.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ow.items()}, strict=False)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    ids = torch.tensor(sample, dtype=torch.long)
+    mask = torch.ones_like(ids)
+
+    def run(i, m):
+        with torch.no_grad():
+            h = hf(input_ids=i, attention_mask=m).last_hidden_state
+            w = torch.arange(1, h.shape[1] + 1, dtype=torch.float32)[None, :, None] * m[:, :, None].float()
+            e = (h * w).sum(1) / w.sum(1)
+            return torch.nn.functional.normalize(e, dim=1)
+    run(ids[:8], mask[:8])                                    # warm-up
+    t = time.perf_counter()
+    emb = run(ids, mask)
+    dt = time.perf_counter() - t
+    return {"value": round(len(sample) / dt, 2), "unit": "sentences/s", "cores": threads,
+            "what": "HF GPTNeoModel fp32 eager + raw weighted-mean pooling + normalise, torch CPU",
+            "seconds": round(dt, 2), "max_abs_diff_vs_port": float(np.abs(emb.numpy() - np.asarray(port_emb)).max())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +310,13 @@ def main():
                "kind": "port", "sample": f"{args.cpu_sample} sentences x {S} tokens, numpy fp32 oracle "
                                          f"(oracle/sgpt_oracle.py), encode+pool+normalise, {cdt:.1f}s",
                "gpu_vs_cpu_max_abs_emb_diff": float(np.abs(got - ce).max())}
+        # The code the reference actually runs on a CPU: HF GPTNeoModel fp32 eager (the un-vendored
+        # dependency behind beir_dense_retriever.py:204-205) + the raw weighted-mean pooling of :258-270, same weights,
+        # same sample, all host cores.  Reported next to the port when `transformers` is importable on the box.
+        try:
+            cpu["hf_transformers"] = hf_cpu_baseline(ocfg, ow, sample, ce)
+        except Exception as e:  # noqa: BLE001 -- an optional, reported-only leg must never sink the bench line
+            cpu["hf_transformers"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     out = {"metric": "encoded sentences/sec (SGPT-125M, seq_len 128, encode + weighted-mean pool + cosine top-10 "
                      "chunk loop)",
