@@ -31,8 +31,8 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "sgpt_hip.h"),
-               os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    headers += [os.path.join(HERE, "..", "include", "sgpt_hip.h"), os.path.abspath(__file__)]
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

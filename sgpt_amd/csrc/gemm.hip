@@ -427,164 +427,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         __syncthreads();  // every wave is done reading the consumed stage
         STAMP(2);
         char* scr = reinterpret_cast<char*>(&lds[st ^ 1][0][0]) + wave * 8192;
-        if constexpr (EPI == EPI_SCORE_FILTER) {
-            // Scorer chunks after the first: the running k-th best score of query m is a lower bound of its final
-            // k-th best, and a later document (higher index) never displaces an equal score, so only scores
-            // STRICTLY above thr[m] can enter the top-k.  They are appended to the query's candidate list
-            // (expected ~k per chunk under the doubling chunk schedule); nothing else leaves the registers.
-            // MFMA C layout (SWAP): lane holds row m = fr of sub-tile i, columns 4g..4g+3 of sub-tile j.
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + wm * 128 + i * 16 + fr;
-                const float th = m < p.m_valid ? p.thr[(long)m * p.thr_ld] : INFINITY;
-                float mx = -INFINITY;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[i][j][r];
-                        v = v != v ? -1.0f : v;                      // cos_scores[isnan] = -1 (exact_search.py:99)
-                        acc[i][j][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-                if (mx > th) {                                       // rare
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = acc[i][j][r];
-                            if (v > th) {
-                                const int slot = atomicAdd(p.cand_cnt + m, 1);
-                                if (slot < p.cand_cap) {
-                                    p.cand_val[(long)m * p.cand_cap + slot] = v;
-                                    p.cand_idx[(long)m * p.cand_cap + slot] = p.idx_base + n0 + wn * 64 + j * 16 + 4 * g + r;
-                                }
-                            }
-                        }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            (void)scr;
-        } else if constexpr (EPI == EPI_NONE) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    asm volatile("" ::"v"(acc[i][j]));
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-        } else if constexpr (SWAP && sizeof(OutT) == 2) {
-            // bf16 row-major: 16 rows x 128 B per round, LDS row stride 144 B
-            constexpr int RS = 144;
-            const int rrow = lane >> 3, rchunk = lane & 7;
-            float4 bb[4];
-            const bool has_bias = EPI == EPI_BIAS_GELU || p.bias != nullptr;   // plain store + bias: BLOOM Q/K projection
-            if (has_bias) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 16 + 4 * g);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    if constexpr (EPI == EPI_BIAS_GELU) {
-                        v[0] = gelu_new_fast(v[0] + bb[j].x); v[1] = gelu_new_fast(v[1] + bb[j].y);
-                        v[2] = gelu_new_fast(v[2] + bb[j].z); v[3] = gelu_new_fast(v[3] + bb[j].w);
-                    } else {
-                        v[0] += bb[j].x; v[1] += bb[j].y; v[2] += bb[j].z; v[3] += bb[j].w;
-                    }
-                    *reinterpret_cast<uint2_a*>(scr + fr * RS + (j * 16 + 4 * g) * 2) =
-                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = h * 8 + rrow;
-                    const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
-                    const int m = m0 + wm * 128 + i * 16 + row;
-                    gstore16<true>(reinterpret_cast<bf16_t*>(out) + (long)m * p.ldo + n0 + wn * 64 + rchunk * 8, v);
-                }
-            }
-        } else if constexpr (SWAP) {
-            // fp32 row-major (+bias +residual): 16 rows x 256 B per round, LDS row stride 272 B.
-            // Each wave walks its 128x64 sub-tile in 8 rounds; the residual loads of round i+RESID_PF can be issued
-            // before round i is processed.  Measured (scripts/gemm_bench.py): prefetch distance 0, 1, 2 -> 275 / 274 /
-            // 273 us for the out-projection, and a start-up stagger of the workgroups changes nothing either: the
-            // kernel's time is the SUM of its MFMA phase (115 us) and the read-modify-write of x at the rate a plain
-            // streaming RMW kernel reaches (scripts/micro/rmw_bench.hip: 154 us, 5.2 TB/s) -- while the epilogues of
-            // other CUs saturate HBM, the k-loops' operand DMA queues behind them and stalls (k-steps of 3.3-10 k
-            // ticks instead of 2.7 k), so the two phases do not overlap however they are offset.
-            constexpr int RS = 272;
-            constexpr int PF = EPI == EPI_BIAS_RESID ? RESID_PF : 0;
-            const int rrow = lane >> 4, rchunk = lane & 15;
-            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (EPI == EPI_BIAS_RESID) bb = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + rchunk * 4);
-            const long gbase = (long)(m0 + wm * 128 + rrow) * p.ldo + n0 + wn * 64 + rchunk * 4;
-            float4 rr[PF + 1][4];
-            if constexpr (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-                for (int q = 0; q < PF; ++q)
-#pragma unroll
-                    for (int h = 0; h < 4; ++h)
-                        rr[q][h] = ldg16<RESID_LD_NT>(p.resid + gbase + (long)(q * 16 + h * 4) * p.ldo);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if constexpr (EPI == EPI_BIAS_RESID) {
-                    if (i + PF < 8) {
-#pragma unroll
-                        for (int h = 0; h < 4; ++h)
-                            rr[(i + PF) % (PF + 1)][h] = ldg16<RESID_LD_NT>(p.resid + gbase + (long)((i + PF) * 16 + h * 4) * p.ldo);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    *reinterpret_cast<float4_a*>(scr + fr * RS + (j * 16 + 4 * g) * 4) =
-                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    float4 v = *reinterpret_cast<const float4_a*>(scr + (h * 4 + rrow) * RS + rchunk * 16);
-                    if constexpr (EPI == EPI_BIAS_RESID) {
-                        const float4 r = rr[i % (PF + 1)][h];
-                        v.x += bb.x + r.x; v.y += bb.y + r.y; v.z += bb.z + r.z; v.w += bb.w + r.w;
-                    }
-                    if constexpr (EPI == EPI_SCORE) {   // cos_scores[isnan] = -1 (exact_search.py:99); padded query rows skipped
-                        v.x = v.x != v.x ? -1.0f : v.x; v.y = v.y != v.y ? -1.0f : v.y;
-                        v.z = v.z != v.z ? -1.0f : v.z; v.w = v.w != v.w ? -1.0f : v.w;
-                        if (m0 + wm * 128 + i * 16 + h * 4 + rrow >= p.m_valid) continue;
-                    }
-                    gstore16<RESID_NT>(reinterpret_cast<float*>(out) + gbase + (long)(i * 16 + h * 4) * p.ldo, __builtin_bit_cast(uint4, v));
-                }
-            }
-        } else {
-            // V^T (bf16, out[n][m]): 16 n-rows x 256 B (128 m) per round, LDS row stride 272 B
-            constexpr int RS = 272;
-            const int rrow = lane >> 4, rchunk = lane & 15;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float bn = p.bias ? p.bias[n0 + wn * 64 + j * 16 + fr] : 0.f;   // BLOOM: V projection bias
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    *reinterpret_cast<uint2_a*>(scr + fr * RS + (i * 16 + 4 * g) * 2) =
-                        make_uint2(pack_bf16x2(acc[i][j][0] + bn, acc[i][j][1] + bn), pack_bf16x2(acc[i][j][2] + bn, acc[i][j][3] + bn));
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int row = h * 4 + rrow;
-                    const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
-                    const int n = n0 + wn * 64 + j * 16 + row;
-                    gstore16<true>(reinterpret_cast<bf16_t*>(out) + (long)n * p.ldo + m0 + wm * 128 + rchunk * 8, v);
-                }
-            }
-        }
+#include "gemm256_epilogue.inc"
         STAMP(3);
         ++dbg_tile;
         if (!has_next) break;
@@ -609,6 +452,190 @@ void launch256(const GemmArgs& a, hipStream_t s) {
     if (skew_env >= 0) b.skew = skew_env;
     if (tiles_total < 2 * grid) b.skew = 0;   // a single tile per workgroup: nothing to interleave with
     hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, SWAP>), dim3(grid), dim3(512), 0, s, b);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Variant D ("deep"): gemm256_kernel with an ASYMMETRIC LDS ring.  One operand of every encoder / scorer GEMM is
+// small and L2-resident (weights, queries), the other streams from HBM (activations, corpus).  With two symmetric
+// 64-KiB stages the streamed operand gets one k-step (~1.3 us) to arrive; a loaded-HBM round trip is longer, and
+// the k-steps stretch from 2.7 k to 3.0-4.0 k ticks (fc2: 1 144 TFLOP/s without stores where the vendor GEMM
+// reaches 1 308; the filtered scorer GEMM 1 035).  Here the streamed ("deep") operand has THREE 32-KiB slots and
+// is fetched two k-steps ahead, the resident ("shallow") one keeps two slots: 96 + 64 = 160 KiB, the whole LDS.
+// Per k-step s a wave issues shallow(s+1) x4 pieces and THEN deep(s+2) x4 pieces; DMA completes in order, so
+// `s_waitcnt vmcnt(4)` at the top of step s+1 means "everything but the newest four pieces", i.e. shallow(s+1) and
+// deep(s+1) have landed while deep(s+2) stays in flight.  Epilogue scratch: after a tile's last step one deep and one
+// shallow slot are free (32 KiB each): waves 0-3 transpose through the first, waves 4-7 through the second.
+template <int EPI, typename OutT, bool SWAP, bool DEEP_A>
+__global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
+    if (p.pred != nullptr && *p.pred == 0) return;
+    typedef __attribute__((address_space(3))) char* lds_cptr_t;
+    constexpr int TM = 256, TN = 256;
+    constexpr int SLOT = TM * CH;                                    // uint4 per 32-KiB slot (256 rows x 8 chunks)
+    __shared__ __attribute__((aligned(16))) uint4 lds[5 * SLOT];    // [deep 0..2 | shallow 0..1] = 160 KiB
+
+    const int N = p.N, K = p.K;
+    const int MT = p.M / TM, NT = N / TN;
+    constexpr int GM = 4, GN = 8;
+    const bool m_major = MT >= NT;
+    const int AT = m_major ? MT : NT, BT = m_major ? NT : MT;
+    const int per_band = GM * BT;
+    const int tiles_total = ((AT + 7) / 8 + GM - 1) / GM * GM * 8 * BT;
+    auto tile_coords = [&](int tile, int& m0, int& n0) -> bool {
+        const int xcd = tile & 7, local = tile >> 3;
+        const int band = local / per_band, inb = local % per_band;
+        const int ng = inb / (GM * GN);
+        const int gn = (BT - ng * GN) < GN ? (BT - ng * GN) : GN;
+        const int r = inb - ng * GM * GN;
+        const int at = xcd + 8 * (band * GM + r / gn), bt = ng * GN + r % gn;
+        m0 = (m_major ? at : bt) * TM; n0 = (m_major ? bt : at) * TN;
+        return at < AT;
+    };
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, g = lane >> 4;
+
+    const bf16_t* __restrict__ Ag = static_cast<const bf16_t*>(p.A);
+    const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(p.W);
+    const int lrow = wave * 32 + (lane >> 3);
+    const int lchunk = (lane & 7) ^ (lane >> 3);
+    const long astep = 8 * p.lda, wstep = 8 * p.ldw;
+    const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0]);
+    auto dma16 = [&](const bf16_t* src, unsigned dst_byte) {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(dst_byte);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(dst)
+                     : "memory");
+    };
+    // slot byte offsets: deep slot sd in [0,3), shallow slot ss in [0,2)
+    auto deep_off = [&](int sd) { return (unsigned)(sd * SLOT * 16); };
+    auto shal_off = [&](int ss) { return (unsigned)((3 + ss) * SLOT * 16); };
+    // piece q (0..3) of this wave's 32 rows of one operand
+    auto piece = [&](const bf16_t* src, long step, int kt, unsigned slot_off, int q) {
+        const unsigned row_off = (unsigned)((wave * 32 + q * 8) * CH * 16);
+        dma16(src + q * step + kt * 64, lds_base + slot_off + row_off);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / 64;   // >= 2 (launcher)
+    OutT* __restrict__ out = static_cast<OutT*>(p.out);
+
+    int tile = blockIdx.x, m0 = 0, n0 = 0;
+    while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
+    if (tile >= tiles_total) return;
+    // per-lane source rows of the two operands for the current tile
+    const bf16_t* asrc = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
+    const bf16_t* wsrc = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
+    const long dstep = DEEP_A ? astep : wstep, sstep = DEEP_A ? wstep : astep;
+    int sd = 0, ss = 0;      // ring slots of the k-step about to be computed
+    int dbg_tile = 0;
+#define STAMP(k)                                                                                   \
+    if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 8) p.dbg[dbg_tile * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
+
+    {   // prologue: deep(0), shallow(0), deep(1) -- in the order the waits assume
+        const bf16_t* dsrc = DEEP_A ? asrc : wsrc;
+        const bf16_t* ssrc = DEEP_A ? wsrc : asrc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece(dsrc, dstep, 0, deep_off(0), q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece(ssrc, sstep, 0, shal_off(0), q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece(dsrc, dstep, 1, deep_off(1), q);
+    }
+    bool first_step = true;
+    while (true) {
+        int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
+        while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
+        const bool has_next = ntile < tiles_total;
+        const bf16_t* nasrc = has_next ? Ag + (long)(nm0 + lrow) * p.lda + lchunk * 8 : asrc;   // past the end: harmless re-fetch
+        const bf16_t* nwsrc = has_next ? Wg + (long)(nn0 + lrow) * p.ldw + lchunk * 8 : wsrc;
+        const bf16_t* d_cur = DEEP_A ? asrc : wsrc, *d_nxt = DEEP_A ? nasrc : nwsrc;
+        const bf16_t* s_cur = DEEP_A ? wsrc : asrc, *s_nxt = DEEP_A ? nwsrc : nasrc;
+        for (int kt = 0; kt < nk; ++kt) {
+            // shallow(kt) and deep(kt) have landed; the newest four pieces (deep(kt+1)) may still be in flight.
+            // The first step of a follow-up tile was already waited for before the previous epilogue's stores.
+            if (kt > 0 || first_step) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();
+            if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 4 && kt < 12)
+                p.dbg[64 + dbg_tile * 16 + kt] = (long long)__builtin_amdgcn_s_memtime();
+            // what this step fetches: shallow(kt+1), deep(kt+2) -- possibly of the next tile
+            const bool s_in = kt + 1 < nk, d_in = kt + 2 < nk;
+            const bf16_t* sp = s_in ? s_cur : s_nxt;  const int skt = s_in ? kt + 1 : 0;
+            const bf16_t* dp = d_in ? d_cur : d_nxt;  const int dkt = d_in ? kt + 2 : kt + 2 - nk;
+            const unsigned s_dst = shal_off(ss ^ 1);
+            const int sd2 = sd + 2 >= 3 ? sd - 1 : sd + 2;
+            const unsigned d_dst = deep_off(sd2);
+            const uint4* la = lds + (DEEP_A ? sd * SLOT : (3 + ss) * SLOT);
+            const uint4* lw = lds + (DEEP_A ? (3 + ss) * SLOT : sd * SLOT);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 af[8], wf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = wn * 64 + j * 16 + fr;
+                    wf[j] = lw[row * CH + ((4 * ks + g) ^ (row & 7))];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = wm * 128 + i * 16 + fr;
+                    af[i] = la[row * CH + ((4 * ks + g) ^ (row & 7))];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma<bf16_t, SWAP>(acc[i][j], af[i], wf[j]);
+                    if (ks == 0) {   // one 1-KiB piece behind every 4 MFMAs: shallow x4 first, then deep x4
+                        if (i < 4) piece(sp, sstep, skt, s_dst, i);
+                        else piece(dp, dstep, dkt, d_dst, i - 4);
+                    }
+                }
+            }
+            ss ^= 1;
+            sd = sd + 1 >= 3 ? 0 : sd + 1;
+        }
+        STAMP(0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // next tile's shallow(0), deep(0) landed; deep(1) in flight
+        first_step = false;
+        STAMP(1);
+        __syncthreads();  // every wave is done reading the slots consumed last
+        STAMP(2);
+        // free slots now: deep (sd + 2) % 3 (consumed by the last step; sd already points at the next tile's step 0)
+        // and shallow ss ^ 1
+        const int sdf = sd + 2 >= 3 ? sd - 1 : sd + 2;
+        char* scr = reinterpret_cast<char*>(lds) + (wave < 4 ? deep_off(sdf) : shal_off(ss ^ 1)) + (wave & 3) * 8192;
+#include "gemm256_epilogue.inc"
+        STAMP(3);
+        ++dbg_tile;
+        if (!has_next) break;
+        tile = ntile; m0 = nm0; n0 = nn0; asrc = nasrc; wsrc = nwsrc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead DMA before the LDS is released
+#undef STAMP
+}
+
+template <int EPI, typename OutT, bool SWAP>
+void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
+    const int MT = a.M / 256, NT = a.N / 256;
+    const int AT = MT >= NT ? MT : NT, BT = MT >= NT ? NT : MT;
+    const int tiles_total = ((AT + 7) / 8 + 3) / 4 * 4 * 8 * BT;
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n / 8 * 8;
+    }();
+    const int grid = tiles_total < ncu ? tiles_total : ncu;
+    if (deep_a) hipLaunchKernelGGL((gemm256d_kernel<EPI, OutT, SWAP, true>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gemm256d_kernel<EPI, OutT, SWAP, false>), dim3(grid), dim3(512), 0, s, a);
 }
 
 
@@ -1154,6 +1181,23 @@ void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream
         if (epi == EPI_BIAS_RESID) return launch_p2<EPI_BIAS_RESID, float, true>(a, s);
         if (epi == EPI_NONE) return launch_p2<EPI_NONE, bf16_t, true>(a, s);
     }
+    // Small problems (short query batches, USEB's 21-32 sentence calls): fewer than half a wave of 256x256 tiles
+    // leaves most of the 256 CUs idle; the register-staged kernel's 128x128 / 64x64 tiles fill the chip instead.
+    // Bit-identical results (see gemm_kernel), so the embeddings stay batch-invariant.  SGPT_NO_SMALL_TILE=1: A/B.
+    static const bool small_tiles = getenv("SGPT_NO_SMALL_TILE") == nullptr;
+    const bool few = small_tiles && epi != EPI_SCORE && epi != EPI_SCORE_FILTER && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
+    static const bool use_deep = getenv("SGPT_GEMM_NODEEP") == nullptr;   // asymmetric-ring kernel (default); env: A/B
+    if (bf && use_deep && !few && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 &&
+        (a.m_valid == a.M || epi == EPI_SCORE || epi == EPI_SCORE_FILTER)) {
+        const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
+        if (epi == EPI_SCORE) return launch256d<EPI_SCORE, float, true>(a, s, deep_a);
+        if (epi == EPI_SCORE_FILTER) return launch256d<EPI_SCORE_FILTER, float, true>(a, s, deep_a);
+        if (epi == EPI_STORE && obf) return launch256d<EPI_STORE, bf16_t, true>(a, s, deep_a);
+        if (epi == EPI_VT) return launch256d<EPI_VT, bf16_t, false>(a, s, deep_a);
+        if (epi == EPI_BIAS_GELU) return launch256d<EPI_BIAS_GELU, bf16_t, true>(a, s, deep_a);
+        if (epi == EPI_BIAS_RESID) return launch256d<EPI_BIAS_RESID, float, true>(a, s, deep_a);
+        if (epi == EPI_NONE) return launch256d<EPI_NONE, bf16_t, true>(a, s, deep_a);
+    }
     static const bool use4w = getenv("SGPT_GEMM4W") != nullptr;
     if (bf && use4w && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.m_valid == a.M || epi == EPI_SCORE)) {
         if (epi == EPI_SCORE) return launch4w<EPI_SCORE, float, true>(a, s);
@@ -1165,15 +1209,12 @@ void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream
     }
     if (epi == EPI_SCORE_FILTER) {   // caller guarantees bf16, M % 256 == 0 (padded queries), N % 256 == 0, K % 64 == 0
         if (!(bf && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0)) abort();
+        static const bool deep_f = getenv("SGPT_GEMM_NODEEP") == nullptr;
+        if (deep_f && a.K >= 128) return launch256d<EPI_SCORE_FILTER, float, true>(a, s, a.M >= a.N);
         return launch256<EPI_SCORE_FILTER, float, true>(a, s);
     }
     if (bf && use256 && epi == EPI_SCORE && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0)
         return launch256<EPI_SCORE, float, true>(a, s);   // scorer: query rows padded to 256 by the caller (m_valid < M)
-    // Small problems (short query batches, USEB's 21-32 sentence calls): fewer than half a wave of 256x256 tiles
-    // leaves most of the 256 CUs idle; the register-staged kernel's 128x128 / 64x64 tiles fill the chip instead.
-    // Bit-identical results (see gemm_kernel), so the embeddings stay batch-invariant.  SGPT_NO_SMALL_TILE=1: A/B.
-    static const bool small_tiles = getenv("SGPT_NO_SMALL_TILE") == nullptr;
-    const bool few = small_tiles && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
     if (bf && use256 && !few && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.m_valid == a.M) {
         if (epi == EPI_STORE && obf) return launch256<EPI_STORE, bf16_t, true>(a, s);
         if (epi == EPI_VT) return launch256<EPI_VT, bf16_t, false>(a, s);

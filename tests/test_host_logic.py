@@ -234,6 +234,6 @@ def test_library_is_not_older_than_its_sources():
     so = os.path.getmtime(_lib.LIB_PATH)
     srcs = [os.path.join(ROOT, "include", "sgpt_hip.h")]
     csrc = os.path.join(ROOT, "sgpt_amd", "csrc")
-    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".inc"))]
     stale = [os.path.basename(s) for s in srcs if os.path.getmtime(s) > so + 1.0]
     assert not stale, f"libsgpt_hip.so is older than {stale}: run `python -m sgpt_amd.build`"
