@@ -262,6 +262,23 @@ def _sliced_classic(ctx, q, c, k, step, idx_base=0, run=None):
     return run
 
 
+@pytest.mark.parametrize("d", [128, 192, 320])
+def test_score_topk_ring_depths(ctx, d):
+    """K = 128 / 192 / 320: two, three (odd: the 3-slot / 2-slot ring parities drift across tiles) and five k-steps
+    per tile of the asymmetric-ring GEMM, materialised and filtered epilogues, against a plain fp32 product."""
+    nq, N, k = 2048, 70_000, 10
+    g = torch.Generator(device="cpu").manual_seed(d)
+    q = torch.randn(nq, d, generator=g).cuda().to(torch.bfloat16)
+    c = torch.randn(N, d, generator=g).cuda().to(torch.bfloat16)
+    val, idx, n = ctx.score_topk(q, c, k)
+    wv, wi, _ = _sliced_classic(ctx, q, c, k, 16384)
+    assert torch.equal(val, wv) and torch.equal(idx, wi)
+    full = q.float() @ c.float().T
+    tv, ti = torch.topk(full, k, dim=1)
+    assert torch.max(torch.abs(val - tv)).item() < 2e-3 * float(tv.abs().max())
+    assert (torch.gather(full, 1, idx) - tv).abs().max().item() < 2e-3 * float(tv.abs().max())
+
+
 @pytest.mark.parametrize("case", ["random", "ascending", "ties", "running"])
 def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case):
     """Long corpora take the threshold-filtered path (EPI_SCORE_FILTER: chunks after the first only append scores
