@@ -652,11 +652,13 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             HIPC(c, hipMemcpyAsync(sav_v, run_val, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, s));
             HIPC(c, hipMemcpyAsync(sav_i, run_idx, (size_t)nq * k * 8, hipMemcpyDeviceToDevice, s));
         }
-        // first chunk: materialise + select -> the initial thresholds
-        st = classic(0, chunk, pv0, pi0, n_run, tv[0], ti[0], nullptr, chunk);
+        // first chunk: materialise + select -> the initial thresholds.  One whole wave of tiles is enough (the
+        // doubling schedule takes over from there): 16 384 documents for nq = 1000 instead of 32 768
+        const long first = unit < chunk ? unit : chunk;
+        st = classic(0, first, pv0, pi0, n_run, tv[0], ti[0], nullptr, chunk);
         if (st != SGPT_OK) return st;
         int cur = 0;
-        long seen = chunk;
+        long seen = first;
         const long n256 = N / 256 * 256;
         // doubling schedule: a filtered chunk is as long as everything seen before it, so a query expects ~k
         // survivors per chunk (k * len / seen) whatever N is; 1 M documents = 1 + 5 launches instead of 31
