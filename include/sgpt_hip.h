@@ -196,7 +196,7 @@ sgpt_status sgpt_scores(sgpt_ctx* ctx, const void* a, const void* b, int32_t dty
  *           columns valid), out = new running best, sorted by descending score
  *           (ties: ascending index); unused tail = (-inf, -1).
  *   returns through *n_out (host) the number of valid columns = min(k, n_run + N).
- * Long corpora (bf16, d % 64 == 0, k <= 256, N >= two chunks): only the first chunk's scores are materialised;
+ * Long corpora (bf16, d % 64 == 0, k <= 1024, N >= two chunks): only the first chunk's scores are materialised;
  * later chunks double in length and their GEMM epilogue appends just the scores above the query's running k-th
  * best to a candidate list that a small merge kernel folds into the running top-k.  The result is identical to
  * the materialised loop; a candidate-list overflow raises a device flag on which a materialised recomputation of

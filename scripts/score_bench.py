@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sgpt_amd import get_context
 ctx = get_context("cuda:0")
-nq, N, d, k = int(os.environ.get("NQ", 1000)), int(os.environ.get("N", 1000000)), 768, 11
+nq, N, d, k = int(os.environ.get("NQ", 1000)), int(os.environ.get("N", 1000000)), 768, int(os.environ.get("K", 11))
 g = torch.Generator(device="cuda").manual_seed(0)
 base = torch.randn(1, d, device="cuda", generator=g) * 3          # anisotropic: shared dominant direction
 c = torch.nn.functional.normalize(base + torch.randn(N, d, device="cuda", generator=g), dim=1).to(torch.bfloat16)
@@ -19,4 +19,4 @@ for _ in range(reps):
     ctx.score_topk(q, c, k, dtype=torch.bfloat16)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / reps
-print(f"nq={nq} N={N}: {dt*1e3:.2f} ms per pass -> {nq/dt:,.0f} queries/s; corpus stream {N*d*2/dt/1e12:.2f} TB/s; {2*nq*N*d/dt/1e12:.0f} TFLOP/s")
+print(f"nq={nq} N={N} k={k}: {dt*1e3:.2f} ms per pass -> {nq/dt:,.0f} queries/s; corpus stream {N*d*2/dt/1e12:.2f} TB/s; {2*nq*N*d/dt/1e12:.0f} TFLOP/s")

@@ -575,8 +575,11 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // Threshold-filtered chunks (after the first): see EPI_SCORE_FILTER.  Candidate capacity per query and chunk;
     // the doubling schedule below keeps the expected count at ~k.
     static const bool classic_only = getenv("SGPT_SCORE_CLASSIC") != nullptr;
-    const int cap = k <= 64 ? 256 : 4 * k;
-    const bool filt = fast && !classic_only && k <= 256 && chunk % 256 == 0 && N >= 2 * chunk;
+    // Capacity and growth: a filtered chunk of len = growth * seen documents expects ~k * growth survivors per query
+    // (the threshold is the k-th best of `seen` documents); the merge sorts the candidates in 2048 LDS slots.
+    const int cap = k <= 64 ? 256 : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
+    const bool half_growth = 2 * cap < 5 * k;          // k > ~340: cap < 2.5 k -> grow by half, expect ~k/2 per chunk
+    const bool filt = fast && !classic_only && k <= 1024 && chunk % 256 == 0 && N >= 2 * chunk;
 
     // the (rare) fallback recomputes with fewer, larger launches: its score tile may leave the Infinity Cache
     long fchunk = chunk;
@@ -663,7 +666,8 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         // doubling schedule: a filtered chunk is as long as everything seen before it, so a query expects ~k
         // survivors per chunk (k * len / seen) whatever N is; 1 M documents = 1 + 5 launches instead of 31
         while (n256 - seen >= 256) {
-            long len = seen < (n256 - seen) ? seen : (n256 - seen);
+            long len = half_growth ? (seen / 2 / 256 * 256 > 256 ? seen / 2 / 256 * 256 : 256) : seen;
+            if (len > n256 - seen) len = n256 - seen;
             if (len > (1L << 19)) len = 1L << 19;
             if (len >= unit) len = len / unit * unit;
             GemmArgs g{};

@@ -30,6 +30,7 @@ __device__ __forceinline__ uint32_t f2key(float f) {  // ascending uint order ==
 constexpr int TK_THREADS = 256;
 constexpr int TK_SORT_MAX = 2048;   // k <= 2048 sorted in LDS (the driver's k+1 = 1001 fits)
 constexpr int TK_FAST_KMAX = 64;
+constexpr int TK_MERGE_KMAX = 1024;  // cand_merge_kernel: running top-k kept in LDS
 constexpr long TK_FAST_MIN_ROW = 4096;
 
 struct Row {
@@ -319,9 +320,21 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
     }
 }
 
-// Merge of the filtered scorer: one workgroup per query sorts {running top-k} U {<= cap appended candidates}
-// (k + cap <= TK_SORT_MAX) and keeps the k best (descending score, ties by ascending index).  The candidate list
-// holds every score of the chunk that beat the running k-th best, so the result equals the full-row selection.
+// Merge of the filtered scorer: one workgroup per query.  The running top-k arrives sorted (descending score, ties by
+// ascending index; unused tail = (-inf, -1)); the <= cap appended candidates are sorted in LDS (bitonic over the next
+// power of two of their COUNT -- typically ~k/2..k entries, not cap), then the two sorted lists are merged by rank:
+// every element's output position is its own position plus the number of elements of the other list that sort
+// before it (binary search; the order is total because indices are unique).  The candidate list holds every score of
+// the chunk that beat the running k-th best, so the result equals the full-row selection.
+__device__ __forceinline__ int count_before(const float* v, const int64_t* id, int n, float qv, int64_t qi) {
+    int lo = 0, hi = n;                       // first position whose element does NOT sort before (qv, qi)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sorts_before(v[mid], id[mid], qv, qi)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __restrict__ run_val,
                                                                const int64_t* __restrict__ run_idx,
                                                                const float* __restrict__ cand_val,
@@ -329,37 +342,43 @@ __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __r
                                                                int* __restrict__ cand_cnt, int cap, int k,
                                                                float* __restrict__ out_val, int64_t* __restrict__ out_idx,
                                                                int* __restrict__ overflow) {
-    __shared__ float s_val[TK_SORT_MAX];
+    __shared__ float s_val[TK_SORT_MAX];      // candidates
     __shared__ int64_t s_idx[TK_SORT_MAX];
+    __shared__ float r_val[TK_MERGE_KMAX];    // running top-k
+    __shared__ int64_t r_idx[TK_MERGE_KMAX];
     const int q = blockIdx.x, t = threadIdx.x;
     const int raw = cand_cnt[q];
     const int cnt = raw < cap ? raw : cap;
-    const int n = k + cnt;
     int np2 = 1;
-    while (np2 < n) np2 <<= 1;
+    while (np2 < cnt) np2 <<= 1;
     for (int i = t; i < np2; i += TK_THREADS) {
-        float v = -INFINITY;
-        int64_t id = 0x7fffffffffffffffLL;
-        if (i < k) {
-            const int64_t r = run_idx[(long)q * k + i];
-            if (r >= 0) { v = run_val[(long)q * k + i]; id = r; }
-        } else if (i < n) {
-            v = cand_val[(long)q * cap + (i - k)];
-            id = cand_idx[(long)q * cap + (i - k)];
-        }
-        s_val[i] = v; s_idx[i] = id;
+        const bool ok = i < cnt;
+        s_val[i] = ok ? cand_val[(long)q * cap + i] : -INFINITY;
+        s_idx[i] = ok ? cand_idx[(long)q * cap + i] : 0x7fffffffffffffffLL;
+    }
+    int nrun = 0;                              // valid entries of the running list (they come first)
+    for (int i = t; i < k; i += TK_THREADS) {
+        const int64_t id = run_idx[(long)q * k + i];
+        r_val[i] = id >= 0 ? run_val[(long)q * k + i] : -INFINITY;
+        r_idx[i] = id >= 0 ? id : 0x7fffffffffffffffLL;
     }
     __syncthreads();
     if (t == 0) {
         cand_cnt[q] = 0;                       // ready for the next filtered chunk
         if (raw > cap) atomicOr(overflow, 1);
     }
-    bitonic_desc<true>(s_val, s_idx, np2, t);
-    for (int i = t; i < k; i += TK_THREADS) {
-        const bool ok = s_idx[i] != 0x7fffffffffffffffLL;
-        out_val[(long)q * k + i] = ok ? s_val[i] : -INFINITY;
-        out_idx[(long)q * k + i] = ok ? s_idx[i] : -1;
+    if (cnt > 1) bitonic_desc<true>(s_val, s_idx, np2, t);
+    nrun = count_before(r_val, r_idx, k, -INFINITY, 0x7fffffffffffffffLL);   // sentinels sort last
+    const int total = nrun + cnt;
+    for (int i = t; i < nrun; i += TK_THREADS) {
+        const int pos = i + count_before(s_val, s_idx, cnt, r_val[i], r_idx[i]);
+        if (pos < k) { out_val[(long)q * k + pos] = r_val[i]; out_idx[(long)q * k + pos] = r_idx[i]; }
     }
+    for (int j = t; j < cnt; j += TK_THREADS) {
+        const int pos = j + count_before(r_val, r_idx, nrun, s_val[j], s_idx[j]);
+        if (pos < k) { out_val[(long)q * k + pos] = s_val[j]; out_idx[(long)q * k + pos] = s_idx[j]; }
+    }
+    for (int i = total + t; i < k; i += TK_THREADS) { out_val[(long)q * k + i] = -INFINITY; out_idx[(long)q * k + i] = -1; }
 }
 
 }  // namespace

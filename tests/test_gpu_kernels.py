@@ -352,3 +352,21 @@ def test_topk_ties_take_lowest_indices_in_every_path(ctx):
     v, i, n = ctx.score_topk(q, c[:6000], 8, idx_base=0)
     v, i, n = ctx.score_topk(q, c[6000:], 8, idx_base=6000, run=(v, i, n))
     assert (i.cpu() == torch.arange(8)).all()
+
+
+@pytest.mark.parametrize("k", [100, 300, 1001])
+def test_score_topk_filtered_large_k(ctx, k):
+    """The BEIR driver retrieves top_k = 1000 (k + 1 = 1001 kept, exact_search.py:104): the filtered path covers
+    k <= 1024 (candidate capacity min(4k, 2048 - k); chunks grow by half when the capacity is below 2.5 k) and must
+    equal the materialise-and-select loop exactly."""
+    nq, N, d = 512, 150_000, 64
+    g = torch.Generator(device="cpu").manual_seed(k)
+    q = torch.randn(nq, d, generator=g).cuda().to(torch.bfloat16)
+    c = torch.randn(N, d, generator=g).cuda().to(torch.bfloat16)
+    val, idx, n = ctx.score_topk(q, c, k, idx_base=7)
+    wv, wi, wn = _sliced_classic(ctx, q, c, k, 40_000, idx_base=7)     # 40 000 < 2 chunks: materialised path
+    assert n == wn == k
+    assert torch.equal(val, wv) and torch.equal(idx, wi)
+    tv, _ = torch.topk(q.float() @ c.float().T, k, dim=1)
+    assert torch.max(torch.abs(val - tv)).item() < 1e-3 * float(tv.abs().max())
+    assert (val[:, :-1] >= val[:, 1:]).all() and (idx >= 7).all()
