@@ -148,6 +148,16 @@ sgpt_status sgpt_encode_layers(sgpt_model* model, const int32_t* ids, const int3
  * is clamped at 1e-9.  The n fp32 values are copied (device pointer); n must cover the longest padded sequence. */
 sgpt_status sgpt_model_set_pool_weights(sgpt_model* model, const float* weights, int32_t n);
 
+/* Cross-encoder scoring: log P(target | prefix) under the LM head for selected token rows.
+ * Replaces, for the rows that matter, `F.log_softmax(model(inps)[0], dim=-1)` + `torch.gather` + `argmax`
+ * of crossencoder/beir/sgptce.py:233-255.  hidden = the post-ln_f hidden states of sgpt_encode (`hidden_out`,
+ * fp32 [T_pad, d_model]); row_idx[i] = the token row whose next-token distribution is asked for, targets[i] the
+ * token id to score.  The LM head is the embedding matrix (GPT-Neo, BLOOM: tied) or "lm_head.weight" /
+ * "lm_head.bias" when those tensors were passed to sgpt_model_load (GPT-J).  Logits are computed in exact-fp32 MFMA.
+ *   out_logprob device fp32[n]; out_greedy device int32[n] (argmax token, first maximum) or NULL. */
+sgpt_status sgpt_lm_logprobs(sgpt_model* model, const float* hidden, const int32_t* row_idx, const int32_t* targets,
+                             int32_t n, float* out_logprob, int32_t* out_greedy, void* stream);
+
 /* Stand-alone pooling over caller-supplied hidden states (USEB layer sweeps, parity tests).
  * Replaces Pooling.forward (sentence_transformers/models/Pooling.py:99-125,129-164) and
  * CustomEmbedder.embed_batcher's pooling branch (beir_dense_retriever.py:238-282).

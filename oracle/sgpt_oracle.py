@@ -466,6 +466,48 @@ def pool(hidden, attention_mask, mode: str = "weightedmean", clamp: bool = True,
 
 
 # ----------------------------------------------------------------------------
+# cross-encoder scoring (crossencoder/beir/sgptce.py:150-262): log P(continuation | context)
+# ----------------------------------------------------------------------------
+def lm_head(w, cfg):
+    """LM head weight [V, d] (+ bias): GPT-Neo / BLOOM tie it to the input embedding (HF tie_word_embeddings),
+    GPT-J carries lm_head.weight / lm_head.bias."""
+    if "lm_head.weight" in w:
+        return w["lm_head.weight"], w.get("lm_head.bias")
+    return (w["word_embeddings.weight"] if "word_embeddings.weight" in w else w["wte.weight"]), None
+
+
+def log_softmax(x):
+    x = np.asarray(x, dtype=F32)
+    m = x.max(axis=-1, keepdims=True)
+    return (x - m - np.log(np.exp(x - m).sum(axis=-1, keepdims=True, dtype=F32))).astype(F32)
+
+
+def ce_model_input(context_enc, continuation_enc, max_length, instruction_len=0):
+    """sgptce.py:204-211: instruction kept, the rest truncated from the left, final token dropped."""
+    rest = (list(context_enc[instruction_len:]) + list(continuation_enc))[-(max_length + 1 - instruction_len):]
+    return (list(context_enc[:instruction_len]) + rest)[:-1]
+
+
+def loglikelihood_tokens(w, cfg, requests, max_length, instruction_len=0):
+    """`_loglikelihood_tokens` restated: per request the sum over the continuation tokens of
+    log_softmax(logits)[position - 1][token] (sgptce.py:233-259), batch size 1 as the reference's default."""
+    hw, hb = lm_head(w, cfg)
+    out = []
+    for _, ctx_enc, cont_enc in requests:
+        inp = ce_model_input(ctx_enc, cont_enc, max_length, instruction_len)
+        ids = np.asarray([inp], dtype=np.int64)
+        last = forward_any(w, cfg, ids, np.ones_like(ids))
+        logits = last[0] @ np.asarray(hw, dtype=F32).T
+        if hb is not None:
+            logits = logits + np.asarray(hb, dtype=F32)
+        lsm = log_softmax(logits)
+        n, c = len(inp), len(cont_enc)
+        rows = lsm[n - c:n]
+        out.append(float(rows[np.arange(c), np.asarray(cont_enc)].astype(np.float64).sum()))
+    return out
+
+
+# ----------------------------------------------------------------------------
 # fp8 (OCP e4m3fn) weight storage with a power-of-two scale per output channel
 # (SURVEY 8d cfg5: "fp8-e4m3fn weights, per-output-channel fp32 scales; the oracle uses the
 # de-quantised weights in fp32").  Pinned against torch.float8_e4m3fn (tests/golden/make_golden.py).

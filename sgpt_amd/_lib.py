@@ -46,6 +46,8 @@ SIGNATURES = {
                                          C.c_void_p]),
     "sgpt_fp8_dequantize_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                            C.c_int32, C.c_void_p]),
+    "sgpt_lm_logprobs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
     "sgpt_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                             C.c_int32, C.c_void_p, C.c_void_p]),
     "sgpt_l2_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

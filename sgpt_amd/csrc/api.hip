@@ -48,6 +48,7 @@ struct sgpt_model {
     float *emb_ln_g = nullptr, *emb_ln_b = nullptr, *alibi = nullptr;   // BLOOM: embedding LayerNorm, ALiBi slopes [H]
     float* zero_bias = nullptr;                      // [max(d, ffn)] zeros: bias-free projections (GPT-J out_proj)
     float* pool_w = nullptr; int pool_w_n = 0;       // learntmean position weights (sgpt_model_set_pool_weights)
+    float *lm_w = nullptr, *lm_b = nullptr;           // LM head [vocab, d] (+bias): tied to the embedding unless "lm_head.*" was given
     void* dq[4] = {nullptr, nullptr, nullptr, nullptr};   // SGPT_FP8W: bf16 scratch for the current block's qkv / o / fc / proj
     std::vector<void*> allocs;
 };
@@ -232,6 +233,13 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         m->alibi = copy_f32("alibi.slopes", H);
     } else {
         m->wpe = copy_f32("wpe.weight", (int64_t)d->max_pos * dm);
+    }
+    // LM head of the cross-encoder scorer (crossencoder/beir/sgptce.py): GPT-Neo / BLOOM tie it to the embedding
+    // (HF tie_word_embeddings), GPT-J carries lm_head.weight / lm_head.bias
+    m->lm_w = m->wte;
+    if (byname.count("lm_head.weight")) {
+        m->lm_w = copy_f32("lm_head.weight", (int64_t)d->vocab * dm);
+        if (byname.count("lm_head.bias")) m->lm_b = copy_f32("lm_head.bias", d->vocab);
     }
     m->lnf_g = copy_f32("ln_f.weight", dm);
     m->lnf_b = copy_f32("ln_f.bias", dm);
@@ -465,6 +473,34 @@ sgpt_status sgpt_model_set_pool_weights(sgpt_model* m, const float* w, int32_t n
     }
     m->pool_w_n = n;
     HIPC(c, hipMemcpy(m->pool_w, w, (size_t)n * 4, hipMemcpyDeviceToDevice));
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_lm_logprobs(sgpt_model* m, const float* hidden, const int32_t* row_idx, const int32_t* targets,
+                             int32_t n, float* out_logprob, int32_t* out_greedy, void* stream) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (!hidden || !row_idx || !targets || !out_logprob || n <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_lm_logprobs: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int dm = m->d.d_model, V = m->d.vocab;
+    const long ldv = (V + 3) / 4 * 4;
+    const int R = n < 1024 ? n : 1024;                       // rows per chunk: logits chunk [R, V] fp32 (206 MB at V = 50 257)
+    const size_t rows_bytes = align_up((size_t)R * dm * 4, 256), lg_bytes = align_up((size_t)R * ldv * 4, 256);
+    sgpt_status st = ensure(c, &c->ws2, &c->ws2_bytes, rows_bytes + lg_bytes);
+    if (st != SGPT_OK) return st;
+    float* rows = (float*)c->ws2;
+    float* logits = (float*)((char*)c->ws2 + rows_bytes);
+    for (int r0 = 0; r0 < n; r0 += R) {
+        const int nr = (n - r0) < R ? (n - r0) : R;
+        launch_gather_rows(hidden, row_idx + r0, nr, dm, rows, s);
+        GemmArgs g{};
+        g.A = rows; g.lda = dm; g.W = m->lm_w; g.ldw = dm; g.M = nr; g.m_valid = nr; g.N = V; g.K = dm;
+        g.out = logits; g.ldo = ldv; g.bias = m->lm_b;
+        gemm(c, SGPT_F32, EPI_STORE, SGPT_F32, g, s);          // exact fp32 MFMA: scores are sums of ~30 log-probabilities
+        launch_logprob_rows(logits, ldv, V, targets + r0, nr, out_logprob + r0, out_greedy ? out_greedy + r0 : nullptr, s);
+    }
+    HIPC(c, hipGetLastError());
     return SGPT_OK;
 }
 

@@ -144,6 +144,10 @@ void launch_fp8_quant_rows(const float* w, long rows, long cols, void* q, float*
 void launch_fp8_dequant_rows(const void* q, const float* scale, long rows, long cols, void* out, int out_dtype,
                              hipStream_t s);
 void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s);
+// cross-encoder scoring (sgptce.py): gather hidden rows; log_softmax + gather target + argmax per logits row
+void launch_gather_rows(const float* src, const int* row_idx, int n, int d, float* dst, hipStream_t s);
+void launch_logprob_rows(const float* logits, long ld, int V, const int* targets, int n, float* out_lp, int* out_arg,
+                         hipStream_t s);
 // out[i] = mean_j in[j][i], in fp32 [n0][n] (layer average of the meanmean / lasttokenmean methods)
 void launch_mean_over_axis0(const float* in, int n0, long n, float* out, hipStream_t s);
 void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s);

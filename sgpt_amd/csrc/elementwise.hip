@@ -331,6 +331,57 @@ __global__ __launch_bounds__(256) void mean_axis0_kernel(const float* __restrict
     out[i] = acc / (float)n0;
 }
 
+// ---- cross-encoder scoring: rows of the last hidden state -> log P(target | prefix) (crossencoder/beir/sgptce.py:150-262) ----
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ row_idx, int n,
+                                                          int d, float* __restrict__ dst) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float4* s4 = reinterpret_cast<const float4*>(src + (long)row_idx[r] * d);
+    float4* d4 = reinterpret_cast<float4*>(dst + (long)r * d);
+    for (int c = lane; c < d / 4; c += 64) d4[c] = s4[c];
+}
+
+// one workgroup per row of logits [n, ld]: log_softmax over the V entries, gathered at the target id
+// (F.log_softmax + torch.gather, sgptce.py:233,255), and the greedy token (argmax, first maximum, :243)
+__global__ __launch_bounds__(256) void logprob_rows_kernel(const float* __restrict__ logits, long ld, int V,
+                                                           const int* __restrict__ targets, float* __restrict__ out_lp,
+                                                           int* __restrict__ out_arg) {
+    __shared__ float s_f[4];
+    __shared__ int s_i[4];
+    const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* x = logits + (long)r * ld;
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int i = t; i < V; i += 256) {
+        const float v = x[i];
+        if (v > mx || (v == mx && i < am)) { mx = v; am = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(am, o, 64);
+        if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+    }
+    if (lane == 0) { s_f[wave] = mx; s_i[wave] = am; }
+    __syncthreads();
+    mx = s_f[0]; am = s_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (s_f[w] > mx || (s_f[w] == mx && s_i[w] < am)) { mx = s_f[w]; am = s_i[w]; }
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = t; i < V; i += 256) sum += expf(x[i] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) s_f[wave] = sum;
+    __syncthreads();
+    if (t == 0) {
+        const float tot = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
+        out_lp[r] = (x[targets[r]] - mx) - logf(tot);
+        if (out_arg) out_arg[r] = am;
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n, float v) {
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;
@@ -410,6 +461,15 @@ void launch_fp8_dequant_rows(const void* q, const float* scale, long rows, long 
     else
         hipLaunchKernelGGL(fp8_dequant_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const uint8_t*)q, scale, rows,
                            cols, (float*)out);
+}
+
+void launch_gather_rows(const float* src, const int* row_idx, int n, int d, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, src, row_idx, n, d, dst);
+}
+
+void launch_logprob_rows(const float* logits, long ld, int V, const int* targets, int n, float* out_lp, int* out_arg,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(logprob_rows_kernel, dim3(n), dim3(256), 0, s, logits, ld, V, targets, out_lp, out_arg);
 }
 
 void launch_mean_over_axis0(const float* in, int n0, long n, float* out, hipStream_t s) {

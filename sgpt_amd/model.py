@@ -148,7 +148,9 @@ class SGPTModel:
             if k2 == "position_weights":          # learntmean table riding along with the weights
                 continue
             if (k2.endswith("attn.attention.bias") or k2.endswith("attn.bias") or k2.endswith("masked_bias")
-                    or k2.endswith("embed_positions") or k2.startswith("lm_head")):
+                    or k2.endswith("embed_positions")):
+                continue
+            if k.startswith("lm_head") and not gptj:     # GPT-Neo / BLOOM tie the LM head to the embedding
                 continue
             t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
             t = t.to(device=self.device, dtype=torch.float32).contiguous()   # H2D staging only
@@ -259,6 +261,20 @@ class SGPTModel:
                                              1 if normalize else 0, _p(layers), _p(mean), _stream_ptr(self.device))
         _lib.check(self.ctx.handle, st, "sgpt_encode_layers")
         return (layers, mean) if per_layer else mean
+
+    def lm_logprobs(self, hidden: torch.Tensor, row_idx, targets, return_greedy: bool = False):
+        """log P(targets[i] | prefix ending at token row row_idx[i]) from post-ln_f hidden states [T_pad, d]
+        (the log_softmax + gather of crossencoder/beir/sgptce.py:233-255) -> fp32[n] on the GPU."""
+        ri = torch.as_tensor(np.asarray(row_idx, dtype=np.int32)).to(self.device)
+        tg = torch.as_tensor(np.asarray(targets, dtype=np.int32)).to(self.device)
+        n = int(ri.numel())
+        out = torch.empty((n,), dtype=torch.float32, device=self.device)
+        greedy = torch.empty((n,), dtype=torch.int32, device=self.device) if return_greedy else None
+        hidden = hidden.contiguous()
+        st = self.ctx.lib.sgpt_lm_logprobs(self.handle, _p(hidden), _p(ri), _p(tg), n, _p(out), _p(greedy),
+                                           _stream_ptr(self.device))
+        _lib.check(self.ctx.handle, st, "sgpt_lm_logprobs")
+        return (out, greedy) if return_greedy else out
 
     def plan_batches(self, lens: np.ndarray, max_sentences: Optional[int] = None) -> List[np.ndarray]:
         """Length-sorted (longest first, SentenceTransformer.py:148-149 / exact_search.py:66-71)

@@ -203,6 +203,7 @@ def main():
     if os.environ.get("GOLDEN_ONLY_EXTRAS"):
         _extras_cases()
         _tokenize_cases()
+        _crossencoder_case()
         return
     if only_j:
         _gptj_cases(Pooling)
@@ -232,6 +233,7 @@ def main():
     _gptj_cases(Pooling)
     _extras_cases()
     _tokenize_cases()
+    _crossencoder_case()
 
     # ---------------- scoring / top-k (reference util.py + exact_search.py) ----------------
     _scoring_cases(U, ES)
@@ -385,6 +387,48 @@ def _tokenize_cases():
     with open(os.path.join(HERE, "tokenize.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(f"wrote tokenize.json ({len(out['cases'])} cases from the reference's Transformer.tokenize / embed loop)")
+
+
+def _crossencoder_case():
+    """Cross-encoder log-probabilities from the reference's own `_loglikelihood_tokens` (crossencoder/beir/sgptce.py:93-262,
+    exec'd from its source: the module itself imports beir and runs a CLI at import) driving HF GPTNeoForCausalLM."""
+    import json
+    import collections
+    import torch.nn.functional as F
+    from transformers import GPTNeoConfig, GPTNeoForCausalLM
+    src = open(f"{REF}/crossencoder/beir/sgptce.py").read().split("\n")
+    ns = {"torch": torch, "F": F, "collections": collections, "tqdm": (lambda it, disable=False: it)}
+    exec(compile("\n".join(src[92:262]), "sgptce.py[93:262]", "exec"), ns)          # group, Reorderer, chunks, _model_call, _loglikelihood_tokens
+    cfg_kw = dict(vocab_size=211, max_position_embeddings=96, hidden_size=128, num_layers=4, num_heads=2, window_size=8)
+    cfg = O.NeoConfig(**cfg_kw)
+    w = O.synth_weights(cfg, seed=51, std=0.08)
+    hc = GPTNeoConfig(vocab_size=cfg.vocab_size, max_position_embeddings=cfg.max_position_embeddings, hidden_size=cfg.hidden_size,
+                      num_layers=cfg.num_layers, num_heads=cfg.num_heads, intermediate_size=cfg.intermediate_size,
+                      window_size=cfg.window_size, attention_types=[[["global", "local"], cfg.num_layers // 2]],
+                      layer_norm_epsilon=cfg.layer_norm_epsilon, attention_dropout=0.0, resid_dropout=0.0, embed_dropout=0.0,
+                      tie_word_embeddings=True)
+    hc._attn_implementation = "eager"
+    lm = GPTNeoForCausalLM(hc).eval()
+    missing, unexpected = lm.load_state_dict({"transformer." + k: torch.from_numpy(v.copy()) for k, v in w.items()}, strict=False)
+    assert not unexpected, unexpected
+    lm.tie_weights()
+    assert torch.equal(lm.lm_head.weight, lm.transformer.wte.weight)
+    rng = np.random.default_rng(510)
+    max_length, instruction_len = 48, 3
+    reqs = []
+    for n_ctx, n_cont in [(20, 5), (3, 1), (40, 9), (70, 12), (10, 30), (47, 2), (5, 5), (60, 48)]:   # several exceed max_length
+        reqs.append((("c", "q"), rng.integers(0, 211, size=n_ctx).tolist(), rng.integers(0, 211, size=n_cont).tolist()))
+    ref = ns["_loglikelihood_tokens"](reqs, lm, max_length, torch.device("cpu"), disable_tqdm=True, batch_size=1,
+                                      instruction_len=instruction_len)
+    ref_b3 = ns["_loglikelihood_tokens"](reqs, lm, max_length, torch.device("cpu"), disable_tqdm=True, batch_size=3,
+                                         instruction_len=instruction_len)
+    got = O.loglikelihood_tokens(w, cfg, reqs, max_length, instruction_len)
+    check("cross-encoder log-likelihoods (batch 1)", got, ref, 2e-4)
+    check("cross-encoder log-likelihoods (batch 3, right-padded)", got, ref_b3, 2e-4)
+    with open(os.path.join(HERE, "crossencoder.json"), "w") as f:
+        json.dump({"cfg": cfg_kw, "seed": 51, "std": 0.08, "max_length": max_length, "instruction_len": instruction_len,
+                   "requests": [[r[1], r[2]] for r in reqs], "loglikelihood": ref}, f)
+    print("wrote crossencoder.json", [round(x, 3) for x in ref])
 
 
 def _scoring_cases(U, ES):

@@ -275,3 +275,48 @@ def test_asym_two_tower_and_speca_adapters():
                           device="cuda:0", dtype="fp32")
         SentenceBERTBOSEOS(speca=True, model=small, tokenizer=SyntheticTokenizer(211), max_seq_length=8)
     mq.close(); md.close()
+
+
+def test_crossencoder_loglikelihood_vs_reference_golden():
+    """cross-encoder re-ranking scores = sum of log P(query token | prompted document ...) --
+    sgpt_lm_logprobs on the continuation rows of one packed forward vs the reference's `_loglikelihood_tokens`
+    output (tests/golden/crossencoder.json), then the GPTRanker surface against the oracle."""
+    from sgpt_amd import SGPTConfig, SGPTModel
+    from sgpt_amd.crossencoder import GPTRanker, loglikelihood_tokens, model_input
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    fx = json.load(open(f"{GOLDEN}/crossencoder.json"))
+    cfg = O.NeoConfig(**fx["cfg"])
+    w = O.synth_weights(cfg, seed=fx["seed"], std=fx["std"])
+    reqs = [(("c", "q"), c, q) for c, q in fx["requests"]]
+    want = np.asarray(fx["loglikelihood"])
+    m = SGPTModel(SGPTConfig(**fx["cfg"]), w, device="cuda:0", dtype="fp32")
+    got = np.asarray(loglikelihood_tokens(reqs, m, fx["max_length"], instruction_len=fx["instruction_len"]))
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-3
+    small = np.asarray(loglikelihood_tokens(reqs, m, fx["max_length"], instruction_len=fx["instruction_len"], max_tokens_per_call=64))
+    assert np.max(np.abs(small - got)) < 1e-3                       # batching does not matter
+    # greedy tokens = argmax of the same logits
+    inp = model_input(reqs[0][1], reqs[0][2], fx["max_length"], fx["instruction_len"])
+    pb = m.pack([inp])
+    _, hid = m.encode_packed(pb, return_hidden=True)
+    lp, greedy = m.lm_logprobs(hid, list(range(len(inp))), [0] * len(inp), return_greedy=True)
+    last = O.forward_any(w, cfg, np.asarray([inp]), np.ones((1, len(inp)), dtype=np.int64))
+    logits = last[0] @ w["wte.weight"].T
+    assert (greedy.cpu().numpy() == logits.argmax(-1)).mean() > 0.95      # ties / 1e-6 differences aside
+    assert np.max(np.abs(lp.cpu().numpy() - O.log_softmax(logits)[:, 0])) < 1e-3
+    # bf16 model: ranking scores stay close
+    mb = SGPTModel(SGPTConfig(**fx["cfg"]), w, device="cuda:0", dtype="bf16")
+    gb = np.asarray(loglikelihood_tokens(reqs, mb, fx["max_length"], instruction_len=fx["instruction_len"]))
+    assert np.max(np.abs(gb - want) / np.maximum(1.0, np.abs(want))) < 3e-2
+    # GPTRanker.predict (prompted documents, few-shot prefix) vs the oracle on the same token ids
+    tok = SyntheticTokenizer(211)
+    rk = GPTRanker(m, tok, max_length=64, prompt_doc="Document : {}\nQuery :", fewshots=("a doc", "a query"),
+                   prompt_doc_start="Document : {}\nQuery : {}\n")
+    pairs = [("what is the capital of france", "paris is the capital of france . " * 4), ("river", "the seine")]
+    scores = rk.predict(pairs, batch_size=8)
+    oreqs = []
+    for qtext, doc in pairs:
+        ctx_ids = tok.encode(rk.fewshots + rk.prompt_doc.format(doc))
+        oreqs.append((("c", "q"), ctx_ids, tok.encode(qtext)))
+    owant = O.loglikelihood_tokens(w, cfg, oreqs, 64, rk.instruction_len)
+    assert np.max(np.abs(np.asarray(scores) - np.asarray(owant)) / np.maximum(1.0, np.abs(owant))) < 1e-3
+    m.close(); mb.close()

@@ -165,3 +165,17 @@ def test_extras_golden_learntmean_and_fp8():
     if hasattr(torch, "float8_e4m3fn"):
         t8 = torch.from_numpy(x.astype(np.float32)).to(torch.float8_e4m3fn)
         assert np.array_equal(t8.view(torch.uint8).numpy(), codes)
+
+
+def test_crossencoder_loglikelihood_golden():
+    """Cross-encoder scores: golden = the reference's own `_loglikelihood_tokens` (crossencoder/beir/sgptce.py) on HF
+    GPTNeoForCausalLM; includes requests longer than max_length (left truncation behind the instruction)."""
+    fx = json.load(open(os.path.join(GOLDEN, "crossencoder.json")))
+    cfg = O.NeoConfig(**fx["cfg"])
+    w = O.synth_weights(cfg, seed=fx["seed"], std=fx["std"])
+    reqs = [(("c", "q"), c, q) for c, q in fx["requests"]]
+    got = O.loglikelihood_tokens(w, cfg, reqs, fx["max_length"], fx["instruction_len"])
+    assert np.max(np.abs(np.asarray(got) - np.asarray(fx["loglikelihood"]))) < 2e-4
+    # truncation rule: instruction kept, rest cut from the left, last token dropped
+    inp = O.ce_model_input(list(range(100, 170)), list(range(12)), 48, 3)
+    assert inp[:3] == [100, 101, 102] and len(inp) == 48 and inp[-1] == 10 and inp[3] == 100 + 70 - (46 - 12)
