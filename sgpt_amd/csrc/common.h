@@ -41,6 +41,17 @@ __device__ __forceinline__ void gstore16(void* ptr, uint4 v) {
 }
 
 template <bool NT>
+__device__ __forceinline__ uint4 ldg16u(const void* ptr) {
+    if constexpr (NT) {
+        typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4)));
+        const u32x4v_t w = __builtin_nontemporal_load(reinterpret_cast<const u32x4v_t*>(ptr));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        return *reinterpret_cast<const uint4*>(ptr);
+    }
+}
+
+template <bool NT>
 __device__ __forceinline__ float4 ldg16(const float* ptr) {
     if constexpr (NT) {
         typedef float f32x4v_t __attribute__((ext_vector_type(4)));
