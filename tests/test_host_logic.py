@@ -237,3 +237,20 @@ def test_library_is_not_older_than_its_sources():
     srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".inc"))]
     stale = [os.path.basename(s) for s in srcs if os.path.getmtime(s) > so + 1.0]
     assert not stale, f"libsgpt_hip.so is older than {stale}: run `python -m sgpt_amd.build`"
+
+
+def test_crossencoder_host_logic_matches_oracle():
+    """Truncation rule and request encoding of the cross-encoder surface (crossencoder/beir/sgptce.py:77-91,204-211)."""
+    from sgpt_amd.crossencoder import encode, model_input
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    rng = np.random.default_rng(0)
+    for n_ctx, n_cont, max_len, instr in [(20, 5, 48, 3), (70, 12, 48, 3), (60, 48, 48, 0), (1, 1, 16, 0), (100, 7, 32, 10)]:
+        c, q = rng.integers(0, 99, n_ctx).tolist(), rng.integers(0, 99, n_cont).tolist()
+        assert model_input(c, q, max_len, instr) == O.ce_model_input(c, q, max_len, instr)
+        assert len(model_input(c, q, max_len, instr)) <= max_len
+    tok = SyntheticTokenizer(300)
+    reqs = encode([("a query", "some context text"), ("q", "")], tok)
+    assert reqs[0][1] == tok.encode("some context text") and reqs[0][2] == tok.encode("a query")
+    assert reqs[1][1] == [tok.eos_token_id]                    # empty context -> end-of-text token
+    with pytest.raises(AssertionError):
+        model_input([1, 2, 3], list(range(50)), 48, 0)         # continuation longer than max_length
