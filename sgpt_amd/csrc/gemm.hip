@@ -639,519 +639,6 @@ void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Variant 4W: the same 256x256x64 tile computed by FOUR waves (2 x 2, 128x128 per wave, one wave per SIMD,
-// up to 512 VGPR+AGPR per lane).  What it buys over the 8-wave kernel (s_memtime: 2 700 ticks per k-step
-// against 2 048 MFMA cycles there):
-//  * fragments are double-buffered in registers (2 x 16 x uint4): the ds_reads of k-chunk c+1 run under the
-//    MFMAs of chunk c, so no fragment-load latency sits behind the barrier;
-//  * ONE barrier per k-step, placed MID-step: the chunk-1 MFMAs that follow it already have their operands
-//    in registers.  Ring discipline: stage s holds k-step s.  Phase A(s) = MFMAs on chunk 0 | ds_read chunk 1
-//    of stage s.  Mid-step: my LDS reads done (lgkmcnt 0), DMA of k-step s+1 landed (vmcnt 0), barrier.
-//    Phase B(s) = MFMAs on chunk 1 | ds_read chunk 0 of stage s^1 (k-step s+1) | DMA of k-step s+2 into
-//    stage s (free: everybody passed the barrier after reading it).  The DMA stream runs two k-steps ahead
-//    and continues across tile boundaries, so a tile switch costs no barrier at all;
-//  * LDS reads per k-step: 4 waves x 32 KiB = 128 KiB instead of 192 KiB.
-// The epilogue transposes through a separate 32-KiB scratch (8 KiB per wave): both stages stay in flight.
-template <int EPI, typename OutT, bool SWAP>
-__global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmArgs p) {
-    typedef __attribute__((address_space(3))) char* lds_cptr_t;
-    constexpr int TM = 256, TN = 256;
-    __shared__ __attribute__((aligned(16))) uint4 lds[2][2][TM * CH];      // 128 KiB: [stage][A|W][row][chunk]
-    __shared__ __attribute__((aligned(16))) char scratch[4][8192];          // 32 KiB: per-wave epilogue transpose
-
-    const int N = p.N, K = p.K;
-    const int MT = p.M / TM, NT = N / TN;
-    constexpr int GM = 4, GN = 8;
-    const bool m_major = MT >= NT;
-    const int AT = m_major ? MT : NT, BT = m_major ? NT : MT;
-    const int per_band = GM * BT;
-    const int tiles_total = ((AT + 7) / 8 + GM - 1) / GM * GM * 8 * BT;
-    auto tile_coords = [&](int tile, int& m0, int& n0) -> bool {
-        const int xcd = tile & 7, local = tile >> 3;
-        const int band = local / per_band, inb = local % per_band;
-        const int ng = inb / (GM * GN);
-        const int gn = (BT - ng * GN) < GN ? (BT - ng * GN) : GN;
-        const int r = inb - ng * GM * GN;
-        const int at = xcd + 8 * (band * GM + r / gn), bt = ng * GN + r % gn;
-        m0 = (m_major ? at : bt) * TM; n0 = (m_major ? bt : at) * TN;
-        return at < AT;
-    };
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 15, g = lane >> 4;
-
-    // LDS-DMA: wave w fills rows [64w, 64w+64) of both operands, 8 rows (1 KiB) per instruction
-    const bf16_t* __restrict__ Ag = static_cast<const bf16_t*>(p.A);
-    const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(p.W);
-    const int lrow = wave * 64 + (lane >> 3);
-    const int lchunk = (lane & 7) ^ (lane >> 3);
-    const long astep = 8 * p.lda, wstep = 8 * p.ldw;
-    const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0][0][0]);
-    auto dma16 = [&](const bf16_t* src, unsigned dst_byte) {
-        unsigned keep;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(dst_byte);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "s"(dst)
-                     : "memory");
-    };
-    auto piece = [&](const bf16_t* asrc, const bf16_t* wsrc, int kt, int st, int q) {   // pieces q = 0..7 of A and of W
-        const unsigned row_off = (unsigned)((wave * 64 + q * 8) * CH * 16);
-        dma16(asrc + q * astep + kt * 64, lds_base + (unsigned)((st * 2 + 0) * TM * CH * 16) + row_off);
-        dma16(wsrc + q * wstep + kt * 64, lds_base + (unsigned)((st * 2 + 1) * TM * CH * 16) + row_off);
-    };
-
-    struct Frag { uint4 a[8], w[8]; };
-    auto ld_a = [&](int st, int ks, int i) -> uint4 {
-        const int row = wm * 128 + i * 16 + fr;
-        return lds[st][0][row * CH + ((4 * ks + g) ^ (row & 7))];
-    };
-    auto ld_w = [&](int st, int ks, int j) -> uint4 {
-        const int row = wn * 128 + j * 16 + fr;
-        return lds[st][1][row * CH + ((4 * ks + g) ^ (row & 7))];
-    };
-
-    f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / 64;      // >= 2 (launcher)
-    OutT* __restrict__ out = static_cast<OutT*>(p.out);
-
-    int tile = blockIdx.x, m0 = 0, n0 = 0;
-    while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
-    if (tile >= tiles_total) return;
-
-    // DMA cursor: the k-step that the NEXT phase B will fetch (two steps ahead of the MFMAs)
-    int c_tile = tile, c_kt = 0;
-    const bf16_t* c_a = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
-    const bf16_t* c_w = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
-    auto advance = [&]() {
-        if (++c_kt < nk) return;
-        int nt = c_tile + gridDim.x, a0 = 0, b0 = 0;
-        while (nt < tiles_total && !tile_coords(nt, a0, b0)) nt += gridDim.x;
-        c_kt = 0;
-        if (nt < tiles_total) {          // past the last tile the cursor re-fetches its own tile (harmless, branch-free issue)
-            c_tile = nt;
-            c_a = Ag + (long)(a0 + lrow) * p.lda + lchunk * 8;
-            c_w = Wg + (long)(b0 + lrow) * p.ldw + lchunk * 8;
-        }
-    };
-    int dbg_tile = 0;
-    // prologue: k-steps 0 and 1 of the first tile
-#pragma unroll
-    for (int q = 0; q < 8; ++q) piece(c_a, c_w, 0, 0, q);
-    advance();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) piece(c_a, c_w, c_kt, 1, q);
-    advance();
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // step 0 landed (16 pieces of step 1 may be in flight)
-    __syncthreads();
-    Frag f0, f1;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { f0.a[i] = ld_a(0, 0, i); f0.w[i] = ld_w(0, 0, i); }
-    int st = 0;
-
-    while (true) {
-        for (int kt = 0; kt < nk; ++kt) {
-            if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 4 && kt < 12)
-                p.dbg[64 + dbg_tile * 16 + kt] = (long long)__builtin_amdgcn_s_memtime();
-            // ---- phase A: chunk 0 from f0; fetch chunk 1 of this stage into f1
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) mma<bf16_t, SWAP>(acc[i][j], f0.a[i], f0.w[j]);
-                f1.a[i] = ld_a(st, 1, i);
-                f1.w[i] = ld_w(st, 1, i);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            // ---- phase B: chunk 1 from f1; fetch chunk 0 of the next k-step into f0; DMA two steps ahead into this stage
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) mma<bf16_t, SWAP>(acc[i][j], f1.a[i], f1.w[j]);
-                f0.a[i] = ld_a(st ^ 1, 0, i);
-                f0.w[i] = ld_w(st ^ 1, 0, i);
-                piece(c_a, c_w, c_kt, st, i);
-            }
-            advance();
-            st ^= 1;
-        }
-        if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 8) p.dbg[dbg_tile * 8 + 0] = (long long)__builtin_amdgcn_s_memtime();
-
-        // ---------------- epilogue (per wave, 128 x 128, two 64-column halves through 8 KiB of scratch) -------------
-        char* scr = &scratch[wave][0];
-        if constexpr (EPI == EPI_NONE) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    asm volatile("" ::"v"(acc[i][j]));
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-        } else if constexpr (SWAP && sizeof(OutT) == 2) {
-            // bf16 row-major: per (i, half) 16 rows x 128 B, LDS row stride 144 B
-            constexpr int RS = 144;
-            const int rrow = lane >> 3, rchunk = lane & 7;
-            const bool has_bias = EPI == EPI_BIAS_GELU || p.bias != nullptr;
-#pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {
-                float4 bb[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    bb[j] = has_bias ? *reinterpret_cast<const float4*>(p.bias + n0 + wn * 128 + jh * 64 + j * 16 + 4 * g)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4& c = acc[i][jh * 4 + j];
-                        float v[4] = {c[0], c[1], c[2], c[3]};
-                        if constexpr (EPI == EPI_BIAS_GELU) {
-                            v[0] = gelu_new_fast(v[0] + bb[j].x); v[1] = gelu_new_fast(v[1] + bb[j].y);
-                            v[2] = gelu_new_fast(v[2] + bb[j].z); v[3] = gelu_new_fast(v[3] + bb[j].w);
-                        } else {
-                            v[0] += bb[j].x; v[1] += bb[j].y; v[2] += bb[j].z; v[3] += bb[j].w;
-                        }
-                        *reinterpret_cast<uint2_a*>(scr + fr * RS + (j * 16 + 4 * g) * 2) =
-                            make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                        c = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int row = h * 8 + rrow;
-                        const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
-                        const int m = m0 + wm * 128 + i * 16 + row;
-                        gstore16<true>(reinterpret_cast<bf16_t*>(out) + (long)m * p.ldo + n0 + wn * 128 + jh * 64 + rchunk * 8, v);
-                    }
-                }
-            }
-        } else if constexpr (SWAP) {
-            // fp32 row-major (+bias +residual | score): per (i, half) 16 rows x 256 B, LDS row stride 272 B
-            constexpr int RS = 272;
-            const int rrow = lane >> 4, rchunk = lane & 15;
-#pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {
-                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (EPI == EPI_BIAS_RESID) bb = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 128 + jh * 64 + rchunk * 4);
-                const long gbase = (long)(m0 + wm * 128 + rrow) * p.ldo + n0 + wn * 128 + jh * 64 + rchunk * 4;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float4 rr[4];
-                    if constexpr (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-                        for (int h = 0; h < 4; ++h) rr[h] = ldg16<RESID_LD_NT>(p.resid + gbase + (long)(i * 16 + h * 4) * p.ldo);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4& c = acc[i][jh * 4 + j];
-                        *reinterpret_cast<float4_a*>(scr + fr * RS + (j * 16 + 4 * g) * 4) = make_float4(c[0], c[1], c[2], c[3]);
-                        c = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        float4 v = *reinterpret_cast<const float4_a*>(scr + (h * 4 + rrow) * RS + rchunk * 16);
-                        if constexpr (EPI == EPI_BIAS_RESID) {
-                            v.x += bb.x + rr[h].x; v.y += bb.y + rr[h].y; v.z += bb.z + rr[h].z; v.w += bb.w + rr[h].w;
-                        }
-                        if constexpr (EPI == EPI_SCORE) {
-                            v.x = v.x != v.x ? -1.0f : v.x; v.y = v.y != v.y ? -1.0f : v.y;
-                            v.z = v.z != v.z ? -1.0f : v.z; v.w = v.w != v.w ? -1.0f : v.w;
-                            if (m0 + wm * 128 + i * 16 + h * 4 + rrow >= p.m_valid) continue;
-                        }
-                        gstore16<RESID_NT>(reinterpret_cast<float*>(out) + gbase + (long)(i * 16 + h * 4) * p.ldo, __builtin_bit_cast(uint4, v));
-                    }
-                }
-            }
-        } else {
-            // V^T (bf16, out[n][m]): per j 16 n-rows x 256 B (128 m), LDS row stride 272 B
-            constexpr int RS = 272;
-            const int rrow = lane >> 4, rchunk = lane & 15;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float bn = p.bias ? p.bias[n0 + wn * 128 + j * 16 + fr] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    f32x4& c = acc[i][j];
-                    *reinterpret_cast<uint2_a*>(scr + fr * RS + (i * 16 + 4 * g) * 2) =
-                        make_uint2(pack_bf16x2(c[0] + bn, c[1] + bn), pack_bf16x2(c[2] + bn, c[3] + bn));
-                    c = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int row = h * 4 + rrow;
-                    const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
-                    const int n = n0 + wn * 128 + j * 16 + row;
-                    gstore16<true>(reinterpret_cast<bf16_t*>(out) + (long)n * p.ldo + m0 + wm * 128 + rchunk * 8, v);
-                }
-            }
-        }
-        if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 8) p.dbg[dbg_tile * 8 + 3] = (long long)__builtin_amdgcn_s_memtime();
-        ++dbg_tile;
-
-        int ntile = tile + gridDim.x;
-        while (ntile < tiles_total && !tile_coords(ntile, m0, n0)) ntile += gridDim.x;
-        if (ntile >= tiles_total) break;
-        tile = ntile;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead DMA before the LDS is released
-}
-
-template <int EPI, typename OutT, bool SWAP>
-void launch4w(const GemmArgs& a, hipStream_t s) {
-    const int MT = a.M / 256, NT = a.N / 256;
-    const int AT = MT >= NT ? MT : NT, BT = MT >= NT ? NT : MT;
-    const int tiles_total = ((AT + 7) / 8 + 3) / 4 * 4 * 8 * BT;
-    static const int ncu = [] {
-        int dev = 0, n = 256;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n / 8 * 8;
-    }();
-    const int grid = tiles_total < ncu ? tiles_total : ncu;
-    hipLaunchKernelGGL((gemm4w_kernel<EPI, OutT, SWAP>), dim3(grid), dim3(256), 0, s, a);
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Variant P2: 256x128 tile, 4 waves (2 x 2, 128x64 per wave), BK = 32, three LDS stages of 24 KiB
-// (72 KiB per workgroup) -> TWO persistent workgroups per CU.  Rationale (s_memtime stamps of
-// gemm256_kernel): the k-loop alone runs at 1350 TFLOP/s but the epilogue of a tile (LDS transpose,
-// residual read-modify-write, stores) leaves the matrix pipe idle; with two independent workgroups
-// per CU one's epilogue runs under the other's MFMAs.  Pipeline: DMA of k-step s+2 is issued at the
-// top of step s; `s_waitcnt vmcnt(6)` (6 DMA pieces per wave per step) keeps one step in flight
-// across the barrier (counted vmcnt is exact while only loads are pending; loads retire in order).
-// 64-byte LDS rows: 16-B chunk index is XORed with (row>>2)&3 -> 16 lanes of a ds_read_b128 group
-// hit 16 different 16-B slots.
-template <int EPI, typename OutT, bool SWAP>
-__global__ __launch_bounds__(256, 2) void gemm_p2_kernel(const GemmArgs p) {
-    typedef __attribute__((address_space(3))) char* lds_cptr_t;
-    constexpr int TM = 256, TN = 128, NST = 3, CHK = 4, ROWS = TM + TN;
-    constexpr int STAGE_U4 = ROWS * CHK;                       // uint4 per stage (24 KiB)
-    __shared__ __attribute__((aligned(16))) uint4 lds[NST][STAGE_U4];
-
-    const int N = p.N, K = p.K;
-    const int MT = p.M / TM, NT = N / TN;
-    constexpr int GM = 8, GN = 8;                              // 64 tiles in flight per XCD
-    const int per_band = GM * NT;
-    const int tiles_total = ((MT + 7) / 8 + GM - 1) / GM * GM * 8 * NT;
-    auto tile_coords = [&](int tile, int& m0, int& n0) -> bool {
-        const int xcd = tile & 7, local = tile >> 3;
-        const int band = local / per_band, inb = local % per_band;
-        const int ng = inb / (GM * GN);
-        const int gn = (NT - ng * GN) < GN ? (NT - ng * GN) : GN;
-        const int r = inb - ng * GM * GN;
-        const int mt = xcd + 8 * (band * GM + r / gn), nt = ng * GN + r % gn;
-        m0 = mt * TM; n0 = nt * TN;
-        return mt < MT;
-    };
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 15, g = lane >> 4;
-
-    // LDS-DMA: 24 pieces of 16 rows x 64 B per k-step; wave w issues pieces w, w+4, ..., w+20
-    // (4 of A, 2 of W).  lane l -> LDS (row l>>2, slot l&3) <- global chunk (l&3) ^ (l>>4).
-    const bf16_t* __restrict__ Ag = static_cast<const bf16_t*>(p.A);
-    const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(p.W);
-    const int lrow = wave * 16 + (lane >> 2);
-    const int lchunk = (lane & 3) ^ (lane >> 4);
-    const long astep = 64 * p.lda, wstep = 64 * p.ldw;
-    const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0][0]);
-    auto dma16 = [&](const bf16_t* src, unsigned dst_byte) {
-        unsigned keep;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(dst_byte);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "s"(dst)
-                     : "memory");
-    };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // one k-step (32 wide): 12 fragment reads, 32 MFMAs, the 6 DMA pieces of step s+2 spread behind them
-    auto kstep = [&](int st, int dst_st, const bf16_t* ia, const bf16_t* iw, int ikt) {
-        uint4 af[8], wf[4];
-        const uint4* sp = lds[st];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = TM + wn * 64 + j * 16 + fr;
-            wf[j] = sp[row * CHK + (g ^ ((row >> 2) & 3))];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = wm * 128 + i * 16 + fr;
-            af[i] = sp[row * CHK + (g ^ ((row >> 2) & 3))];
-        }
-        const unsigned dbase = lds_base + (unsigned)(dst_st * STAGE_U4 * 16);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma<bf16_t, SWAP>(acc[i][j], af[i], wf[j]);
-            if (i < 4) dma16(ia + i * astep + ikt * 32, dbase + (unsigned)((wave + 4 * i) * 1024));
-            else if (i < 6) dma16(iw + (i - 4) * wstep + ikt * 32, dbase + (unsigned)((16 + wave + 4 * (i - 4)) * 1024));
-        }
-    };
-    auto issue_all = [&](int dst_st, const bf16_t* ia, const bf16_t* iw, int ikt) {
-        const unsigned dbase = lds_base + (unsigned)(dst_st * STAGE_U4 * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(ia + i * astep + ikt * 32, dbase + (unsigned)((wave + 4 * i) * 1024));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(iw + i * wstep + ikt * 32, dbase + (unsigned)((16 + wave + 4 * i) * 1024));
-    };
-
-    const int nk = K / 32;   // >= 2
-    OutT* __restrict__ out = static_cast<OutT*>(p.out);
-
-    int tile = blockIdx.x, m0 = 0, n0 = 0;
-    while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
-    if (tile >= tiles_total) return;
-    const bf16_t* asrc = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
-    const bf16_t* wsrc = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
-    int st = 0;               // stage of the step being computed
-    int skip_wait = 0;        // steps whose DMA was already waited for before the previous epilogue
-    issue_all(0, asrc, wsrc, 0);
-    issue_all(1, asrc, wsrc, 1);
-    while (true) {
-        int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
-        while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
-        const bool has_next = ntile < tiles_total;
-        const bf16_t* nasrc = has_next ? Ag + (long)(nm0 + lrow) * p.lda + lchunk * 8 : asrc;
-        const bf16_t* nwsrc = has_next ? Wg + (long)(nn0 + lrow) * p.ldw + lchunk * 8 : wsrc;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (skip_wait > 0) --skip_wait;
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // DMA of this step landed; next step's may fly
-            __syncthreads();
-            // prefetch step kt+2 (of this tile, or steps 0/1 of the next; past the very end: harmless re-fetch)
-            const int pk = kt + 2;
-            const bool intile = pk < nk;
-            int st2 = st + 2; st2 = st2 >= NST ? st2 - NST : st2;
-            kstep(st, st2, intile ? asrc : nasrc, intile ? wsrc : nwsrc, intile ? pk : pk - nk);
-            st = st + 1 == NST ? 0 : st + 1;
-        }
-        // the next tile's first two k-steps were issued before any store of this epilogue: wait for them now
-        // (loads only -> exact), so the stores below get two k-steps to drain before the next counted wait
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        skip_wait = 2;
-        __syncthreads();  // every wave is done with the stage just consumed: it becomes the epilogue scratch
-        int stc = st - 1; stc = stc < 0 ? stc + NST : stc;
-        char* scr = reinterpret_cast<char*>(&lds[stc][0]) + wave * 6144;
-        if constexpr (EPI == EPI_NONE) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    asm volatile("" ::"v"(acc[i][j]));
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-        } else if constexpr (SWAP && sizeof(OutT) == 2) {
-            constexpr int RS = 144;
-            const int rrow = lane >> 3, rchunk = lane & 7;
-            float4 bb[4];
-            if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 16 + 4 * g);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    if constexpr (EPI == EPI_BIAS_GELU) {
-                        v[0] = gelu_new_fast(v[0] + bb[j].x); v[1] = gelu_new_fast(v[1] + bb[j].y);
-                        v[2] = gelu_new_fast(v[2] + bb[j].z); v[3] = gelu_new_fast(v[3] + bb[j].w);
-                    }
-                    *reinterpret_cast<uint2_a*>(scr + fr * RS + (j * 16 + 4 * g) * 2) =
-                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = h * 8 + rrow;
-                    const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
-                    const int m = m0 + wm * 128 + i * 16 + row;
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (long)m * p.ldo + n0 + wn * 64 + rchunk * 8) = v;
-                }
-            }
-        } else if constexpr (SWAP) {
-            constexpr int RS = 272;
-            const int rrow = lane >> 4, rchunk = lane & 15;
-            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (EPI == EPI_BIAS_RESID) bb = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + rchunk * 4);
-            const long gbase = (long)(m0 + wm * 128 + rrow) * p.ldo + n0 + wn * 64 + rchunk * 4;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float4 rr[4];
-                if constexpr (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-                    for (int h = 0; h < 4; ++h)
-                        rr[h] = *reinterpret_cast<const float4*>(p.resid + gbase + (long)(i * 16 + h * 4) * p.ldo);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    *reinterpret_cast<float4_a*>(scr + fr * RS + (j * 16 + 4 * g) * 4) =
-                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    float4 v = *reinterpret_cast<const float4_a*>(scr + (h * 4 + rrow) * RS + rchunk * 16);
-                    if constexpr (EPI == EPI_BIAS_RESID) {
-                        v.x += bb.x + rr[h].x; v.y += bb.y + rr[h].y; v.z += bb.z + rr[h].z; v.w += bb.w + rr[h].w;
-                    }
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + gbase + (long)(i * 16 + h * 4) * p.ldo) = v;
-                }
-            }
-        } else {
-            constexpr int RS = 272;
-            const int rrow = lane >> 4, rchunk = lane & 15;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    *reinterpret_cast<uint2_a*>(scr + fr * RS + (i * 16 + 4 * g) * 2) =
-                        make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int row = h * 4 + rrow;
-                    const uint4 v = *reinterpret_cast<const uint4_a*>(scr + row * RS + rchunk * 16);
-                    const int n = n0 + wn * 64 + j * 16 + row;
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (long)n * p.ldo + m0 + wm * 128 + rchunk * 8) = v;
-                }
-            }
-        }
-        if (!has_next) break;
-        tile = ntile; m0 = nm0; n0 = nn0; asrc = nasrc; wsrc = nwsrc;
-    }
-}
-
-template <int EPI, typename OutT, bool SWAP>
-void launch_p2(const GemmArgs& a, hipStream_t s) {
-    const int MT = a.M / 256, NT = a.N / 128;
-    const int tiles_total = ((MT + 7) / 8 + 7) / 8 * 8 * 8 * NT;
-    static const int ncu = [] {
-        int dev = 0, n = 256;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n / 8 * 8;
-    }();
-    const int grid = tiles_total < 2 * ncu ? tiles_total : 2 * ncu;
-    hipLaunchKernelGGL((gemm_p2_kernel<EPI, OutT, SWAP>), dim3(grid), dim3(256), 0, s, a);
-}
-
 template <typename T, int EPI, typename OutT, bool SWAP>
 void launch(const GemmArgs& a, hipStream_t s) {
     // 64x64 tiles when 128x128 ones would leave most of the 256 CUs idle (short query batches, USEB's 21-32 sentence
@@ -1172,15 +659,6 @@ void launch(const GemmArgs& a, hipStream_t s) {
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     const bool bf = dtype == 1, obf = out_dtype == 1;
     static const bool use256 = getenv("SGPT_GEMM128") == nullptr;
-    static const bool use_p2 = getenv("SGPT_GEMM_P2") != nullptr;
-    if (bf && use_p2 && a.M % 256 == 0 && a.N % 128 == 0 && a.K % 32 == 0 && a.K >= 64 && a.m_valid == a.M &&
-        !((epi == EPI_STORE || epi == EPI_VT) && a.bias != nullptr)) {
-        if (epi == EPI_STORE && obf) return launch_p2<EPI_STORE, bf16_t, true>(a, s);
-        if (epi == EPI_VT) return launch_p2<EPI_VT, bf16_t, false>(a, s);
-        if (epi == EPI_BIAS_GELU) return launch_p2<EPI_BIAS_GELU, bf16_t, true>(a, s);
-        if (epi == EPI_BIAS_RESID) return launch_p2<EPI_BIAS_RESID, float, true>(a, s);
-        if (epi == EPI_NONE) return launch_p2<EPI_NONE, bf16_t, true>(a, s);
-    }
     // Small problems (short query batches, USEB's 21-32 sentence calls): fewer than half a wave of 256x256 tiles
     // leaves most of the 256 CUs idle; the register-staged kernel's 128x128 / 64x64 tiles fill the chip instead.
     // Bit-identical results (see gemm_kernel), so the embeddings stay batch-invariant.  SGPT_NO_SMALL_TILE=1: A/B.
@@ -1197,15 +675,6 @@ void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream
         if (epi == EPI_BIAS_GELU) return launch256d<EPI_BIAS_GELU, bf16_t, true>(a, s, deep_a);
         if (epi == EPI_BIAS_RESID) return launch256d<EPI_BIAS_RESID, float, true>(a, s, deep_a);
         if (epi == EPI_NONE) return launch256d<EPI_NONE, bf16_t, true>(a, s, deep_a);
-    }
-    static const bool use4w = getenv("SGPT_GEMM4W") != nullptr;
-    if (bf && use4w && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 && (a.m_valid == a.M || epi == EPI_SCORE)) {
-        if (epi == EPI_SCORE) return launch4w<EPI_SCORE, float, true>(a, s);
-        if (epi == EPI_STORE && obf) return launch4w<EPI_STORE, bf16_t, true>(a, s);
-        if (epi == EPI_VT) return launch4w<EPI_VT, bf16_t, false>(a, s);
-        if (epi == EPI_BIAS_GELU) return launch4w<EPI_BIAS_GELU, bf16_t, true>(a, s);
-        if (epi == EPI_BIAS_RESID) return launch4w<EPI_BIAS_RESID, float, true>(a, s);
-        if (epi == EPI_NONE) return launch4w<EPI_NONE, bf16_t, true>(a, s);
     }
     if (epi == EPI_SCORE_FILTER) {   // caller guarantees bf16, M % 256 == 0 (padded queries), N % 256 == 0, K % 64 == 0
         if (!(bf && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0)) abort();
