@@ -499,26 +499,27 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
 
     const bf16_t* __restrict__ Ag = static_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(p.W);
-    const int lrow = wave * 32 + (lane >> 3);
     const int lchunk = (lane & 7) ^ (lane >> 3);
-    const long astep = 8 * p.lda, wstep = 8 * p.ldw;
     const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0]);
-    auto dma16 = [&](const bf16_t* src, unsigned dst_byte) {
-        unsigned keep;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(dst_byte);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "s"(dst)
-                     : "memory");
+    // LDS-DMA piece: wave-uniform 64-bit base in SGPRs + a per-lane 32-bit byte offset, M0 = LDS destination.
+    // (A per-lane 64-bit pointer per piece costs two VALU adds each -- 14 of the ~30 VALU instructions of a k-step,
+    // and VALU issue competes with MFMA issue; M0 is declared clobbered instead of being saved and restored.)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned a_loff = (unsigned)(((lane >> 3) * p.lda + lchunk * 8) * 2);
+    const unsigned w_loff = (unsigned)(((lane >> 3) * p.ldw + lchunk * 8) * 2);
+    auto dma16 = [&](const char* base_uniform, unsigned lane_off, unsigned dst_byte) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(lane_off), "s"(base_uniform), "s"(dst_byte)
+                     : "memory", "m0");
     };
     // slot byte offsets: deep slot sd in [0,3), shallow slot ss in [0,2)
     auto deep_off = [&](int sd) { return (unsigned)(sd * SLOT * 16); };
     auto shal_off = [&](int ss) { return (unsigned)((3 + ss) * SLOT * 16); };
-    // piece q (0..3) of this wave's 32 rows of one operand
-    auto piece = [&](const bf16_t* src, long step, int kt, unsigned slot_off, int q) {
-        const unsigned row_off = (unsigned)((wave * 32 + q * 8) * CH * 16);
-        dma16(src + q * step + kt * 64, lds_base + slot_off + row_off);
+    // piece q (0..3) of this wave's 32 rows of one operand; `src` = wave-uniform pointer to the operand tile's row 0
+    auto piece = [&](const bf16_t* src, long ld, unsigned loff, int kt, unsigned slot_off, int q) {
+        const unsigned row_off = (unsigned)((wave_u * 32 + q * 8) * CH * 16);
+        dma16(reinterpret_cast<const char*>(src + (long)(wave_u * 32 + q * 8) * ld + kt * 64), loff, lds_base + slot_off + row_off);
     };
 
     f32x4 acc[8][4];
@@ -534,9 +535,10 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
     if (tile >= tiles_total) return;
     // per-lane source rows of the two operands for the current tile
-    const bf16_t* asrc = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
-    const bf16_t* wsrc = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
-    const long dstep = DEEP_A ? astep : wstep, sstep = DEEP_A ? wstep : astep;
+    const bf16_t* asrc = Ag + (long)m0 * p.lda;          // wave-uniform tile bases
+    const bf16_t* wsrc = Wg + (long)n0 * p.ldw;
+    const long dld = DEEP_A ? p.lda : p.ldw, sld = DEEP_A ? p.ldw : p.lda;
+    const unsigned dloff = DEEP_A ? a_loff : w_loff, sloff = DEEP_A ? w_loff : a_loff;
     int sd = 0, ss = 0;      // ring slots of the k-step about to be computed
     int dbg_tile = 0;
 #define STAMP(k)                                                                                   \
@@ -546,11 +548,11 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         const bf16_t* dsrc = DEEP_A ? asrc : wsrc;
         const bf16_t* ssrc = DEEP_A ? wsrc : asrc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) piece(dsrc, dstep, 0, deep_off(0), q);
+        for (int q = 0; q < 4; ++q) piece(dsrc, dld, dloff, 0, deep_off(0), q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) piece(ssrc, sstep, 0, shal_off(0), q);
+        for (int q = 0; q < 4; ++q) piece(ssrc, sld, sloff, 0, shal_off(0), q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) piece(dsrc, dstep, 1, deep_off(1), q);
+        for (int q = 0; q < 4; ++q) piece(dsrc, dld, dloff, 1, deep_off(1), q);
     }
     // Late-barrier pipeline: the k-step's barrier sits in front of its LAST row pair, and the first fragments of the
     // next k-step are read behind it, under that pair's MFMAs -- no ds_read latency is left between a barrier and the
@@ -571,8 +573,8 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
         while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
         const bool has_next = ntile < tiles_total;
-        const bf16_t* nasrc = has_next ? Ag + (long)(nm0 + lrow) * p.lda + lchunk * 8 : asrc;   // past the end: harmless re-fetch
-        const bf16_t* nwsrc = has_next ? Wg + (long)(nn0 + lrow) * p.ldw + lchunk * 8 : wsrc;
+        const bf16_t* nasrc = has_next ? Ag + (long)nm0 * p.lda : asrc;   // past the end: harmless re-fetch
+        const bf16_t* nwsrc = has_next ? Wg + (long)nn0 * p.ldw : wsrc;
         const bf16_t* d_cur = DEEP_A ? asrc : wsrc, *d_nxt = DEEP_A ? nasrc : nwsrc;
         const bf16_t* s_cur = DEEP_A ? wsrc : asrc, *s_nxt = DEEP_A ? nwsrc : nasrc;
         for (int kt = 0; kt < nk; ++kt) {
@@ -615,8 +617,8 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mma<bf16_t, SWAP>(acc[i][j], af[q & 1][h], wf[ks][j]);
                     if (ks == 0) {   // one 1-KiB piece behind every 4 MFMAs: shallow x4 first, then deep x4
-                        if (i < 4) piece(sp, sstep, skt, s_dst, i);
-                        else piece(dp, dstep, dkt, d_dst, i - 4);
+                        if (i < 4) piece(sp, sld, sloff, skt, s_dst, i);
+                        else piece(dp, dld, dloff, dkt, d_dst, i - 4);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
