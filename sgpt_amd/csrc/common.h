@@ -111,6 +111,7 @@ struct GemmArgs {
     long lda, ldw, ldo;
     int m_valid;        // rows >= m_valid are computed from clamped reads and not stored
     int skew;           // persistent kernel: start-up stagger (shader cycles per phase), see gemm256_kernel
+    int gm, gn;         // gemm256d: supertile shape in tiles (major x minor); 0 = default 4 x 8
     const int* pred;    // device flag or null: the kernel exits at once when *pred == 0 (sync-free fallback launches)
     // EPI_SCORE_FILTER
     const float* thr;   // per-query threshold thr[m * thr_ld] (the running k-th best score; -inf = keep all)

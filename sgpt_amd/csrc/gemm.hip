@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
 
     const int N = p.N, K = p.K;
     const int MT = p.M / TM, NT = N / TN;
-    constexpr int GM = 4, GN = 8;
+    const int GM = p.gm > 0 ? p.gm : 4, GN = p.gn > 0 ? p.gn : 8;
     const bool m_major = MT >= NT;
     const int AT = m_major ? MT : NT, BT = m_major ? NT : MT;
     const int per_band = GM * BT;
@@ -655,9 +655,15 @@ void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n / 8 * 8;
     }();
-    const int grid = tiles_total < ncu ? tiles_total : ncu;
-    if (deep_a) hipLaunchKernelGGL((gemm256d_kernel<EPI, OutT, SWAP, true>), dim3(grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((gemm256d_kernel<EPI, OutT, SWAP, false>), dim3(grid), dim3(512), 0, s, a);
+    GemmArgs b = a;
+    static const int env_gm = getenv("SGPT_GM") ? atoi(getenv("SGPT_GM")) : 0, env_gn = getenv("SGPT_GN") ? atoi(getenv("SGPT_GN")) : 0;
+    if (env_gm > 0) b.gm = env_gm;
+    if (env_gn > 0) b.gn = env_gn;
+    const int gm = b.gm > 0 ? b.gm : 4;
+    const int tiles_pad = ((AT + 7) / 8 + gm - 1) / gm * gm * 8 * BT;
+    const int grid = tiles_pad < ncu ? tiles_pad : ncu;
+    if (deep_a) hipLaunchKernelGGL((gemm256d_kernel<EPI, OutT, SWAP, true>), dim3(grid), dim3(512), 0, s, b);
+    else hipLaunchKernelGGL((gemm256d_kernel<EPI, OutT, SWAP, false>), dim3(grid), dim3(512), 0, s, b);
 }
 
 
