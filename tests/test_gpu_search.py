@@ -320,3 +320,29 @@ def test_crossencoder_loglikelihood_vs_reference_golden():
     owant = O.loglikelihood_tokens(w, cfg, oreqs, 64, rk.instruction_len)
     assert np.max(np.abs(np.asarray(scores) - np.asarray(owant)) / np.maximum(1.0, np.abs(owant))) < 1e-3
     m.close(); mb.close()
+
+
+def test_crossencoder_gptj_untied_lm_head():
+    """GPT-J (SGPT-5.8B family) carries its own lm_head.weight / lm_head.bias (HF GPTJForCausalLM): the cross-encoder
+    scorer must use them instead of the tied embedding."""
+    from helpers import oracle_cfg_weights
+    from sgpt_amd import SGPTConfig, SGPTModel
+    from sgpt_amd.crossencoder import loglikelihood_tokens
+    cfg_kw = dict(vocab_size=211, n_positions=96, n_embd=512, n_layer=2, n_head=2, rotary_dim=64)
+    cfg, w = oracle_cfg_weights(cfg_kw, 61, 0.04)
+    rng = np.random.default_rng(61)
+    w = dict(w)
+    w["lm_head.weight"] = (rng.standard_normal((211, 512)) * 0.05).astype(np.float32)
+    w["lm_head.bias"] = (rng.standard_normal(211) * 0.5).astype(np.float32)
+    reqs = [(("c", "q"), rng.integers(0, 211, size=a).tolist(), rng.integers(0, 211, size=b).tolist())
+            for a, b in [(12, 4), (30, 9), (5, 1), (60, 20)]]
+    want = np.asarray(O.loglikelihood_tokens(w, cfg, reqs, 64, 2))
+    m = SGPTModel(SGPTConfig.from_hf_dict(dict(cfg_kw, model_type="gptj")), w, device="cuda:0", dtype="fp32")
+    got = np.asarray(loglikelihood_tokens(reqs, m, 64, instruction_len=2))
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-3
+    # and it is not the tied head
+    w_tied = {k: v for k, v in w.items() if not k.startswith("lm_head")}
+    w_tied["lm_head.weight"] = w["wte.weight"]
+    tied = np.asarray(O.loglikelihood_tokens(w_tied, cfg, reqs, 64, 2))
+    assert np.max(np.abs(tied - want)) > 0.1
+    m.close()
