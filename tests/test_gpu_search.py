@@ -346,3 +346,20 @@ def test_crossencoder_gptj_untied_lm_head():
     tied = np.asarray(O.loglikelihood_tokens(w_tied, cfg, reqs, 64, 2))
     assert np.max(np.abs(tied - want)) > 0.1
     m.close()
+
+
+def test_crossencoder_bloom_tied_head():
+    """BLOOM ties the LM head to word_embeddings (ALiBi positions, embedding LayerNorm): same scorer, third family."""
+    from helpers import oracle_cfg_weights
+    from sgpt_amd import SGPTConfig, SGPTModel
+    from sgpt_amd.crossencoder import loglikelihood_tokens
+    cfg_kw = dict(vocab_size=211, hidden_size=256, n_layer=2, n_head=2)
+    cfg, w = oracle_cfg_weights(cfg_kw, 62, 0.04)
+    rng = np.random.default_rng(62)
+    reqs = [(("c", "q"), rng.integers(0, 211, size=a).tolist(), rng.integers(0, 211, size=b).tolist())
+            for a, b in [(14, 3), (33, 10), (2, 2), (50, 16)]]
+    want = np.asarray(O.loglikelihood_tokens(w, cfg, reqs, 64, 0))
+    m = SGPTModel(SGPTConfig.from_hf_dict(dict(cfg_kw, model_type="bloom")), w, device="cuda:0", dtype="fp32")
+    got = np.asarray(loglikelihood_tokens(reqs, m, 64))
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-3
+    m.close()
