@@ -288,3 +288,23 @@ def test_encode_graph_capture_and_replay():
     graph = (time.perf_counter() - t) / 20
     print(f"32-query batch (<=32 tokens): eager {eager * 1e3:.3f} ms, hipGraph replay {graph * 1e3:.3f} ms")
     assert graph < eager * 1.5
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_encode_long_sequences_full_context(dtype):
+    """Sequences up to max_position_embeddings = 2048 (the API limit): 32 key tiles per query block, global and
+    256-token sliding-window layers, mixed with short sequences in one packed call."""
+    from sgpt_amd import SGPTConfig, SGPTModel
+    cfg_kw = dict(vocab_size=211, max_position_embeddings=2048, hidden_size=128, num_layers=2, num_heads=2, window_size=256)
+    cfg = O.NeoConfig(**cfg_kw)
+    w = O.synth_weights(cfg, seed=77, std=0.06)
+    rng = np.random.default_rng(77)
+    seqs = [rng.integers(0, 211, size=n).tolist() for n in (2048, 1000, 257, 17, 1)]
+    want = O.encode(w, cfg, seqs, batch_size=1)
+    m = SGPTModel(SGPTConfig(**cfg_kw), w, device="cuda:0", dtype=dtype)
+    got = m.encode_ids(seqs).cpu().numpy()
+    m.close()
+    if dtype == "fp32":
+        assert maxabs(got, want) < TOL_FP32
+    else:
+        assert np.isfinite(got).all() and maxabs(got, want) < TOL_BF16_ABS and float(row_cos(got, want).min()) > TOL_BF16_COS
