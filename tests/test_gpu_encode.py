@@ -308,3 +308,25 @@ def test_encode_long_sequences_full_context(dtype):
         assert maxabs(got, want) < TOL_FP32
     else:
         assert np.isfinite(got).all() and maxabs(got, want) < TOL_BF16_ABS and float(row_cos(got, want).min()) > TOL_BF16_COS
+
+
+@pytest.mark.parametrize("arch", ["gptj", "bloom"])
+def test_encode_long_sequences_gptj_bloom(arch):
+    """Rotary positions (GPT-J) and ALiBi key offsets (BLOOM, left-padded batch) over ~700-token sequences."""
+    from helpers import oracle_cfg_weights
+    from sgpt_amd import SGPTConfig, SGPTModel
+    if arch == "gptj":
+        cfg_kw = dict(vocab_size=211, n_positions=1024, n_embd=256, n_layer=2, n_head=2, rotary_dim=64)
+    else:
+        cfg_kw = dict(vocab_size=211, hidden_size=256, n_layer=2, n_head=4)
+    cfg, w = oracle_cfg_weights(cfg_kw, 88, 0.04)
+    rng = np.random.default_rng(88)
+    seqs = [rng.integers(0, 211, size=n).tolist() for n in (700, 333, 64, 3)]
+    side = "left" if arch == "bloom" else "right"
+    want = O.encode(w, cfg, seqs, batch_size=len(seqs), pad_side=side)
+    S = max(len(s) for s in seqs)
+    pad_left = [S - len(s) for s in seqs] if side == "left" else None
+    m = SGPTModel(SGPTConfig.from_hf_dict(dict(cfg_kw, model_type=arch)), w, device="cuda:0", dtype="fp32")
+    got = m.encode_ids(seqs, pad_left=pad_left).cpu().numpy()
+    m.close()
+    assert maxabs(got, want) < TOL_FP32
