@@ -18,6 +18,8 @@
  *     sgpt_ctx_create / sgpt_model_load / *_destroy / *_free and workspace growth;
  *   - no C++ exception crosses the ABI: functions return SGPT_OK (0) or a negative
  *     sgpt_status; sgpt_last_error(ctx) returns a message for the last failure on ctx;
+ *   - calls on one ctx must be issued from one thread onto ONE stream at a time: the activation / scorer workspaces are
+ *     per-ctx scratch shared by every model and call on it (use one ctx per stream for concurrent streams);
  *   - a ctx is bound to one HIP device and is re-entrant per ctx, not thread-safe
  *     (the reference runs one single-threaded Python process per GPU,
  *     sentence_transformers/SentenceTransformer.py:275-283).
@@ -32,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPT_ABI_VERSION 2
+#define SGPT_ABI_VERSION 3
 
 typedef int sgpt_status;
 #define SGPT_OK 0
@@ -40,11 +42,12 @@ typedef int sgpt_status;
 #define SGPT_ERR_HIP (-2)         /* a HIP runtime call failed */
 #define SGPT_ERR_MISSING (-3)     /* a required weight tensor was not supplied */
 #define SGPT_ERR_OOM (-4)
+#define SGPT_ERR_RANGE (-5)       /* SGPT_F16: a weight / LayerNorm parameter does not fit the f16 range */
 
 typedef struct sgpt_ctx sgpt_ctx;
 typedef struct sgpt_model sgpt_model;
 
-enum { SGPT_F32 = 0, SGPT_BF16 = 1, SGPT_FP8W = 2 };       /* element types; FP8W: model compute_dtype only */
+enum { SGPT_F32 = 0, SGPT_BF16 = 1, SGPT_FP8W = 2, SGPT_F16 = 3 };   /* element types; FP8W: model compute_dtype only */
 enum { SGPT_ARCH_GPTNEO = 0, SGPT_ARCH_GPTJ = 1, SGPT_ARCH_BLOOM = 2 };
 enum { SGPT_POOL_WEIGHTEDMEAN = 0, SGPT_POOL_MEAN = 1, SGPT_POOL_LASTTOKEN = 2, SGPT_POOL_LEARNTMEAN = 3 };
 enum { SGPT_COS = 0, SGPT_DOT = 1 };
@@ -62,7 +65,14 @@ typedef struct {
     int32_t window;          /* GPT-Neo local-attention window (256) */
     float ln_eps;            /* 1e-5 */
     float attn_scale;        /* 1.0 for GPT-Neo (no 1/sqrt(dh), HF:gpt_neo:110); 1/sqrt(dh) for GPT-J (HF:gptj:148) and BLOOM (HF:bloom:186) */
-    int32_t compute_dtype;   /* SGPT_BF16: bf16 MFMA operands, fp32 accumulate/residual/LN/softmax;
+    int32_t compute_dtype;   /* SGPT_F16 : IEEE half MFMA operands (weights, LN output, q/k/v, probabilities, context, GELU
+                                           output), fp32 accumulate/residual/LN/softmax -- the same MFMA rate as bf16 with 3
+                                           more mantissa bits: the mode that meets the 1e-3 cosine bar against the fp32
+                                           reference.  Range-guarded: sgpt_model_load refuses weights /
+                                           LayerNorm parameters outside the f16 range (SGPT_ERR_RANGE) and every kernel that
+                                           rounds an activation to f16 raises a device flag at |v| >= 32768, read with
+                                           sgpt_range_check;
+                                SGPT_BF16: bf16 MFMA operands, fp32 accumulate/residual/LN/softmax;
                                 SGPT_F32 : exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the parity gate;
                                 SGPT_FP8W: the six matmul weights per block are STORED as OCP e4m3fn with one
                                            power-of-two fp32 scale per output channel (the
@@ -174,8 +184,23 @@ sgpt_status sgpt_pool_learnt(sgpt_ctx* ctx, const void* hidden, int32_t hidden_d
 sgpt_status sgpt_l2_normalize(sgpt_ctx* ctx, const float* in, int64_t n, int32_t d,
                               void* out, int32_t out_dtype, void* stream);
 
-/* fp32 -> bf16 (RNE) element-wise; used to keep a corpus shard in HBM as bf16. */
+/* fp32 -> bf16 / f16 (RNE) element-wise; used to keep a corpus shard in HBM in the scorer's 16-bit operand format
+ * (out_dtype SGPT_BF16 | SGPT_F16; normalised embeddings are in [-1, 1], inside either range). */
+sgpt_status sgpt_f32_to_16(sgpt_ctx* ctx, const float* in, int64_t numel, void* out, int32_t out_dtype, void* stream);
 sgpt_status sgpt_f32_to_bf16(sgpt_ctx* ctx, const float* in, int64_t numel, void* out, void* stream);
+
+/* SGPT_F16 range guard: *flagged = 1 when, since the last reset, a kernel rounded an activation of magnitude >= 32768
+ * (or a non-finite one) to f16 -- the results of the affected calls are not trustworthy and the model should be
+ * re-loaded with SGPT_BF16.  Synchronises `stream` (one 4-byte read-back); the Python host calls it once per
+ * encode_ids() and raises.  The reference's fp32 CPU path has no such failure mode. */
+sgpt_status sgpt_range_check(sgpt_ctx* ctx, int32_t* flagged, int32_t reset, void* stream);
+
+/* hipGraph support.  sgpt_ctx_generation changes whenever a library-owned buffer that launched kernels point into is
+ * re-allocated (workspace growth, a larger learnt-pooling table): a graph captured at generation g must be re-captured
+ * (or refused) once the value differs.  sgpt_ctx_reserve grows the encoder / scorer workspaces to at least the given
+ * sizes up front so that no growth happens while graphs are alive. */
+uint64_t sgpt_ctx_generation(const sgpt_ctx* ctx);
+sgpt_status sgpt_ctx_reserve(sgpt_ctx* ctx, size_t encode_bytes, size_t score_bytes);
 
 /* fp8 weight storage (SGPT_FP8W) building blocks, exported for parity tests and for callers that keep
  * their own quantised checkpoints.  w device fp32[rows, cols] (cols % 4 == 0) -> codes uint8[rows, cols]
@@ -190,8 +215,8 @@ sgpt_status sgpt_fp8_dequantize_rows(sgpt_ctx* ctx, const uint8_t* codes, const 
 /* Replaces cos_sim / dot_score = torch.mm(a, b.T) (sentence_transformers/util.py:24-63;
  * beir.util, imported at custommodels/exact_search.py:9): out[i][j] = <a_i, b_j>, NaN kept.
  * For cosine the caller normalises first (sgpt_l2_normalize), exactly as util.py:41-43.
- *   a device [na,d], b device [nb,d], both of `dtype` (fp32: exact fp32 MFMA; bf16: bf16 MFMA,
- *   fp32 accumulate); d multiple of 4 (fp32) / 8 (bf16); out device fp32[na, ldo], ldo >= nb, ldo%4==0. */
+ *   a device [na,d], b device [nb,d], both of `dtype` (fp32: exact fp32 MFMA; bf16 / f16: 16-bit MFMA,
+ *   fp32 accumulate); d multiple of 4 (fp32) / 8 (16-bit); out device fp32[na, ldo], ldo >= nb, ldo%4==0. */
 sgpt_status sgpt_scores(sgpt_ctx* ctx, const void* a, const void* b, int32_t dtype,
                         int64_t na, int64_t nb, int32_t d, float* out, int64_t ldo, void* stream);
 
@@ -206,7 +231,7 @@ sgpt_status sgpt_scores(sgpt_ctx* ctx, const void* a, const void* b, int32_t dty
  *           columns valid), out = new running best, sorted by descending score
  *           (ties: ascending index); unused tail = (-inf, -1).
  *   returns through *n_out (host) the number of valid columns = min(k, n_run + N).
- * Long corpora (bf16, d % 64 == 0, k <= 1024, N >= two chunks): only the first chunk's scores are materialised;
+ * Long corpora (bf16 or f16, d % 64 == 0, d >= 128, k <= 1024, N >= two chunks): only the first chunk's scores are materialised;
  * later chunks double in length and their GEMM epilogue appends just the scores above the query's running k-th
  * best to a candidate list that a small merge kernel folds into the running top-k.  The result is identical to
  * the materialised loop; a candidate-list overflow raises a device flag on which a materialised recomputation of

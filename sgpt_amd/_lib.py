@@ -7,8 +7,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGPT_HIP_LIB") or os.path.join(HERE, "lib", "libsgpt_hip.so")   # env: A/B builds of the same ABI
 
-SGPT_F32, SGPT_BF16, SGPT_FP8W = 0, 1, 2
-SGPT_ABI_VERSION = 2
+SGPT_F32, SGPT_BF16, SGPT_FP8W, SGPT_F16 = 0, 1, 2, 3
+SGPT_ABI_VERSION = 3
+SGPT_ERR_RANGE = -5
 SGPT_ARCH_GPTNEO, SGPT_ARCH_GPTJ, SGPT_ARCH_BLOOM = 0, 1, 2
 POOL_MODES = {"weightedmean": 0, "mean": 1, "lasttoken": 2, "learntmean": 3}
 
@@ -52,6 +53,10 @@ SIGNATURES = {
                             C.c_int32, C.c_void_p, C.c_void_p]),
     "sgpt_l2_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "sgpt_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sgpt_f32_to_16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sgpt_range_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]),
+    "sgpt_ctx_generation": (C.c_uint64, [C.c_void_p]),
+    "sgpt_ctx_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
     "sgpt_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                               C.c_void_p, C.c_int64, C.c_void_p]),
     "sgpt_score_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
@@ -73,6 +78,10 @@ _lib = None
 
 class SgptHipError(RuntimeError):
     pass
+
+
+class SgptRangeError(SgptHipError):
+    """dtype='f16': a weight or an activation left the IEEE-half range (|v| >= 32768); use dtype='bf16'."""
 
 
 def load():
@@ -101,4 +110,6 @@ def check(ctx_handle, status, what=""):
     msg = msg.decode() if msg else ""
     if status == -1:
         raise ValueError(f"{what}: {msg}")
+    if status == SGPT_ERR_RANGE:
+        raise SgptRangeError(f"{what}: {msg}")
     raise SgptHipError(f"{what}: status {status}: {msg}")

@@ -33,7 +33,7 @@ class CustomEmbedder:
 
     def __init__(self, model_name="EleutherAI/gpt-neo-1.3B", batch_size=250, device="cuda:0", save_emb=False,
                  reinit=False, layeridx=-1, method="mean", dataset="scifact", specb=False, maxseqlen=None,
-                 model: Optional[SGPTModel] = None, tokenizer=None, dtype="bf16", **kwargs):
+                 model: Optional[SGPTModel] = None, tokenizer=None, dtype="f16", **kwargs):
         if reinit:
             raise NotImplementedError("reinit (random re-initialisation ablation) is not part of the hot path")
         self.device = torch.device(device)
@@ -110,13 +110,15 @@ class CustomEmbedder:
     # device-resident variants used by DenseRetrievalExactSearch below (no D2H of embeddings)
     def encode_queries_device(self, queries, normalize=False):
         if os.path.exists(f"{self.base_path}_queries.pickle") or self.save_emb:
-            return torch.from_numpy(self.encode_queries(queries)).to(self.model.device)
-        return self.embed_device([q for (_, q) in queries], True, normalize=False)
+            emb = torch.from_numpy(self.encode_queries(queries)).to(self.model.device)
+            return get_context(self.model.device).l2_normalize(emb) if normalize else emb
+        return self.embed_device([q for (_, q) in queries], True, normalize=normalize)
 
     def encode_corpus_device(self, corpus, batch_num="", normalize=False):
         if os.path.exists(f"{self.base_path}_corpus{batch_num}.pickle") or self.save_emb:
-            return torch.from_numpy(self.encode_corpus(corpus, batch_num=batch_num)).to(self.model.device)
-        return self.embed_device([t for (_, t) in self._corpus_texts(corpus)], False, normalize=False)
+            emb = torch.from_numpy(self.encode_corpus(corpus, batch_num=batch_num)).to(self.model.device)
+            return get_context(self.model.device).l2_normalize(emb) if normalize else emb
+        return self.embed_device([t for (_, t) in self._corpus_texts(corpus)], False, normalize=normalize)
 
 
 class DenseRetrievalExactSearch:
@@ -133,7 +135,7 @@ class DenseRetrievalExactSearch:
         self.corpus_chunk_size = corpus_chunk_size
         self.show_progress_bar = True
         self.convert_to_tensor = True
-        self.score_dtype = score_dtype          # torch.float32: exact-fp32 MFMA; torch.bfloat16: bf16 corpus in HBM
+        self.score_dtype = score_dtype          # torch.float32: exact-fp32 MFMA; torch.float16 / bfloat16: 16-bit corpus in HBM
         self.results = {}
 
     def _to_dev(self, ctx, x):
@@ -214,7 +216,7 @@ class SentenceBERTBOSEOS:
     List[{"title","text"}] corpus."""
 
     def __init__(self, model_path=None, sep: str = " ", speca=False, specb=False, model: Optional[SGPTModel] = None,
-                 tokenizer=None, max_seq_length: int = 300, method: str = "weightedmean", dtype="bf16",
+                 tokenizer=None, max_seq_length: int = 300, method: str = "weightedmean", dtype="f16",
                  device="cuda:0", **kwargs):
         self.sep = sep
         self.speca, self.specb = speca, specb
@@ -251,7 +253,7 @@ class SentenceBERTAsym:
 
     def __init__(self, model_path=None, sep: str = " ", query_model: Optional[SGPTModel] = None,
                  doc_model: Optional[SGPTModel] = None, tokenizer=None, max_seq_length: int = 300,
-                 method: str = "weightedmean", dtype="bf16", device="cuda:0", **kwargs):
+                 method: str = "weightedmean", dtype="f16", device="cuda:0", **kwargs):
         self.sep = sep
         if query_model is None or doc_model is None:
             from .formats import read_st_folder

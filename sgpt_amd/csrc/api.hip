@@ -19,6 +19,10 @@ struct sgpt_ctx {
     // grow-only workspaces
     void* ws = nullptr; size_t ws_bytes = 0;        // encoder activations
     void* ws2 = nullptr; size_t ws2_bytes = 0;      // scorer: score chunk + ping-pong top-k
+    // bumped whenever a library-owned buffer that launched kernels point into is re-allocated (workspace growth,
+    // learnt pooling weights): a hipGraph captured earlier holds stale pointers once this moves (sgpt_ctx_generation)
+    uint64_t generation = 0;
+    int* range_flag = nullptr;                      // device int: an f16 activation left the representable range
     // GEMM profiling (bench.py roofline)
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -78,6 +82,7 @@ sgpt_status ensure(sgpt_ctx* c, void** p, size_t* have, size_t need) {
     if (hipMalloc(p, need) != hipSuccess) { *p = nullptr; return fail(c, SGPT_ERR_OOM, "hipMalloc workspace failed"); }
     HIPC(c, hipMemset(*p, 0, need));
     *have = need;
+    c->generation++;
     return SGPT_OK;
 }
 
@@ -117,6 +122,10 @@ sgpt_status sgpt_ctx_create(int hip_device, sgpt_ctx** out) {
     if (hipSetDevice(hip_device) != hipSuccess) return SGPT_ERR_HIP;
     sgpt_ctx* c = new sgpt_ctx();
     c->device = hip_device;
+    if (hipMalloc((void**)&c->range_flag, 256) != hipSuccess || hipMemset(c->range_flag, 0, 256) != hipSuccess) {
+        delete c;
+        return SGPT_ERR_OOM;
+    }
     *out = c;
     return SGPT_OK;
 }
@@ -127,11 +136,34 @@ void sgpt_ctx_destroy(sgpt_ctx* c) {
     hipDeviceSynchronize();
     if (c->ws) hipFree(c->ws);
     if (c->ws2) hipFree(c->ws2);
+    if (c->range_flag) hipFree(c->range_flag);
     for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
 }
 
 const char* sgpt_last_error(const sgpt_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+uint64_t sgpt_ctx_generation(const sgpt_ctx* c) { return c ? c->generation : 0; }
+
+sgpt_status sgpt_ctx_reserve(sgpt_ctx* c, size_t encode_bytes, size_t score_bytes) {
+    if (!c) return SGPT_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    sgpt_status st = ensure(c, &c->ws, &c->ws_bytes, encode_bytes);
+    if (st != SGPT_OK) return st;
+    return ensure(c, &c->ws2, &c->ws2_bytes, score_bytes);
+}
+
+sgpt_status sgpt_range_check(sgpt_ctx* c, int32_t* flagged, int32_t reset, void* stream) {
+    if (!c || !flagged) return SGPT_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    int h = 0;
+    HIPC(c, hipMemcpyAsync(&h, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPC(c, hipStreamSynchronize(s));
+    if (reset && h) HIPC(c, hipMemsetAsync(c->range_flag, 0, sizeof(int), s));
+    *flagged = h;
+    return SGPT_OK;
+}
 
 sgpt_status sgpt_prof_enable(sgpt_ctx* c, int32_t on) {
     if (!c) return SGPT_ERR_INVALID;
@@ -171,10 +203,11 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     if (dm % 128 || ffn % 128 || H <= 0 || dm % H) return fail(c, SGPT_ERR_INVALID, "d_model and d_ffn must be multiples of 128");
     const int dh = dm / H;
     if (d->compute_dtype != SGPT_F32 && dh != 64 && dh != 128 && dh != 256)
-        return fail(c, SGPT_ERR_INVALID, "bf16 attention supports head_dim 64, 128 or 256");
+        return fail(c, SGPT_ERR_INVALID, "16-bit attention supports head_dim 64, 128 or 256");
     if (dh > 256 || dh % 4) return fail(c, SGPT_ERR_INVALID, "head_dim must be <= 256 and a multiple of 4");
     if (dm > 4096) return fail(c, SGPT_ERR_INVALID, "d_model > 4096 not supported");
-    if (d->compute_dtype != SGPT_BF16 && d->compute_dtype != SGPT_F32 && d->compute_dtype != SGPT_FP8W)
+    if (d->compute_dtype != SGPT_BF16 && d->compute_dtype != SGPT_F32 && d->compute_dtype != SGPT_FP8W &&
+        d->compute_dtype != SGPT_F16)
         return fail(c, SGPT_ERR_INVALID, "bad compute_dtype");
     if (gptj && (d->rotary_dim <= 0 || d->rotary_dim > dh || d->rotary_dim % 2))
         return fail(c, SGPT_ERR_INVALID, "GPT-J needs an even rotary_dim in (0, head_dim]");
@@ -186,9 +219,16 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     m->d = *d;
     m->d.layer_is_local = nullptr;
     const bool fp8 = d->compute_dtype == SGPT_FP8W;
-    const bool bf = d->compute_dtype == SGPT_BF16;
+    const bool f16 = d->compute_dtype == SGPT_F16;
+    const bool bf = d->compute_dtype == SGPT_BF16 || f16;          // 16-bit packed weights
     const size_t esz = fp8 ? 1 : (bf ? 2 : 4);
     sgpt_status st = SGPT_OK;
+    // SGPT_F16 range audit: stats[0] = max|matmul weight|, [1] = max|LayerNorm gamma|, [2] = max|LayerNorm beta|
+    unsigned* stats = nullptr;
+    if (f16) {
+        if (hipMalloc((void**)&stats, 16) != hipSuccess) { delete m; return fail(c, SGPT_ERR_OOM, "hipMalloc failed"); }
+        hipMemsetAsync(stats, 0, 16, 0);
+    }
 
     auto find = [&](const std::string& name, int64_t numel) -> const float* {
         auto it = byname.find(name);
@@ -210,11 +250,20 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         if (hipMemcpyAsync(dst, src, numel * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memcpy " + name);
         return dst;
     };
+    // LayerNorm parameters whose output is rounded to the 16-bit GEMM operand format
+    auto copy_ln = [&](const std::string& base, float** g, float** b) {
+        *g = copy_f32(base + ".weight", dm);
+        *b = copy_f32(base + ".bias", dm);
+        if (f16 && *g && *b) { launch_absmax(*g, dm, stats + 1, 0); launch_absmax(*b, dm, stats + 2, 0); }
+    };
     // matmul weight [rows, cols] -> packed dtype at row `row_off` of dst (fp8: codes + one scale per row)
     auto pack_rows = [&](const float* src, int64_t rows, int64_t cols, void* dst, int64_t row_off, float* scale) {
         const int64_t off = row_off * cols, numel = rows * cols;
         if (fp8) launch_fp8_quant_rows(src, rows, cols, (uint8_t*)dst + off, scale + row_off, 0);
-        else if (bf) launch_f32_to_bf16(src, numel, (bf16_t*)dst + off, 0);
+        else if (bf) {
+            launch_f32_to_16(src, numel, (bf16_t*)dst + off, f16 ? DT_F16 : DT_BF16, 0);
+            if (f16) launch_absmax(src, numel, stats + 0, 0);
+        }
         else if (hipMemcpyAsync((float*)dst + off, src, numel * 4, hipMemcpyDeviceToDevice, 0) != hipSuccess)
             st = fail(c, SGPT_ERR_HIP, "memcpy weight");
     };
@@ -262,8 +311,8 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         const std::string p = "h." + std::to_string(i) + ".";
         LayerW& l = m->L[i];
         l.is_local = (gptj || bloom) ? 0 : (d->layer_is_local ? d->layer_is_local[i] : (i & 1));
-        l.ln1_g = copy_f32(p + ln1 + ".weight", dm); l.ln1_b = copy_f32(p + ln1 + ".bias", dm);
-        if (!gptj) { l.ln2_g = copy_f32(p + ln2 + ".weight", dm); l.ln2_b = copy_f32(p + ln2 + ".bias", dm); }
+        copy_ln(p + ln1, &l.ln1_g, &l.ln1_b);
+        if (!gptj) copy_ln(p + ln2, &l.ln2_g, &l.ln2_b);
         else l.ln2_g = l.ln2_b = nullptr;
         if (gptj) l.b_o = m->zero_bias;
         else l.b_o = copy_f32(p + (bloom ? std::string("self_attention.dense.bias") : attn + "out_proj.bias"), dm);
@@ -301,6 +350,18 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         m->dq[2] = dalloc((size_t)ffn * dm * 2); m->dq[3] = dalloc((size_t)dm * ffn * 2);
     }
     if (st == SGPT_OK && hipDeviceSynchronize() != hipSuccess) st = fail(c, SGPT_ERR_HIP, "sync after weight pack");
+    if (f16) {
+        // f16 has 5 exponent bits: refuse a checkpoint whose weights, or whose LayerNorm output bound
+        // max|gamma| * sqrt(d) + max|beta| (|x_hat| <= sqrt(d-1)), can leave the format.  Activations behind the GEMMs are
+        // range-checked on the device at run time (RangeTrack in the store epilogues -> sgpt_range_check).
+        unsigned h[4] = {0, 0, 0, 0};
+        if (st == SGPT_OK && hipMemcpy(h, stats, 12, hipMemcpyDeviceToHost) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "range audit");
+        hipFree(stats);
+        float wmax, gmax, bmax;
+        memcpy(&wmax, &h[0], 4); memcpy(&gmax, &h[1], 4); memcpy(&bmax, &h[2], 4);
+        if (st == SGPT_OK && (!(wmax < 65504.f) || !(gmax * sqrtf((float)dm) + bmax < 32768.f)))
+            st = fail(c, SGPT_ERR_RANGE, "SGPT_F16: weights or LayerNorm parameters exceed the f16 range; load with SGPT_BF16");
+    }
     if (st != SGPT_OK) { sgpt_model_free(m); return st; }
     *out = m;
     return SGPT_OK;
@@ -331,7 +392,9 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     if (pool_mode < 0 || pool_mode > 3) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad pool_mode");
     if (pool_mode == SGPT_POOL_LEARNTMEAN && (out || layer_out || layer_mean)) {
         if (!m->pool_w) return fail(c, SGPT_ERR_MISSING, "sgpt_encode: learntmean needs sgpt_model_set_pool_weights first");
-        if (!pad_left && max_alloc > m->pool_w_n)
+        // with pad_left on the device the longest padded position is not known here: the kernel clamps the table index,
+        // and the Python host checks max(pad_left + len) before the call (model.py::_check_learnt)
+        if (!pad_left && max_alloc - 15 > m->pool_w_n)
             return fail(c, SGPT_ERR_INVALID, "sgpt_encode: fewer learnt position weights than the longest sequence");
     }
     if (max_alloc > 2048) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: sequence longer than 2048 tokens");
@@ -340,8 +403,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     hipStream_t s = (hipStream_t)stream;
     const int dm = m->d.d_model, ffn = m->d.d_ffn, H = m->d.n_heads, dh = dm / H;
     const bool fp8 = m->d.compute_dtype == SGPT_FP8W;
-    const bool bf = m->d.compute_dtype != SGPT_F32;
-    const int dt = bf ? SGPT_BF16 : SGPT_F32;
+    const bool bf = m->d.compute_dtype != SGPT_F32;                 // 16-bit MFMA operands (bf16 or f16)
+    const int dt = !bf ? SGPT_F32 : (m->d.compute_dtype == SGPT_F16 ? SGPT_F16 : SGPT_BF16);
     const size_t esz = bf ? 2 : 4;
     const size_t SLACK = 64;  // rows of zeroed slack behind buffers the attention key tiles may over-read
 
@@ -377,13 +440,13 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         HIPC(c, hipMemsetAsync((float*)qkv + (size_t)T * 3 * dm, 0, SLACK * 3 * dm * esz, s));
     }
     if (gptj) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz, s));
-    launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, s);
+    launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, m->d.vocab, m->d.max_pos, s);
     if (m->emb_ln_g) launch_layernorm(x, m->emb_ln_g, m->emb_ln_b, x, SGPT_F32, T, dm, m->d.ln_eps, s);   // BLOOM :499
     for (int li = 0; li < n_layers_run; ++li) {
         LayerW l = m->L[li];
         if (layer_out)   // hidden_states[li] = input of block li (HF:gpt_neo:475-478)
             launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, 0, pool_mode,
-                            normalize, m->pool_w, layer_out + (size_t)li * B * dm, s);
+                            normalize, m->pool_w, m->pool_w_n, layer_out + (size_t)li * B * dm, s);
         if (fp8) {  // this block's weights: e4m3fn codes * 2^k -> bf16, exact; <1 % of the block's time at T >= 16k
             launch_fp8_dequant_rows(l.w_qkv, l.s_qkv, (long)3 * dm, dm, m->dq[0], SGPT_BF16, s);
             launch_fp8_dequant_rows(l.w_o, l.s_o, dm, dm, m->dq[1], SGPT_BF16, s);
@@ -394,17 +457,19 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
         GemmArgs g{};
         g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
+        g.range_flag = dt == SGPT_F16 ? c->range_flag : nullptr;
         AttnArgs at{};
+        at.dtype = dt;
         at.seq_off = seq_off; at.B = B; at.H = H; at.dh = dh; at.window = l.is_local ? m->d.window : 0;
         at.scale = m->d.attn_scale; at.max_alloc_len = max_alloc; at.ctx = ctx; at.ldo = dm; at.alibi = m->alibi;
         if (bf) {
             // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]
             g.W = l.w_qkv; g.N = 2 * dm; g.out = qkv; g.ldo = 2 * dm; g.bias = l.b_qkv;            // bias: BLOOM only
-            gemm(c, dt, EPI_STORE, SGPT_BF16, g, s);
+            gemm(c, dt, EPI_STORE, dt, g, s);
             g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; g.N = dm; g.out = vt; g.ldo = T;
             g.bias = l.b_qkv ? l.b_qkv + 2 * dm : nullptr;
-            gemm(c, dt, EPI_VT, SGPT_BF16, g, s);
-            if (gptj) launch_rope(qkv, SGPT_BF16, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
+            gemm(c, dt, EPI_VT, dt, g, s);
+            if (gptj) launch_rope(qkv, dt, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
             at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
             launch_attn_bf16(at, s);
         } else {
@@ -431,10 +496,10 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     }
     if (out)
         launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, apply_final_ln,
-                        pool_mode, normalize, m->pool_w, out, s);
+                        pool_mode, normalize, m->pool_w, m->pool_w_n, out, s);
     if (layer_out)
         launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, apply_final_ln,
-                        pool_mode, normalize, m->pool_w, layer_out + (size_t)n_layers_run * B * dm, s);
+                        pool_mode, normalize, m->pool_w, m->pool_w_n, layer_out + (size_t)n_layers_run * B * dm, s);
     if (layer_mean) launch_mean_over_axis0(layer_out, n_layers_run + 1, (long)B * dm, layer_mean, s);
     HIPC(c, hipGetLastError());
     return SGPT_OK;
@@ -470,6 +535,7 @@ sgpt_status sgpt_model_set_pool_weights(sgpt_model* m, const float* w, int32_t n
         if (hipMalloc((void**)&p, (size_t)n * 4) != hipSuccess) return fail(c, SGPT_ERR_OOM, "hipMalloc pool weights failed");
         m->allocs.push_back(p);           // the old, smaller table is released with the model
         m->pool_w = p;
+        c->generation++;                  // captured graphs still point at the old table
     }
     m->pool_w_n = n;
     HIPC(c, hipMemcpy(m->pool_w, w, (size_t)n * 4, hipMemcpyDeviceToDevice));
@@ -553,18 +619,23 @@ sgpt_status sgpt_l2_normalize(sgpt_ctx* c, const float* in, int64_t n, int32_t d
     return SGPT_OK;
 }
 
-sgpt_status sgpt_f32_to_bf16(sgpt_ctx* c, const float* in, int64_t numel, void* out, void* stream) {
-    if (!c || !in || !out || numel <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_f32_to_bf16: bad arguments");
+sgpt_status sgpt_f32_to_16(sgpt_ctx* c, const float* in, int64_t numel, void* out, int32_t out_dtype, void* stream) {
+    if (!c || !in || !out || numel <= 0 || (out_dtype != SGPT_BF16 && out_dtype != SGPT_F16))
+        return fail(c, SGPT_ERR_INVALID, "sgpt_f32_to_16: bad arguments");
     HIPC(c, hipSetDevice(c->device));
-    launch_f32_to_bf16(in, numel, out, (hipStream_t)stream);
+    launch_f32_to_16(in, numel, out, out_dtype, (hipStream_t)stream);
     HIPC(c, hipGetLastError());
     return SGPT_OK;
 }
 
+sgpt_status sgpt_f32_to_bf16(sgpt_ctx* c, const float* in, int64_t numel, void* out, void* stream) {
+    return sgpt_f32_to_16(c, in, numel, out, SGPT_BF16, stream);
+}
+
 static sgpt_status check_score_dims(sgpt_ctx* c, int dtype, int d) {
-    if (dtype != SGPT_F32 && dtype != SGPT_BF16) return fail(c, SGPT_ERR_INVALID, "score: bad dtype");
-    const int mult = dtype == SGPT_BF16 ? 8 : 4;
-    if (d <= 0 || d % mult) return fail(c, SGPT_ERR_INVALID, "score: d must be a multiple of 4 (fp32) / 8 (bf16)");
+    if (dtype != SGPT_F32 && dtype != SGPT_BF16 && dtype != SGPT_F16) return fail(c, SGPT_ERR_INVALID, "score: bad dtype");
+    const int mult = dtype == SGPT_F32 ? 4 : 8;
+    if (d <= 0 || d % mult) return fail(c, SGPT_ERR_INVALID, "score: d must be a multiple of 4 (fp32) / 8 (bf16, f16)");
     return SGPT_OK;
 }
 
@@ -606,7 +677,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // bf16 fast path: the 256x256 LDS-DMA GEMM needs the query rows padded to a multiple of 256 (zero rows,
     // never stored) and d % 64 == 0; chunks that are multiples of 256 documents take it, the ragged tail and
     // fp32 go through the 128^2 kernel.
-    const bool fast = dtype == SGPT_BF16 && d % 64 == 0;
+    const bool fast = dtype != SGPT_F32 && d % 64 == 0 && d >= 128;
     const int nq_pad = (nq + 255) / 256 * 256;
     // Threshold-filtered chunks (after the first): see EPI_SCORE_FILTER.  Candidate capacity per query and chunk;
     // the doubling schedule below keeps the expected count at ~k.
@@ -649,7 +720,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         HIPC(c, hipMemsetAsync(qpad, 0, (size_t)nq_pad * d * 2, s));
         HIPC(c, hipMemcpyAsync(qpad, q, (size_t)nq * d * 2, hipMemcpyDeviceToDevice, s));
     }
-    const size_t esz = dtype == SGPT_BF16 ? 2 : 4;
+    const size_t esz = dtype == SGPT_F32 ? 4 : 2;
 
     // Materialise-and-select over documents [lo, hi): the reference's chunk loop (exact_search.py:96-132).
     // (pv, pi, have) = running best going in; the last chunk writes (fin_v, fin_i), earlier ones ping-pong.
@@ -762,7 +833,7 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
                             int32_t iters, float* ms_out) {
     if (!c || !ms_out || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_bench_gemm: bad arguments");
     HIPC(c, hipSetDevice(c->device));
-    const size_t esz = dtype == SGPT_BF16 ? 2 : 4, osz = out_dtype == SGPT_BF16 ? 2 : 4;
+    const size_t esz = dtype == SGPT_F32 ? 4 : 2, osz = out_dtype == SGPT_F32 ? 4 : 2;
     void *A = nullptr, *W = nullptr, *O = nullptr; float* bias = nullptr;
     HIPC(c, hipMalloc(&A, (size_t)M * K * esz));
     HIPC(c, hipMalloc(&W, (size_t)N * K * esz));

@@ -4,15 +4,15 @@
 // fp32 softmax, P.V.  Right/left padding never reaches a real token (pad keys are masked,
 // :119-120), so only the rows of each sequence's own span are touched.
 //
-// bf16 path (attn_bf16_kernel): one wave per 16 query rows, no LDS, no barriers.
-//   S^T = K.Q^T via v_mfma_f32_16x16x32_bf16 with K rows as the A-operand: a lane then owns ONE
+// 16-bit path (attn16_lds_kernel<H>, H = bf16 or f16 operands): one wave per 16 query rows.
+//   S^T = K.Q^T via v_mfma_f32_16x16x32_{bf16,f16} with K rows as the A-operand: a lane then owns ONE
 //   query (column lane&15) and keys {4g+r} of each 16-key tile, so
 //     - the row max / row sum are in-lane reductions + 2 shuffles (xor 16, 32),
 //     - the 8 probabilities a lane holds for a 32-key step ARE the B-operand fragment of
 //       O^T = V^T.P^T under the k-slot permutation  slot(g,j) <-> key 16*(j>>2) + 4g + (j&3);
 //       the A-operand (V^T rows, written transposed by the QKV GEMM epilogue) applies the same
 //       permutation with two 8-byte loads along the token axis.  No P round trip through LDS.
-//   Online softmax (running max m, running sum l) over 32-key steps; masked scores are -inf and
+//   Online softmax (running max m, running sum l) over 64-key tiles; masked scores are -inf and
 //   m starts at -1e30 so a fully masked step contributes exp(-inf) = 0 without NaN.
 //
 // fp32 path (attn_f32_kernel): exact-fp32 VALU kernel for the parity gate, one wave per query row.
@@ -32,120 +32,17 @@ namespace {
 #endif
 constexpr bool ATTN_NT = SGPT_ATTN_NT != 0;
 
-template <int DH>
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs p) {
-    constexpr int KS = DH / 32;  // k-slices of the QK^T contraction
-    constexpr int DT = DH / 16;  // 16-wide output tiles over the head dim
-    const int sq = blockIdx.z, head = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s0 = p.seq_off[sq];
-    const int alloc = p.seq_off[sq + 1] - s0;  // multiple of 16; rows >= seq_len are filler queries
-    const int q0 = blockIdx.x * 64 + wave * 16;
-    if (q0 >= alloc) return;
-    const int fr = lane & 15, g = lane >> 4;
-
-    const bf16_t* __restrict__ qb = static_cast<const bf16_t*>(p.q) + (long)head * DH;
-    const bf16_t* __restrict__ kb = static_cast<const bf16_t*>(p.k) + (long)head * DH;
-    const bf16_t* __restrict__ vt = static_cast<const bf16_t*>(p.v) + (long)head * DH * p.ldvt;
-
-    // Q as the B-operand: lane (query fr, k-group g) holds 8 contiguous head-dim elements
-    bf16x8 qf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (long)(s0 + q0 + fr) * p.ldq + ks * 32 + 8 * g);
-
-    f32x4 o[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -1e30f, l_run = 0.f;
-    const int qi = q0 + fr;  // this lane's query (sequence-relative)
-    const float slope = p.alibi ? p.alibi[head] : 0.f;
-
-    int j_lo = 0;
-    if (p.window > 0) { j_lo = q0 - p.window + 1; j_lo = j_lo < 0 ? 0 : (j_lo & ~31); }
-    const int j_hi = q0 + 15;  // last key any of the 16 queries may see
-    for (int j0 = j_lo; j0 <= j_hi; j0 += 32) {
-        // ---- S^T tiles: [16 keys][16 queries] x 2 ----
-        f32x4 s[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const bf16_t* kr = kb + (long)(s0 + j0 + nt * 16 + fr) * p.ldq + 8 * g;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + ks * 32);
-                s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[nt], 0, 0, 0);
-            }
-        }
-        // ---- mask + online softmax (lane: query qi, keys j0 + nt*16 + 4g + r) ----
-        float mx = -INFINITY;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kj = j0 + nt * 16 + 4 * g + r;
-                const bool vis = (kj <= qi) && (p.window <= 0 || kj > qi - p.window);
-                const float v = vis ? s[nt][r] * p.scale + slope * (float)kj : -INFINITY;
-                s[nt][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
-        float ps = 0.f;
-        float pv[8];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[nt][r] - m_new);
-                pv[nt * 4 + r] = e;
-                ps += e;
-            }
-        l_run = l_run * alpha + ps;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
-        }
-        // P^T fragment (B-operand): slot j <-> key j0 + 16*(j>>2) + 4g + (j&3)
-        uint4 pu;
-        pu.x = pack_bf16x2(pv[0], pv[1]); pu.y = pack_bf16x2(pv[2], pv[3]);
-        pu.z = pack_bf16x2(pv[4], pv[5]); pu.w = pack_bf16x2(pv[6], pv[7]);
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pu);
-        // ---- O^T += V^T . P^T ----
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const bf16_t* vr = vt + (long)(dt * 16 + fr) * p.ldvt + s0 + j0 + 4 * g;
-            uint4 vu;
-            const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
-            const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 16);
-            vu.x = v0.x; vu.y = v0.y; vu.z = v1.x; vu.w = v1.y;
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vu), pf, o[dt], 0, 0, 0);
-        }
-    }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_run;
-    // O^T tile dt: lane holds head-dim rows dt*16 + 4g + r for query column fr
-    bf16_t* orow = static_cast<bf16_t*>(p.ctx) + (long)(s0 + qi) * p.ldo + (long)head * DH + 4 * g;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-        *reinterpret_cast<uint2*>(orow + dt * 16) =
-            make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
-}
-
-// ---- v2: K / V^T tiles of 64 keys staged in LDS and shared by the block's 4 waves ----
-// The direct-from-global kernel above re-fetches every K/V fragment once per wave (4x) with 16
-// scattered 64-byte pieces per instruction and has one dependent global round trip per 8 MFMAs
-// (measured 2.4 % MFMA-busy).  Here a 256-thread block (64 queries of one (sequence, head)) loads
+// ---- K / V^T tiles of 64 keys staged in LDS and shared by the block's 8 waves ----
+// (A direct-from-global predecessor re-fetched every K/V fragment once per wave with 16 scattered 64-byte pieces
+// per instruction and one dependent global round trip per 8 MFMAs: 2.4 % MFMA-busy; removed in round 2.)
+// A 512-thread block (128 queries of one (sequence, head)) loads
 // each 64-key tile ONCE with row-contiguous 16-byte loads into LDS
 //     Ks[64 keys][DH]   (16-B chunk index XOR (key & 7): conflict-free ds_read_b128 fragments)
 //     Vs[DH][64 keys]   (same swizzle; ds_read_b64 pairs for the permuted k-slots)
 // and every wave takes its MFMA operands from there.  Same math / lane maps as above.
-template <int DH>
-__global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
+// H = bf16_t | f16_t: the 16-bit format of q / k / V^T, of the probabilities fed to the P.V MFMA and of the context
+template <typename H, int DH>
+__global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
     constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
     constexpr int NT = 512, QB = 128;                          // 8 waves x 16 queries per block
     constexpr int ORS = DH * 2 + 16;                           // output-transpose row stride (bytes)
@@ -166,10 +63,10 @@ __global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
     const bf16_t* __restrict__ kb = static_cast<const bf16_t*>(p.k) + (long)head * DH;
     const bf16_t* __restrict__ vt = static_cast<const bf16_t*>(p.v) + (long)head * DH * p.ldvt;
 
-    bf16x8 qf[KS];
+    uint4 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-        qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (long)(s0 + q0 + fr) * p.ldq + ks * 32 + 8 * g);
+        qf[ks] = *reinterpret_cast<const uint4*>(qb + (long)(s0 + q0 + fr) * p.ldq + ks * 32 + 8 * g);
 
     f32x4 o[DT];
 #pragma unroll
@@ -218,7 +115,7 @@ __global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const uint4 kv = Ks[row * CPR + ((ks * 4 + g) ^ (row & 7))];
-                s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kv), qf[ks], s[nt], 0, 0, 0);
+                s[nt] = Half<H>::mfma16(kv, qf[ks], s[nt]);
             }
         }
         float mx = -INFINITY;
@@ -244,8 +141,8 @@ __global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
             const float e0 = __expf(s[nt][0] - m_new), e1 = __expf(s[nt][1] - m_new);
             const float e2 = __expf(s[nt][2] - m_new), e3 = __expf(s[nt][3] - m_new);
             ps += (e0 + e1) + (e2 + e3);
-            pw[nt * 2] = pack_bf16x2(e0, e1);
-            pw[nt * 2 + 1] = pack_bf16x2(e2, e3);
+            pw[nt * 2] = Half<H>::pack2(e0, e1);          // probabilities in [0, 1]: inside either format's range
+            pw[nt * 2 + 1] = Half<H>::pack2(e2, e3);
         }
         l_run = l_run * alpha + ps;
 #pragma unroll
@@ -257,7 +154,6 @@ __global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
         for (int step = 0; step < 2; ++step) {
             uint4 pu;
             pu.x = pw[step * 4]; pu.y = pw[step * 4 + 1]; pu.z = pw[step * 4 + 2]; pu.w = pw[step * 4 + 3];
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, pu);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int row = dt * 16 + fr;
@@ -267,7 +163,7 @@ __global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
                 const uint2 v0 = *reinterpret_cast<const uint2*>(vrow + c0 * 16 + (g & 1) * 8);
                 const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + c1 * 16 + (g & 1) * 8);
                 uint4 vu; vu.x = v0.x; vu.y = v0.y; vu.z = v1.x; vu.w = v1.y;
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vu), pf, o[dt], 0, 0, 0);
+                o[dt] = Half<H>::mfma16(vu, pu, o[dt]);
             }
         }
     }
@@ -282,7 +178,8 @@ __global__ __launch_bounds__(512) void attn_bf16_lds_kernel(const AttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
         *reinterpret_cast<uint2_a*>(os + fr * ORS + (dt * 16 + 4 * g) * 2) =
-            make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+            make_uint2(Half<H>::pack2(o[dt][0] * inv, o[dt][1] * inv), Half<H>::pack2(o[dt][2] * inv, o[dt][3] * inv));   // a convex
+    // combination of V rows: bounded by max|V|, which the V projection's epilogue already range-checked (f16)
     constexpr int RPI = 64 / CPR;                    // rows per store instruction
     bf16_t* obase = static_cast<bf16_t*>(p.ctx) + (long)(s0 + q0) * p.ldo + (long)head * DH;
 #pragma unroll
@@ -346,20 +243,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
 }  // namespace
 
 void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
-    dim3 grid((a.max_alloc_len + 63) / 64, a.H, a.B);
-    static const bool direct = getenv("SGPT_ATTN_DIRECT") != nullptr;   // A/B switch: LDS-staged (default) vs direct
-    if (direct) {
-        if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_kernel<64>, grid, dim3(256), 0, s, a);
-        else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_kernel<128>, grid, dim3(256), 0, s, a);
-        else if (a.dh == 256) hipLaunchKernelGGL(attn_bf16_kernel<256>, grid, dim3(256), 0, s, a);
-        else abort();
-        return;
-    }
-    dim3 grid2((a.max_alloc_len + 127) / 128, a.H, a.B);
-    if (a.dh == 64) hipLaunchKernelGGL(attn_bf16_lds_kernel<64>, grid2, dim3(512), 0, s, a);
-    else if (a.dh == 128) hipLaunchKernelGGL(attn_bf16_lds_kernel<128>, grid2, dim3(512), 0, s, a);
-    else if (a.dh == 256) hipLaunchKernelGGL(attn_bf16_lds_kernel<256>, grid2, dim3(512), 0, s, a);
+    dim3 grid((a.max_alloc_len + 127) / 128, a.H, a.B);
+#define ATTN_CASE(H)                                                                                       \
+    if (a.dh == 64) hipLaunchKernelGGL((attn16_lds_kernel<H, 64>), grid, dim3(512), 0, s, a);              \
+    else if (a.dh == 128) hipLaunchKernelGGL((attn16_lds_kernel<H, 128>), grid, dim3(512), 0, s, a);       \
+    else if (a.dh == 256) hipLaunchKernelGGL((attn16_lds_kernel<H, 256>), grid, dim3(512), 0, s, a);       \
     else abort();
+    if (a.dtype == DT_F16) { ATTN_CASE(f16_t) } else { ATTN_CASE(bf16_t) }
+#undef ATTN_CASE
 }
 
 void launch_attn_f32(const AttnArgs& a, hipStream_t s) {

@@ -4,8 +4,17 @@
 #include <stdint.h>
 
 typedef uint16_t bf16_t;  // raw bf16 bits in memory
+// raw IEEE binary16 bits in memory.  A distinct type (not a second typedef of uint16_t) so that kernels templated on the
+// 16-bit operand format pick the matching conversion / MFMA; pointer arithmetic on either 16-bit type is the same.
+struct f16_t { uint16_t bits; };
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// element-type codes of include/sgpt_hip.h
+constexpr int DT_F32 = 0, DT_BF16 = 1, DT_FP8W = 2, DT_F16 = 3;
+__host__ __device__ constexpr bool dt_is16(int dt) { return dt == DT_BF16 || dt == DT_F16; }
 
 #define WAVE 64
 
@@ -25,6 +34,63 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
+
+// fp32 -> f16, round-to-nearest-even (v_cvt_f16_f32 under the default rounding mode; NOT v_cvt_pkrtz), bit-identical to
+// torch.Tensor.to(float16).  Overflow gives +-inf: every kernel that rounds activations to f16 tracks max|v| and raises
+// the context's range flag (see RangeTrack) so a model whose activations leave the f16 range fails loudly.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+
+// 16-bit operand format traits: H = bf16_t | f16_t
+template <typename H> struct Half;
+template <> struct Half<bf16_t> {
+    static constexpr bool is_f16 = false;
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    static __device__ __forceinline__ float lo(uint32_t u) { return __uint_as_float(u << 16); }
+    static __device__ __forceinline__ float hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+    static __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Half<f16_t> {
+    static constexpr bool is_f16 = true;
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+    static __device__ __forceinline__ float lo(uint32_t u) {
+        return (float)__builtin_bit_cast(f16x2_t, u)[0];
+    }
+    static __device__ __forceinline__ float hi(uint32_t u) {
+        return (float)__builtin_bit_cast(f16x2_t, u)[1];
+    }
+    static __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <typename H> __device__ __forceinline__ uint16_t f32_to_h(float f) { return (uint16_t)(Half<H>::pack2(f, 0.0f) & 0xffffu); }
+
+// f16 range guard.  Kernels that round fp32 activations to f16 feed every value through note(); finish() raises the
+// context's device flag when a magnitude reached RANGE_LIMIT (half of the f16 maximum: head-room for the GPT-J rotary
+// rotation, which can grow a pair by sqrt(2)).  bf16 has the fp32 exponent range: the tracker compiles to nothing.
+constexpr float RANGE_LIMIT = 32768.0f;
+template <typename H> struct RangeTrack {
+    float amax = 0.f;
+    __device__ __forceinline__ void note(float a, float b) {
+        if constexpr (Half<H>::is_f16) amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));   // v_max3_f32 with |.| modifiers
+    }
+    __device__ __forceinline__ void finish(int* flag) const {
+        if constexpr (Half<H>::is_f16) {
+            if (flag != nullptr && !(amax < RANGE_LIMIT)) atomicOr(flag, 1);            // also catches NaN
+        }
+    }
+};
 
 // 16-byte global store.  NT = non-temporal (`global_store_dwordx4 ... nt`): for streaming outputs the producing
 // kernel never re-reads.  Measured on the GEMM epilogues: plain stores write-allocate in the 4 MiB XCD L2 and
@@ -122,6 +188,7 @@ struct GemmArgs {
     int cand_cap;
     long idx_base;      // global index of W row 0
     long long* dbg;     // optional s_memtime stamps of workgroup 0 / wave 0 (micro-benchmark diagnostics)
+    int* range_flag;    // f16 outputs: device flag raised when a stored magnitude reaches RANGE_LIMIT (or null)
 };
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
@@ -138,17 +205,18 @@ struct AttnArgs {
     float scale;
     int max_alloc_len;
     const float* alibi;  // [H] ALiBi slopes (BLOOM) or null: score += slope_h * key_index (HF:bloom:45-89)
+    int dtype;           // DT_BF16 | DT_F16 (16-bit path)
 };
-void launch_attn_bf16(const AttnArgs& a, hipStream_t s);
+void launch_attn_bf16(const AttnArgs& a, hipStream_t s);   // 16-bit MFMA path (bf16 or f16 by a.dtype)
 void launch_attn_f32(const AttnArgs& a, hipStream_t s);
 
-void launch_embed(const int* ids, const int* pos, const float* wte, const float* wpe, float* x, int T, int d,
-                  hipStream_t s);
+void launch_embed(const int* ids, const int* pos, const float* wte, const float* wpe, float* x, int T, int d, int vocab,
+                  int max_pos, hipStream_t s);
 void launch_layernorm(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
                       float eps, hipStream_t s);
 void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,
                      const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize,
-                     const float* pos_weights, float* out, hipStream_t s);
+                     const float* pos_weights, int pos_weights_n, float* out, hipStream_t s);
 void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, int d, int mode,
                  const float* pos_weights, float* out, hipStream_t s);
 // fp8 e4m3fn weight storage, one power-of-two scale per row (output channel)
@@ -163,6 +231,9 @@ void launch_logprob_rows(const float* logits, long ld, int V, const int* targets
 // out[i] = mean_j in[j][i], in fp32 [n0][n] (layer average of the meanmean / lasttokenmean methods)
 void launch_mean_over_axis0(const float* in, int n0, long n, float* out, hipStream_t s);
 void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s);
+void launch_f32_to_16(const float* in, long numel, void* out, int out_dtype, hipStream_t s);   // DT_BF16 | DT_F16, RNE
+// max |in[i]| folded into *out_bits (the fp32 bit pattern of a non-negative float, atomicMax; zero it first)
+void launch_absmax(const float* in, long numel, unsigned* out_bits, hipStream_t s);
 void launch_fill_f32(float* p, long n, float v, hipStream_t s);
 // GPT-J rotary embedding, in place on the q / k columns of the projection buffer
 void launch_rope(void* qk, int dtype, long ld, long k_off, const int* pos, const float* sin_t, const float* cos_t, int T,

@@ -15,17 +15,21 @@ namespace {
 // ---- wte[ids] + wpe[pos]  (HF:gpt_neo/modeling_gpt_neo.py:444,462-463) ----
 __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ ids, const int* __restrict__ pos,
                                                     const float* __restrict__ wte, const float* __restrict__ wpe,
-                                                    float* __restrict__ x, int T, int d) {
+                                                    float* __restrict__ x, int T, int d, int vocab, int max_pos) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
     const int lane = threadIdx.x & 63;
-    const float4* a = reinterpret_cast<const float4*>(wte + (long)ids[row] * d);
+    // ids / positions are clamped into the tables: a C-ABI caller's bad id reads a wrong row, never out of bounds
+    // (the Python host validates and raises before the call, model.py::SGPTModel.pack)
+    int id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float4* a = reinterpret_cast<const float4*>(wte + (long)id * d);
     float4* o = reinterpret_cast<float4*>(x + (long)row * d);
     if (wpe == nullptr) {  // GPT-J: no learned position embedding (HF:gptj:484)
         for (int c = lane; c < d / 4; c += 64) o[c] = a[c];
         return;
     }
-    const float4* b = reinterpret_cast<const float4*>(wpe + (long)pos[row] * d);
+    int ps = pos[row]; ps = ps < 0 ? 0 : (ps >= max_pos ? max_pos - 1 : ps);
+    const float4* b = reinterpret_cast<const float4*>(wpe + (long)ps * d);
     for (int c = lane; c < d / 4; c += 64) {
         const float4 u = a[c], v = b[c];
         o[c] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)row * d + c) = r.v[i];
             } else {
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)row * d + c) =
-                    make_uint2(pack_bf16x2(r.v[i].x, r.v[i].y), pack_bf16x2(r.v[i].z, r.v[i].w));
+                    make_uint2(Half<OutT>::pack2(r.v[i].x, r.v[i].y), Half<OutT>::pack2(r.v[i].z, r.v[i].w));
             }
         }
     }
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void lnf_pool_kernel(const float* __restrict__
                                                        const int* __restrict__ seq_len,
                                                        const int* __restrict__ pad_left, int d, float eps,
                                                        int apply_ln, int mode, int normalize,
-                                                       const float* __restrict__ pw, float* __restrict__ out) {
+                                                       const float* __restrict__ pw, int pw_n, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][d] + 8
     const int sq = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void lnf_pool_kernel(const float* __restrict__
         if (apply_ln) r.normalize(g, b, d, eps, lane);
         // mode 3 (learntmean): trained per-position weights, indexed like the padded position
         // (WeightedMeanPooling.py:21-39; useb_dense_retriever.py:253-270)
-        const float w = mode == 0 ? (float)(P + t + 1) : (mode == 3 ? pw[P + t] : 1.0f);
+        const float w = mode == 0 ? (float)(P + t + 1) : (mode == 3 ? pw[P + t < pw_n ? P + t : pw_n - 1] : 1.0f);   // index clamped: no OOB read
         den += w;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -177,6 +181,11 @@ template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
                        __uint_as_float(u.y & 0xffff0000u));
 }
 
+template <> __device__ __forceinline__ float4 load4<f16_t>(const f16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(Half<f16_t>::lo(u.x), Half<f16_t>::hi(u.x), Half<f16_t>::lo(u.y), Half<f16_t>::hi(u.y));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pool_kernel(const T* __restrict__ h, const int* __restrict__ mask, int S, int d,
                                                    int mode, const float* __restrict__ pw, float* __restrict__ out) {
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ i
     for (int c = lane; c < d; c += 64) {
         const float v = xr[c] / nrm;
         if constexpr (sizeof(OutT) == 4) reinterpret_cast<float*>(out)[row * d + c] = v;
-        else reinterpret_cast<bf16_t*>(out)[row * d + c] = f32_to_bf16(v);
+        else reinterpret_cast<uint16_t*>(out)[row * d + c] = f32_to_h<OutT>(v);
     }
 }
 
@@ -247,8 +256,8 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ buf, long ld,
             *reinterpret_cast<float2*>(ptr) = make_float2(v.x * cs - v.y * sn, v.y * cs + v.x * sn);
         } else {
             const uint32_t u = *reinterpret_cast<const uint32_t*>(ptr);
-            const float x0 = __uint_as_float(u << 16), x1 = __uint_as_float(u & 0xffff0000u);
-            *reinterpret_cast<uint32_t*>(ptr) = pack_bf16x2(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
+            const float x0 = Half<T>::lo(u), x1 = Half<T>::hi(u);   // f16: |rotated| <= sqrt(2) * RANGE_LIMIT < 65504
+            *reinterpret_cast<uint32_t*>(ptr) = Half<T>::pack2(x0 * cs - x1 * sn, x1 * cs + x0 * sn);
         }
     }
 }
@@ -326,10 +335,24 @@ __global__ __launch_bounds__(256) void fp8_dequant_rows_kernel(const uint8_t* __
     }
 }
 
-__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, long numel,
-                                                       bf16_t* __restrict__ out) {
+template <typename H>
+__global__ __launch_bounds__(256) void cvt16_kernel(const float* __restrict__ in, long numel, uint16_t* __restrict__ out) {
     const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += stride) out[i] = f32_to_bf16(in[i]);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += stride) out[i] = f32_to_h<H>(in[i]);
+}
+
+// max |x| of an fp32 array folded into *out_bits by atomicMax on the bit pattern (non-negative floats order like
+// unsigned integers; NaN maps above +inf and is therefore caught by a `< limit` test on the result)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ in, long numel, unsigned* __restrict__ out_bits) {
+    const long stride = (long)gridDim.x * 256;
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += stride) {
+        const unsigned b = __float_as_uint(in[i]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
 }
 
 __global__ __launch_bounds__(256) void mean_axis0_kernel(const float* __restrict__ in, int n0, long n,
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(256) void fill_rand_kernel(T* __restrict__ p, long 
         unsigned h = (unsigned)i * 2654435761u ^ seed;
         h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
         const float v = ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
-        if constexpr (sizeof(T) == 4) p[i] = v; else p[i] = f32_to_bf16(v);
+        if constexpr (sizeof(T) == 4) p[i] = v; else reinterpret_cast<uint16_t*>(p)[i] = f32_to_h<T>(v);
     }
 }
 
@@ -413,17 +436,20 @@ inline int cap_grid(long blocks) { return (int)(blocks < 1 ? 1 : (blocks > 8192 
 
 }  // namespace
 
-void launch_embed(const int* ids, const int* pos, const float* wte, const float* wpe, float* x, int T, int d,
-                  hipStream_t s) {
-    hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, pos, wte, wpe, x, T, d);
+void launch_embed(const int* ids, const int* pos, const float* wte, const float* wpe, float* x, int T, int d, int vocab,
+                  int max_pos, hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, pos, wte, wpe, x, T, d, vocab, max_pos);
 }
 
 void launch_layernorm(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
                       float eps, hipStream_t s) {
 #define LN_CASE(NV)                                                                                              \
-    if (out_dtype == 1)                                                                                          \
+    if (out_dtype == DT_BF16)                                                                                    \
         hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,          \
                            (bf16_t*)out, T, d, eps);                                                             \
+    else if (out_dtype == DT_F16)                                                                                \
+        hipLaunchKernelGGL((layernorm_kernel<f16_t, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,           \
+                           (f16_t*)out, T, d, eps);                                                              \
     else                                                                                                         \
         hipLaunchKernelGGL((layernorm_kernel<float, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,           \
                            (float*)out, T, d, eps);
@@ -436,11 +462,11 @@ void launch_layernorm(const float* x, const float* g, const float* b, void* out,
 
 void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,
                      const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize,
-                     const float* pos_weights, float* out, hipStream_t s) {
+                     const float* pos_weights, int pos_weights_n, float* out, hipStream_t s) {
     const size_t sm = (size_t)(4 * d + 8) * sizeof(float);
 #define LP_CASE(NV)                                                                                              \
     hipLaunchKernelGGL((lnf_pool_kernel<NV>), dim3(B), dim3(256), sm, s, x, g, b, seq_off, seq_len, pad_left, d, \
-                       eps, apply_ln, mode, normalize, pos_weights, out);
+                       eps, apply_ln, mode, normalize, pos_weights, pos_weights_n, out);
     const int nv = (d + 255) / 256;
     if (nv <= 1) { LP_CASE(1) } else if (nv <= 2) { LP_CASE(2) } else if (nv <= 3) { LP_CASE(3) }
     else if (nv <= 4) { LP_CASE(4) } else if (nv <= 8) { LP_CASE(8) } else if (nv <= 10) { LP_CASE(10) }
@@ -451,8 +477,10 @@ void launch_lnf_pool(const float* x, const float* g, const float* b, const int* 
 void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, int d, int mode,
                  const float* pos_weights, float* out, hipStream_t s) {
     dim3 grid(B, (d / 4 + 255) / 256);
-    if (dtype == 1)
+    if (dtype == DT_BF16)
         hipLaunchKernelGGL(pool_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)hidden, mask, S, d, mode, pos_weights, out);
+    else if (dtype == DT_F16)
+        hipLaunchKernelGGL(pool_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)hidden, mask, S, d, mode, pos_weights, out);
     else
         hipLaunchKernelGGL(pool_kernel<float>, grid, dim3(256), 0, s, (const float*)hidden, mask, S, d, mode, pos_weights, out);
 }
@@ -488,12 +516,20 @@ void launch_mean_over_axis0(const float* in, int n0, long n, float* out, hipStre
 
 void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s) {
     const int grid = (int)((n + 3) / 4);
-    if (out_dtype == 1) hipLaunchKernelGGL(l2norm_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, in, n, d, (bf16_t*)out);
+    if (out_dtype == DT_BF16) hipLaunchKernelGGL(l2norm_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, in, n, d, (bf16_t*)out);
+    else if (out_dtype == DT_F16) hipLaunchKernelGGL(l2norm_kernel<f16_t>, dim3(grid), dim3(256), 0, s, in, n, d, (f16_t*)out);
     else hipLaunchKernelGGL(l2norm_kernel<float>, dim3(grid), dim3(256), 0, s, in, n, d, (float*)out);
 }
 
-void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s) {
-    hipLaunchKernelGGL(cvt_bf16_kernel, dim3(cap_grid((numel + 255) / 256)), dim3(256), 0, s, in, numel, (bf16_t*)out);
+void launch_f32_to_16(const float* in, long numel, void* out, int out_dtype, hipStream_t s) {
+    const int grid = cap_grid((numel + 255) / 256);
+    if (out_dtype == DT_F16) hipLaunchKernelGGL(cvt16_kernel<f16_t>, dim3(grid), dim3(256), 0, s, in, numel, (uint16_t*)out);
+    else hipLaunchKernelGGL(cvt16_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, in, numel, (uint16_t*)out);
+}
+void launch_f32_to_bf16(const float* in, long numel, void* out, hipStream_t s) { launch_f32_to_16(in, numel, out, DT_BF16, s); }
+
+void launch_absmax(const float* in, long numel, unsigned* out_bits, hipStream_t s) {
+    hipLaunchKernelGGL(absmax_kernel, dim3(cap_grid((numel + 255) / 256)), dim3(256), 0, s, in, numel, out_bits);
 }
 
 void launch_fill_f32(float* p, long n, float v, hipStream_t s) {
@@ -501,8 +537,10 @@ void launch_fill_f32(float* p, long n, float v, hipStream_t s) {
 }
 
 void launch_fill_rand(void* p, long n, int dtype, unsigned seed, float scale, hipStream_t s) {
-    if (dtype == 1)
+    if (dtype == DT_BF16)
         hipLaunchKernelGGL(fill_rand_kernel<bf16_t>, dim3(cap_grid((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)p, n, seed, scale);
+    else if (dtype == DT_F16)
+        hipLaunchKernelGGL(fill_rand_kernel<f16_t>, dim3(cap_grid((n + 255) / 256)), dim3(256), 0, s, (f16_t*)p, n, seed, scale);
     else
         hipLaunchKernelGGL(fill_rand_kernel<float>, dim3(cap_grid((n + 255) / 256)), dim3(256), 0, s, (float*)p, n, seed, scale);
 }
@@ -512,8 +550,10 @@ void launch_rope(void* qk, int dtype, long ld, long k_off, const int* pos, const
     const int half = rotary_dim / 2;
     const long n = (long)T * H * half;
     const int grid = (int)((n + 255) / 256);
-    if (dtype == 1)
+    if (dtype == DT_BF16)
         hipLaunchKernelGGL(rope_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)qk, ld, k_off, pos, sin_t, cos_t, T, H, dh, half);
+    else if (dtype == DT_F16)
+        hipLaunchKernelGGL(rope_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (f16_t*)qk, ld, k_off, pos, sin_t, cos_t, T, H, dh, half);
     else
         hipLaunchKernelGGL(rope_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)qk, ld, k_off, pos, sin_t, cos_t, T, H, dh, half);
 }

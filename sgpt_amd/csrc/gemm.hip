@@ -43,15 +43,14 @@ constexpr int CH = 8;  // 16-byte chunks per row per k-step
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<bf16_t> { static constexpr int EPC = 8; };
+template <> struct ElemTraits<f16_t> { static constexpr int EPC = 8; };
 template <> struct ElemTraits<float> { static constexpr int EPC = 4; };
 
 template <typename T, bool SWAP>
 __device__ __forceinline__ void mma(f32x4& acc, const uint4& act, const uint4& wgt) {
     if constexpr (sizeof(T) == 2) {
-        bf16x8 a = __builtin_bit_cast(bf16x8, act);
-        bf16x8 w = __builtin_bit_cast(bf16x8, wgt);
-        if constexpr (SWAP) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
-        else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc, 0, 0, 0);
+        if constexpr (SWAP) acc = Half<T>::mfma16(wgt, act, acc);
+        else acc = Half<T>::mfma16(act, wgt, acc);
     } else {
         const float a[4] = {__uint_as_float(act.x), __uint_as_float(act.y), __uint_as_float(act.z),
                             __uint_as_float(act.w)};
@@ -72,9 +71,16 @@ template <> __device__ __forceinline__ void store4<float>(float* p, float a, flo
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
 }
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_f16x2(a, b), pack_f16x2(c, d));
+}
 template <typename OutT> __device__ __forceinline__ void store1(OutT* p, float a);
 template <> __device__ __forceinline__ void store1<float>(float* p, float a) { *p = a; }
 template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float a) { *p = f32_to_bf16(a); }
+template <> __device__ __forceinline__ void store1<f16_t>(f16_t* p, float a) { p->bits = f32_to_h<f16_t>(a); }
+// range tracker of the output format (a no-op unless OutT = f16_t)
+template <typename OutT> struct OutRange { typedef RangeTrack<bf16_t> type; };
+template <> struct OutRange<f16_t> { typedef RangeTrack<f16_t> type; };
 
 // NI = 16-row MFMA fragments per wave and dimension: 4 -> 128x128 tile (64x64 per wave), 2 -> 64x64 tile (32x32 per wave)
 // for problems too small to fill the chip with larger tiles.  Every GEMM kernel in this file feeds each output element the
@@ -194,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     // ---------------- epilogue ----------------
     OutT* __restrict__ out = static_cast<OutT*>(p.out);
     const int mv = p.m_valid;
+    typename OutRange<OutT>::type range;
     if constexpr (SWAP) {
         // lane: m = .. + fr ; n = .. + 4g + r  -> 4 consecutive n, row-major vector store
 #pragma unroll
@@ -212,9 +219,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                     const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
                     v[0] += bb.x + rr.x; v[1] += bb.y + rr.y; v[2] += bb.z + rr.z; v[3] += bb.w + rr.w;
                 } else if (EPI == EPI_BIAS_GELU || (EPI == EPI_STORE && p.bias != nullptr)) {
-                    // N is a multiple of 4 for every biased projection
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    if (full) {
+                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    } else {       // ragged last column group (LM head: vocab % 4 != 0): no read past the bias array
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (n + r < N) ? p.bias[n + r] : 0.f;
+                    }
                 }
                 if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (v[r] != v[r]) ? -1.0f : v[r];  // exact_search.py:99
                 }
+                range.note(v[0], v[1]); range.note(v[2], v[3]);
                 OutT* dst = out + (long)m * p.ldo + n;
                 if (full) {
                     store4<OutT>(dst, v[0], v[1], v[2], v[3]);
@@ -246,212 +258,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 const int m = m0 + wm * (16 * NI) + i * 16 + 4 * g;
                 if (m >= M) continue;  // M (token axis) is padded to a multiple of 128 by the caller
                 const float bn = p.bias ? p.bias[n] : 0.f;   // BLOOM: V projection has a bias
+                range.note(acc[i][j][0] + bn, acc[i][j][1] + bn); range.note(acc[i][j][2] + bn, acc[i][j][3] + bn);
                 store4<OutT>(out + (long)n * p.ldo + m, acc[i][j][0] + bn, acc[i][j][1] + bn, acc[i][j][2] + bn, acc[i][j][3] + bn);
             }
         }
     }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// 256x256 tile, 8 waves (2 x 4, 128x64 per wave), bf16 only: the throughput kernel of the encoder.
-// Why not the 128^2 kernel above: per k-step it moves 64 KiB LDS->VGPR plus 32 KiB VGPR->LDS
-// (ds_write_b128 ~79 B/clk) = ~660 LDS cycles against 512 MFMA cycles: LDS-bound by construction.
-// Here the per-wave tile doubles (LDS reads per FLOP x0.75), the block tile quadruples (fills
-// per FLOP x0.5) and the fill is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
-// ds_write).  The DMA writes LDS lane-linearly, so the 16-B chunk swizzle (chunk ^ row&7) is
-// applied on the per-lane SOURCE address and again on the fragment read (cdna guide rule 21).
-// Two LDS stages of 64 KiB; the DMA of k-step k+1 is in flight during the MFMAs of k-step k.
-template <int EPI, typename OutT, bool SWAP>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
-    if (p.pred != nullptr && *p.pred == 0) return;   // predicated (fallback) launch that is not needed
-    typedef __attribute__((address_space(3))) char* lds_cptr_t;
-    constexpr int TM = 256, TN = 256;
-    __shared__ __attribute__((aligned(16))) uint4 lds[2][2][TM * CH];  // 128 KiB
-
-    const int N = p.N, K = p.K;
-    const int MT = p.M / TM, NT = N / TN;
-    // Persistent: one workgroup per CU walks tiles b, b+grid, ... (grid is a multiple of 8, so a
-    // workgroup's tiles stay on its XCD).  The LONGER tile axis ("major": tokens for the encoder GEMMs,
-    // documents for the scorer) is interleaved over the 8 XCDs; inside an XCD tiles are ordered in
-    // 4 (major) x 8 (minor) supertiles so the ~32 tiles in flight share 4 + 8 operand panels in the L2.
-    constexpr int GM = 4, GN = 8;
-    const bool m_major = MT >= NT;
-    const int AT = m_major ? MT : NT, BT = m_major ? NT : MT;   // major / minor tile counts
-    const int per_band = GM * BT;
-    const int tiles_total = ((AT + 7) / 8 + GM - 1) / GM * GM * 8 * BT;   // padded tile-id space
-    auto tile_coords = [&](int tile, int& m0, int& n0) -> bool {
-        const int xcd = tile & 7, local = tile >> 3;
-        const int band = local / per_band, inb = local % per_band;
-        const int ng = inb / (GM * GN);
-        const int gn = (BT - ng * GN) < GN ? (BT - ng * GN) : GN;
-        const int r = inb - ng * GM * GN;
-        const int at = xcd + 8 * (band * GM + r / gn), bt = ng * GN + r % gn;
-        m0 = (m_major ? at : bt) * TM; n0 = (m_major ? bt : at) * TN;
-        return at < AT;
-    };
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int fr = lane & 15, g = lane >> 4;
-
-    // LDS-DMA: wave w fills rows [32w, 32w+32) of both operands, 8 rows (1 KiB) per instruction.
-    // lane l -> LDS (row 8q + (l>>3), slot l&7) <- global chunk (l&7)^(l>>3) of that row.
-    const bf16_t* __restrict__ Ag = static_cast<const bf16_t*>(p.A);
-    const bf16_t* __restrict__ Wg = static_cast<const bf16_t*>(p.W);
-    const int lrow = wave * 32 + (lane >> 3);
-    const int lchunk = (lane & 7) ^ (lane >> 3);
-    const long astep = 8 * p.lda, wstep = 8 * p.ldw;
-
-    // Inline asm, not __builtin_amdgcn_global_load_lds: hipcc treats the builtin as an LDS store and
-    // drains it (s_waitcnt vmcnt(0)) in front of the very next ds_read, which would serialise the
-    // DMA of k-step k+1 with the MFMAs of k-step k.  The asm form is invisible to that pass; its
-    // completion is waited for by hand (vmcnt(0) + barrier at the top of the next step).
-    // M0 = wave-uniform LDS byte address of the 1-KiB destination (saved/restored: compiler-reserved).
-    const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0][0][0]);
-    auto dma16 = [&](const bf16_t* src, unsigned dst_byte) {
-        unsigned keep;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(dst_byte);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "s"(dst)
-                     : "memory");
-    };
-    auto issue = [&](const bf16_t* asrc, const bf16_t* wsrc, int kt, int st) {
-        const int kc = kt * 64;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned row_off = (unsigned)((wave * 32 + q * 8) * CH * 16);
-            dma16(asrc + q * astep + kc, lds_base + (unsigned)((st * 2 + 0) * TM * CH * 16) + row_off);
-            dma16(wsrc + q * wstep + kc, lds_base + (unsigned)((st * 2 + 1) * TM * CH * 16) + row_off);
-        }
-    };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // one k-step = two 32-wide slices.  The 8 DMA pieces of the NEXT step are issued one behind every
-    // 4 MFMAs of slice 0, so their ~60 issue cycles each hide under the matrix pipe instead of sitting
-    // between the barrier and the first ds_read.
-    auto kstep = [&](int st, const bf16_t* ia, const bf16_t* iw, int ikt) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 af[8], wf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + fr;
-                wf[j] = lds[st][1][row * CH + ((4 * ks + g) ^ (row & 7))];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = wm * 128 + i * 16 + fr;
-                af[i] = lds[st][0][row * CH + ((4 * ks + g) ^ (row & 7))];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mma<bf16_t, SWAP>(acc[i][j], af[i], wf[j]);
-                if (ks == 0) {   // one 1-KiB DMA piece behind every 4 MFMAs of slice 0 (branch-free)
-                    const int q = i >> 1;
-                    const unsigned row_off = (unsigned)((wave * 32 + q * 8) * CH * 16);
-                    if (i & 1) dma16(iw + q * wstep + ikt * 64, lds_base + (unsigned)(((st ^ 1) * 2 + 1) * TM * CH * 16) + row_off);
-                    else dma16(ia + q * astep + ikt * 64, lds_base + (unsigned)(((st ^ 1) * 2 + 0) * TM * CH * 16) + row_off);
-                }
-            }
-        }
-    };
-
-    const int nk = K / 64;
-    OutT* __restrict__ out = static_cast<OutT*>(p.out);
-
-    // first valid tile of this workgroup
-    int tile = blockIdx.x, m0 = 0, n0 = 0;
-    while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
-    if (tile >= tiles_total) return;
-    const bf16_t* asrc = Ag + (long)(m0 + lrow) * p.lda + lchunk * 8;
-    const bf16_t* wsrc = Wg + (long)(n0 + lrow) * p.ldw + lchunk * 8;
-    int st = 0;
-    int dbg_tile = 0;
-#define STAMP(k)                                                                                   \
-    if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 8) p.dbg[dbg_tile * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
-    bool first_tile = true;
-    // Start-up stagger: all 256 workgroups run equally long tiles, so without it every CU reaches its
-    // epilogue (the HBM-heavy phase: residual read-modify-write) at the same moment and the chip
-    // alternates between an HBM-bound and an MFMA-bound phase.  Four phases per XCD, offset by
-    // `skew` cycles each, spread the epilogue traffic under the other CUs' MFMA phases.
-    if (p.skew > 0) {
-        const int phase = (blockIdx.x >> 3) & 3;
-        const long until = (long)__builtin_amdgcn_s_memtime() + (long)phase * p.skew;
-        while (phase && (long)__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
-    }
-    issue(asrc, wsrc, 0, 0);
-    while (true) {
-        // look up the next tile now: its first k-step is prefetched under this tile's last MFMAs
-        int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
-        while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
-        const bool has_next = ntile < tiles_total;
-        const bf16_t* nasrc = Ag + (long)(nm0 + lrow) * p.lda + lchunk * 8;
-        const bf16_t* nwsrc = Wg + (long)(nn0 + lrow) * p.ldw + lchunk * 8;
-        for (int kt = 0; kt < nk; ++kt) {
-            // this wave's DMA of this step has landed.  Step 0 of a follow-up tile was already waited for
-            // BEFORE the previous epilogue issued its stores (below), so those stores get a whole k-step
-            // of MFMAs to drain before the next vmcnt(0) (CDNA vmcnt counts stores as well).
-            if (kt > 0 || first_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                   // everyone's has; the other stage is free
-            if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 4 && kt < 12)
-                p.dbg[64 + dbg_tile * 16 + kt] = (long long)__builtin_amdgcn_s_memtime();
-            // prefetch target: next k-step of this tile, or step 0 of the next tile; the very last step
-            // of the last tile re-fetches its own step 0 into the idle stage (harmless, keeps the loop
-            // branch-free: a branch per DMA piece splits the MFMA block and makes hipcc spill)
-            const bool intile = kt + 1 < nk;
-            const bf16_t* ia = intile ? asrc : (has_next ? nasrc : asrc);
-            const bf16_t* iw = intile ? wsrc : (has_next ? nwsrc : wsrc);
-            kstep(st, ia, iw, intile ? kt + 1 : 0);
-            st ^= 1;
-        }
-        STAMP(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's step-0 DMA landed (nothing else pending)
-        first_tile = false;
-        STAMP(1);
-
-        // ---------------- epilogue: transpose through LDS, full-row 16-byte stores ----------------
-        // The MFMA C layout gives a lane 4 consecutive elements of ONE row per fragment, i.e. 16 rows x
-        // 32..64-byte pieces per store instruction -- store-issue-bound (measured: 1186 TF/s without
-        // stores, 510-830 with).  Each wave instead round-trips its 128x64 tile through its 8-KiB slice
-        // of the LDS stage that was just consumed (the other stage already holds the next tile's first
-        // k-step), 16 rows at a time, and stores whole 128/256-byte rows with dwordx4.
-        __syncthreads();  // every wave is done reading the consumed stage
-        STAMP(2);
-        char* scr = reinterpret_cast<char*>(&lds[st ^ 1][0][0]) + wave * 8192;
-#include "gemm256_epilogue.inc"
-        STAMP(3);
-        ++dbg_tile;
-        if (!has_next) break;
-        tile = ntile; m0 = nm0; n0 = nn0; asrc = nasrc; wsrc = nwsrc;
-    }
-}
-
-template <int EPI, typename OutT, bool SWAP>
-void launch256(const GemmArgs& a, hipStream_t s) {
-    const int MT = a.M / 256, NT = a.N / 256;
-    const int AT = MT >= NT ? MT : NT, BT = MT >= NT ? NT : MT;
-    const int tiles_total = ((AT + 7) / 8 + 3) / 4 * 4 * 8 * BT;
-    static const int ncu = [] {
-        int dev = 0, n = 256;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n / 8 * 8;
-    }();
-    const int grid = tiles_total < ncu ? tiles_total : ncu;
-    GemmArgs b = a;
-    static const int skew_env = getenv("SGPT_SKEW") ? atoi(getenv("SGPT_SKEW")) : -1;
-    if (skew_env >= 0) b.skew = skew_env;
-    if (tiles_total < 2 * grid) b.skew = 0;   // a single tile per workgroup: nothing to interleave with
-    hipLaunchKernelGGL((gemm256_kernel<EPI, OutT, SWAP>), dim3(grid), dim3(512), 0, s, b);
+    range.finish(p.range_flag);
 }
 
 
@@ -467,7 +279,7 @@ void launch256(const GemmArgs& a, hipStream_t s) {
 // deep(s+1) have landed while deep(s+2) stays in flight.  The barrier sits in front of the step's last row pair and
 // the next step's first fragments are read behind it (see the loop): 2 615 instead of 2 700 cycles per k-step.  Epilogue scratch: after a tile's last step one deep and one
 // shallow slot are free (32 KiB each): waves 0-3 transpose through the first, waves 4-7 through the second.
-template <int EPI, typename OutT, bool SWAP, bool DEEP_A>
+template <typename T, int EPI, typename OutT, bool SWAP, bool DEEP_A>
 __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     if (p.pred != nullptr && *p.pred == 0) return;
     typedef __attribute__((address_space(3))) char* lds_cptr_t;
@@ -511,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :
                      : "v"(lane_off), "s"(base_uniform), "s"(dst_byte)
-                     : "memory", "m0");
+                     : "memory");
     };
     // slot byte offsets: deep slot sd in [0,3), shallow slot ss in [0,2)
     auto deep_off = [&](int sd) { return (unsigned)(sd * SLOT * 16); };
@@ -541,6 +353,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     const unsigned dloff = DEEP_A ? a_loff : w_loff, sloff = DEEP_A ? w_loff : a_loff;
     int sd = 0, ss = 0;      // ring slots of the k-step about to be computed
     int dbg_tile = 0;
+    typename OutRange<OutT>::type range;
 #define STAMP(k)                                                                                   \
     if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 8) p.dbg[dbg_tile * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
 
@@ -615,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
                 for (int h = 0; h < 2; ++h) {
                     const int i = 2 * pr + h;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mma<bf16_t, SWAP>(acc[i][j], af[q & 1][h], wf[ks][j]);
+                    for (int j = 0; j < 4; ++j) mma<T, SWAP>(acc[i][j], af[q & 1][h], wf[ks][j]);
                     if (ks == 0) {   // one 1-KiB piece behind every 4 MFMAs: shallow x4 first, then deep x4
                         if (i < 4) piece(sp, sld, sloff, skt, s_dst, i);
                         else piece(dp, dld, dloff, dkt, d_dst, i - 4);
@@ -641,10 +454,11 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         tile = ntile; m0 = nm0; n0 = nn0; asrc = nasrc; wsrc = nwsrc;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead DMA before the LDS is released
+    range.finish(p.range_flag);
 #undef STAMP
 }
 
-template <int EPI, typename OutT, bool SWAP>
+template <typename T, int EPI, typename OutT, bool SWAP>
 void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
     const int MT = a.M / 256, NT = a.N / 256;
     const int AT = MT >= NT ? MT : NT, BT = MT >= NT ? NT : MT;
@@ -662,8 +476,8 @@ void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
     const int gm = b.gm > 0 ? b.gm : 4;
     const int tiles_pad = ((AT + 7) / 8 + gm - 1) / gm * gm * 8 * BT;
     const int grid = tiles_pad < ncu ? tiles_pad : ncu;
-    if (deep_a) hipLaunchKernelGGL((gemm256d_kernel<EPI, OutT, SWAP, true>), dim3(grid), dim3(512), 0, s, b);
-    else hipLaunchKernelGGL((gemm256d_kernel<EPI, OutT, SWAP, false>), dim3(grid), dim3(512), 0, s, b);
+    if (deep_a) hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, true>), dim3(grid), dim3(512), 0, s, b);
+    else hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, false>), dim3(grid), dim3(512), 0, s, b);
 }
 
 
@@ -682,55 +496,46 @@ void launch(const GemmArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 4>), dim3(grid), dim3(256), 0, s, a);
 }
 
-}  // namespace
-
-void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
-    const bool bf = dtype == 1, obf = out_dtype == 1;
-    static const bool use256 = getenv("SGPT_GEMM128") == nullptr;
+// 16-bit operand format H (bf16_t | f16_t): the 256x256 LDS-DMA kernel where the shape allows, else the register-staged one
+template <typename H>
+void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
+    const bool o16 = dt_is16(out_dtype);
     // Small problems (short query batches, USEB's 21-32 sentence calls): fewer than half a wave of 256x256 tiles
     // leaves most of the 256 CUs idle; the register-staged kernel's 128x128 / 64x64 tiles fill the chip instead.
     // Bit-identical results (see gemm_kernel), so the embeddings stay batch-invariant.  SGPT_NO_SMALL_TILE=1: A/B.
     static const bool small_tiles = getenv("SGPT_NO_SMALL_TILE") == nullptr;
-    const bool few = small_tiles && epi != EPI_SCORE && epi != EPI_SCORE_FILTER && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
-    static const bool use_deep = getenv("SGPT_GEMM_NODEEP") == nullptr;   // asymmetric-ring kernel (default); env: A/B
-    if (bf && use_deep && !few && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128 &&
-        (a.m_valid == a.M || epi == EPI_SCORE || epi == EPI_SCORE_FILTER)) {
+    const bool scorer = epi == EPI_SCORE || epi == EPI_SCORE_FILTER;
+    const bool few = small_tiles && !scorer && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
+    static const bool use256 = getenv("SGPT_GEMM128") == nullptr;
+    const bool shape256 = a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128;
+    if (epi == EPI_SCORE_FILTER && !shape256) abort();   // caller guarantees padded queries, N % 256 == 0, d % 64 == 0, d >= 128
+    if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
-        if (epi == EPI_SCORE) return launch256d<EPI_SCORE, float, true>(a, s, deep_a);
-        if (epi == EPI_SCORE_FILTER) return launch256d<EPI_SCORE_FILTER, float, true>(a, s, deep_a);
-        if (epi == EPI_STORE && obf) return launch256d<EPI_STORE, bf16_t, true>(a, s, deep_a);
-        if (epi == EPI_VT) return launch256d<EPI_VT, bf16_t, false>(a, s, deep_a);
-        if (epi == EPI_BIAS_GELU) return launch256d<EPI_BIAS_GELU, bf16_t, true>(a, s, deep_a);
-        if (epi == EPI_BIAS_RESID) return launch256d<EPI_BIAS_RESID, float, true>(a, s, deep_a);
-        if (epi == EPI_NONE) return launch256d<EPI_NONE, bf16_t, true>(a, s, deep_a);
+        if (epi == EPI_SCORE) return launch256d<H, EPI_SCORE, float, true>(a, s, deep_a);
+        if (epi == EPI_SCORE_FILTER) return launch256d<H, EPI_SCORE_FILTER, float, true>(a, s, deep_a);
+        if (epi == EPI_STORE && o16) return launch256d<H, EPI_STORE, H, true>(a, s, deep_a);
+        if (epi == EPI_VT) return launch256d<H, EPI_VT, H, false>(a, s, deep_a);
+        if (epi == EPI_BIAS_GELU) return launch256d<H, EPI_BIAS_GELU, H, true>(a, s, deep_a);
+        if (epi == EPI_BIAS_RESID) return launch256d<H, EPI_BIAS_RESID, float, true>(a, s, deep_a);
+        if (epi == EPI_NONE) return launch256d<H, EPI_NONE, H, true>(a, s, deep_a);
     }
-    if (epi == EPI_SCORE_FILTER) {   // caller guarantees bf16, M % 256 == 0 (padded queries), N % 256 == 0, K % 64 == 0
-        if (!(bf && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0)) abort();
-        static const bool deep_f = getenv("SGPT_GEMM_NODEEP") == nullptr;
-        if (deep_f && a.K >= 128) return launch256d<EPI_SCORE_FILTER, float, true>(a, s, a.M >= a.N);
-        return launch256<EPI_SCORE_FILTER, float, true>(a, s);
-    }
-    if (bf && use256 && epi == EPI_SCORE && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0)
-        return launch256<EPI_SCORE, float, true>(a, s);   // scorer: query rows padded to 256 by the caller (m_valid < M)
-    if (bf && use256 && !few && a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.m_valid == a.M) {
-        if (epi == EPI_STORE && obf) return launch256<EPI_STORE, bf16_t, true>(a, s);
-        if (epi == EPI_VT) return launch256<EPI_VT, bf16_t, false>(a, s);
-        if (epi == EPI_BIAS_GELU) return launch256<EPI_BIAS_GELU, bf16_t, true>(a, s);
-        if (epi == EPI_BIAS_RESID) return launch256<EPI_BIAS_RESID, float, true>(a, s);
-        if (epi == EPI_NONE) return launch256<EPI_NONE, bf16_t, true>(a, s);
-    }
-    if (bf) {
-        if (epi == EPI_STORE && obf) return launch<bf16_t, EPI_STORE, bf16_t, true>(a, s);
-        if (epi == EPI_STORE && !obf) return launch<bf16_t, EPI_STORE, float, true>(a, s);
-        if (epi == EPI_VT) return launch<bf16_t, EPI_VT, bf16_t, false>(a, s);
-        if (epi == EPI_BIAS_GELU) return launch<bf16_t, EPI_BIAS_GELU, bf16_t, true>(a, s);
-        if (epi == EPI_BIAS_RESID) return launch<bf16_t, EPI_BIAS_RESID, float, true>(a, s);
-        if (epi == EPI_SCORE) return launch<bf16_t, EPI_SCORE, float, true>(a, s);
-    } else {
-        if (epi == EPI_STORE) return launch<float, EPI_STORE, float, true>(a, s);
-        if (epi == EPI_BIAS_GELU) return launch<float, EPI_BIAS_GELU, float, true>(a, s);
-        if (epi == EPI_BIAS_RESID) return launch<float, EPI_BIAS_RESID, float, true>(a, s);
-        if (epi == EPI_SCORE) return launch<float, EPI_SCORE, float, true>(a, s);
-    }
+    if (epi == EPI_STORE && o16) return launch<H, EPI_STORE, H, true>(a, s);
+    if (epi == EPI_STORE && !o16) return launch<H, EPI_STORE, float, true>(a, s);
+    if (epi == EPI_VT) return launch<H, EPI_VT, H, false>(a, s);
+    if (epi == EPI_BIAS_GELU) return launch<H, EPI_BIAS_GELU, H, true>(a, s);
+    if (epi == EPI_BIAS_RESID) return launch<H, EPI_BIAS_RESID, float, true>(a, s);
+    if (epi == EPI_SCORE) return launch<H, EPI_SCORE, float, true>(a, s);
+    abort();
+}
+
+}  // namespace
+
+void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
+    if (dtype == DT_BF16) return launch_gemm16<bf16_t>(epi, out_dtype, a, s);
+    if (dtype == DT_F16) return launch_gemm16<f16_t>(epi, out_dtype, a, s);
+    if (epi == EPI_STORE) return launch<float, EPI_STORE, float, true>(a, s);
+    if (epi == EPI_BIAS_GELU) return launch<float, EPI_BIAS_GELU, float, true>(a, s);
+    if (epi == EPI_BIAS_RESID) return launch<float, EPI_BIAS_RESID, float, true>(a, s);
+    if (epi == EPI_SCORE) return launch<float, EPI_SCORE, float, true>(a, s);
     abort();
 }

@@ -5,6 +5,7 @@ Replaces the device leg of CustomEmbedder.embed / embed_batcher
 (biencoder/beir/beir_dense_retriever.py:158-314) and of SentenceTransformer._encode
 (sentence_transformers/SentenceTransformer.py:217-255)."""
 import ctypes as C
+import itertools
 import json
 import os
 from dataclasses import dataclass, field
@@ -14,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F32, SGPT_FP8W
+from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F16, SGPT_F32, SGPT_FP8W, SgptRangeError
 from .runtime import Context, get_context, _p, _stream_ptr
 
 ALIGN = 16         # sequence starts on the packed token axis (MFMA 16-row tiles; V^T 8-byte loads)
@@ -85,39 +86,113 @@ class PackedBatch:
     max_pos: int = 0  # largest position id (pad_left + len - 1): bounds the learntmean weight table
 
 
-def pack_host(seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None):
-    """Token lists -> numpy arrays of the packed layout (pure index arithmetic, host side)."""
+def _flatten(seqs, total: int) -> np.ndarray:
+    """Ragged token lists -> one int32 vector, at C speed: a [B,S] ndarray is a reshape, lists of ndarrays a
+    concatenate, lists of lists one itertools.chain pass (no per-token Python bytecode)."""
+    if isinstance(seqs, np.ndarray) and seqs.ndim == 2:
+        return np.ascontiguousarray(seqs, dtype=np.int32).reshape(-1)
+    if len(seqs) and isinstance(seqs[0], np.ndarray):
+        return np.concatenate(seqs).astype(np.int32, copy=False)
+    return np.fromiter(itertools.chain.from_iterable(seqs), dtype=np.int32, count=total)
+
+
+def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None) -> dict:
+    """Sizes and offsets of the packed layout (no token data yet)."""
     B = len(seqs)
-    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=B)
+    if isinstance(seqs, np.ndarray) and seqs.ndim == 2:
+        lens = np.full(B, seqs.shape[1], dtype=np.int64)
+    else:
+        lens = np.fromiter(map(len, seqs), dtype=np.int64, count=B)
     if B == 0 or (lens <= 0).any():
         raise ValueError("Empty items should be cleaned prior to running")  # beir_dense_retriever.py:180-181
     alloc = (lens + ALIGN - 1) // ALIGN * ALIGN
     off = np.zeros(B + 1, dtype=np.int64)
     np.cumsum(alloc, out=off[1:])
-    T_used = int(off[-1])
-    T_pad = (T_used + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE
-    ids = np.zeros(T_pad, dtype=np.int32)
-    pos = np.zeros(T_pad, dtype=np.int32)
+    T_pad = (int(off[-1]) + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE
     pl = np.zeros(B, dtype=np.int32) if pad_left is None else np.asarray(pad_left, dtype=np.int32)
-    flat = np.fromiter((t for s in seqs for t in s), dtype=np.int32, count=int(lens.sum()))
-    # destination row of every real token: seq_off[b] + t
-    rep_off = np.repeat(off[:-1], lens)
-    within = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
-    rows = rep_off + within
-    ids[rows] = flat
-    pos[rows] = (within + np.repeat(pl.astype(np.int64), lens)).astype(np.int32)
-    return dict(ids=ids, pos=pos, seq_off=off.astype(np.int32), seq_len=lens.astype(np.int32), pad_left=pl,
-                B=B, T_pad=T_pad, max_alloc=int(alloc.max()), n_tokens=int(lens.sum()),
-                max_pos=int((lens + pl.astype(np.int64)).max()) - 1)
+    return dict(B=B, lens=lens, alloc=alloc, off=off, T_pad=T_pad, pl=pl, n_tokens=int(lens.sum()),
+                max_alloc=int(alloc.max()), max_pos=int((lens + pl.astype(np.int64)).max()) - 1)
+
+
+def arena_ints(lay: dict) -> int:
+    """int32 words of the one-buffer host/device image: [ids T_pad | pos T_pad | seq_off B+1 | seq_len B | pad_left B]."""
+    return 2 * lay["T_pad"] + 3 * lay["B"] + 1
+
+
+def fill_arena(seqs, lay: dict, arena: np.ndarray):
+    """Writes the packed layout of include/sgpt_hip.h::sgpt_encode into `arena` (int32, >= arena_ints words; pure index
+    arithmetic, vectorised).  Returns (largest, smallest) token id: the caller validates them against the vocabulary."""
+    B, T_pad, lens, off, pl = lay["B"], lay["T_pad"], lay["lens"], lay["off"], lay["pl"]
+    n = lay["n_tokens"]
+    ids, pos = arena[:T_pad], arena[T_pad: 2 * T_pad]
+    ids[:] = 0
+    pos[:] = 0
+    flat = _flatten(seqs, n)
+    if flat.shape[0] != n:
+        raise ValueError("ragged token input does not match its lengths")
+    if (lens == lens[0]).all() and lens[0] % ALIGN == 0:      # rectangular, aligned: rows are already in place
+        ids[:n] = flat
+        pos[:n] = (np.arange(n, dtype=np.int64) % lens[0] + np.repeat(pl.astype(np.int64), lens)).astype(np.int32)
+    else:
+        within = np.arange(n, dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+        rows = np.repeat(off[:-1], lens) + within            # destination row of every real token: seq_off[b] + t
+        ids[rows] = flat
+        pos[rows] = (within + np.repeat(pl.astype(np.int64), lens)).astype(np.int32)
+    o = 2 * T_pad
+    arena[o: o + B + 1] = off
+    arena[o + B + 1: o + 2 * B + 1] = lens
+    arena[o + 2 * B + 1: o + 3 * B + 1] = pl
+    return int(flat.max()), int(flat.min())
+
+
+def pack_host(seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None):
+    """Token lists -> numpy arrays of the packed layout (host side; the dict form used by tests and EncodeGraph)."""
+    lay = pack_layout(seqs, pad_left)
+    arena = np.empty(arena_ints(lay), dtype=np.int32)
+    fill_arena(seqs, lay, arena)
+    B, T_pad = lay["B"], lay["T_pad"]
+    o = 2 * T_pad
+    return dict(ids=arena[:T_pad], pos=arena[T_pad:o], seq_off=arena[o: o + B + 1], seq_len=arena[o + B + 1: o + 2 * B + 1],
+                pad_left=arena[o + 2 * B + 1: o + 3 * B + 1], B=B, T_pad=T_pad, max_alloc=lay["max_alloc"],
+                n_tokens=lay["n_tokens"], max_pos=lay["max_pos"], arena=arena)
+
+
+class _Staging:
+    """Two pinned int32 host arenas used alternately for the H2D copy of packed batches: the copy of batch i+1 is
+    filled while the copy of batch i is still in flight (an event per arena says when it may be overwritten)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = [None, None]
+        self.events = [None, None]
+        self.turn = 0
+
+    def acquire(self, n_int: int):
+        i = self.turn
+        self.turn ^= 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()                    # the previous copy out of this arena has completed
+        if self.bufs[i] is None or self.bufs[i].numel() < n_int:
+            cap = max(n_int + n_int // 4, 1 << 16)
+            self.bufs[i] = torch.empty(cap, dtype=torch.int32).pin_memory()
+        return i, self.bufs[i]
+
+    def release(self, i: int):
+        ev = self.events[i] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.events[i] = ev
 
 
 class SGPTModel:
     """GPT-Neo weights resident on one GPU behind an `sgpt_model*` handle."""
 
     def __init__(self, cfg: SGPTConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device=None,
-                 dtype: str = "bf16", ctx: Optional[Context] = None, max_tokens_per_call: int = 32768):
-        if dtype not in ("bf16", "fp32", "fp8"):
-            raise ValueError("dtype must be 'bf16' (MFMA bf16 operands), 'fp32' (exact fp32 MFMA) or "
+                 dtype: str = "f16", ctx: Optional[Context] = None, max_tokens_per_call: int = 32768):
+        if dtype in ("fp16", "float16", "half"):
+            dtype = "f16"
+        if dtype not in ("f16", "bf16", "fp32", "fp8"):
+            raise ValueError("dtype must be 'f16' (IEEE-half MFMA operands, range-guarded: the 1e-3-parity mode), "
+                             "'bf16' (bf16 MFMA operands), 'fp32' (exact fp32 MFMA) or "
                              "'fp8' (e4m3fn weight storage, bf16 arithmetic)")
         self.cfg = cfg
         self.ctx = ctx or get_context(device)
@@ -134,7 +209,7 @@ class SGPTModel:
                          vocab=cfg.vocab_size, max_pos=cfg.max_position_embeddings, window=cfg.window_size,
                          ln_eps=cfg.layer_norm_epsilon,
                          attn_scale=float(1.0 / np.sqrt(np.float32(dh))) if (gptj or bloom) else 1.0,   # HF:gptj:148, HF:bloom:186 / HF:gpt_neo:110
-                         compute_dtype={"bf16": SGPT_BF16, "fp32": SGPT_F32, "fp8": SGPT_FP8W}[dtype],
+                         compute_dtype={"f16": SGPT_F16, "bf16": SGPT_BF16, "fp32": SGPT_F32, "fp8": SGPT_FP8W}[dtype],
                          layer_is_local=C.cast(local, C.POINTER(C.c_uint8)), rotary_dim=cfg.rotary_dim if gptj else 0)
         if gptj:
             weights = dict(weights)
@@ -163,6 +238,7 @@ class SGPTModel:
                    "sgpt_model_load")
         self.handle = h
         del keep  # the library now owns packed copies
+        self._staging = _Staging(self.device)
         self.position_weights = None
         if "position_weights" in weights:
             self.set_position_weights(weights["position_weights"])
@@ -192,26 +268,30 @@ class SGPTModel:
             root = os.path.join(root, "0_Transformer")
         with open(os.path.join(root, "config.json")) as f:
             cfg = SGPTConfig.from_hf_dict(json.load(f))
-        st = os.path.join(root, "model.safetensors")
-        if os.path.exists(st):
-            from safetensors.torch import load_file
-            sd = load_file(st)
-        else:
-            sd = torch.load(os.path.join(root, "pytorch_model.bin"), map_location="cpu")
-        model = cls(cfg, sd, **kw)
+        model = cls(cfg, load_state_dict(root), **kw)
         wmp = os.path.join(path, "1_WeightedMeanPooling", "pytorch_model.bin")
         if os.path.exists(wmp):
-            model.set_position_weights(torch.load(wmp, map_location="cpu")["position_weights"])
+            model.set_position_weights(torch.load(wmp, map_location="cpu", weights_only=True)["position_weights"])
         return model
 
     # ---- packing ----
     def pack(self, seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None) -> PackedBatch:
-        h = pack_host(seqs, pad_left)
-        if h["max_alloc"] > 2048 or int(h["seq_len"].max()) + int(h["pad_left"].max()) > self.cfg.max_position_embeddings:
+        """Token lists -> device-resident packed batch: ONE pinned, non-blocking H2D copy of the whole layout."""
+        lay = pack_layout(seqs, pad_left)
+        if lay["max_alloc"] > 2048 or lay["max_pos"] >= self.cfg.max_position_embeddings:
             raise ValueError("sequence longer than max_position_embeddings")
-        dev = lambda a: torch.from_numpy(a).to(self.device, non_blocking=False)  # noqa: E731
-        return PackedBatch(dev(h["ids"]), dev(h["pos"]), dev(h["seq_off"]), dev(h["seq_len"]), dev(h["pad_left"]),
-                           h["B"], h["T_pad"], h["max_alloc"], h["n_tokens"], h["max_pos"])
+        n_int = arena_ints(lay)
+        slot, host = self._staging.acquire(n_int)
+        hi, lo = fill_arena(seqs, lay, host.numpy())
+        if lo < 0 or hi >= self.cfg.vocab_size:
+            raise ValueError(f"token id out of range [0, {self.cfg.vocab_size})")
+        dev = torch.empty(n_int, dtype=torch.int32, device=self.device)
+        dev.copy_(host[:n_int], non_blocking=True)
+        self._staging.release(slot)
+        B, T = lay["B"], lay["T_pad"]
+        o = 2 * T
+        return PackedBatch(dev[:T], dev[T:o], dev[o: o + B + 1], dev[o + B + 1: o + 2 * B + 1],
+                           dev[o + 2 * B + 1: o + 3 * B + 1], B, T, lay["max_alloc"], lay["n_tokens"], lay["max_pos"])
 
     # ---- one C call: forward + pool ----
     def encode_packed(self, pb: PackedBatch, mode: str = "weightedmean", normalize: bool = False,
@@ -291,46 +371,70 @@ class SGPTModel:
         out.append(order[start:])
         return out
 
+    def _check_range(self):
+        """dtype='f16': fail loudly if an activation left the half range during the calls just issued."""
+        if self.dtype == "f16" and self.ctx.range_check(reset=True):
+            raise SgptRangeError("dtype='f16': an activation reached |v| >= 32768 (IEEE-half range); "
+                                 "this checkpoint needs dtype='bf16'")
+
+    def _batched(self, seqs, pad_left, run) -> torch.Tensor:
+        """Length-sorted token-budget batches -> `run(pb, out_rows)` per batch -> rows back in input order."""
+        n = len(seqs)
+        d = self.cfg.hidden_size
+        if n == 0:
+            return torch.empty((0, d), dtype=torch.float32, device=self.device)
+        lens = np.fromiter(map(len, seqs), dtype=np.int64, count=n)
+        if (lens <= 0).any():
+            raise ValueError("Empty items should be cleaned prior to running")
+        plan = self.plan_batches(lens)
+        if len(plan) == 1 and np.array_equal(plan[0], np.arange(n)):     # already in order: no un-sort pass
+            sel = plan[0]
+            res = torch.empty((n, d), dtype=torch.float32, device=self.device)
+            run(self.pack(seqs, pad_left), res)
+            self._check_range()
+            return res
+        sorted_rows = torch.empty((n, d), dtype=torch.float32, device=self.device)
+        o = 0
+        for sel in plan:
+            pb = self.pack([seqs[i] for i in sel], None if pad_left is None else [pad_left[i] for i in sel])
+            run(pb, sorted_rows[o: o + pb.B])
+            o += pb.B
+        order = torch.from_numpy(np.concatenate(plan)).pin_memory().to(self.device, non_blocking=True)
+        res = torch.empty_like(sorted_rows)
+        res[order] = sorted_rows                                   # un-sort (SentenceTransformer.py:205), one pass
+        self._check_range()
+        return res
+
     def encode_ids_all_layers(self, seqs: Sequence[Sequence[int]], mode: str = "mean",
                               pad_left: Optional[Sequence[int]] = None) -> torch.Tensor:
         """n token lists -> fp32[n,d]: the per-layer pooled vectors of all L+1 hidden states, averaged
         (`meanmean` with mode='mean', `lasttokenmean` with mode='lasttoken'), one forward per batch."""
-        n = len(seqs)
-        if n == 0:
-            return torch.empty((0, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
-        lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
-        if (lens <= 0).any():
-            raise ValueError("Empty items should be cleaned prior to running")
-        res = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
-        for sel in self.plan_batches(lens):
-            pb = self.pack([seqs[i] for i in sel], None if pad_left is None else [pad_left[i] for i in sel])
-            res[torch.from_numpy(sel).to(self.device)] = self.encode_packed_layers(pb, mode)
-        return res
+        return self._batched(seqs, pad_left, lambda pb, out: out.copy_(self.encode_packed_layers(pb, mode)))
 
     def encode_ids(self, seqs: Sequence[Sequence[int]], mode: str = "weightedmean", normalize: bool = False,
                    layer_idx: int = -1, pad_left: Optional[Sequence[int]] = None,
                    out_dtype=torch.float32) -> torch.Tensor:
         """n token lists -> fp32[n,d] embeddings on the GPU, row-aligned with the input order."""
-        n = len(seqs)
-        if n == 0:
-            return torch.empty((0, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
-        lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
-        if (lens <= 0).any():
-            raise ValueError("Empty items should be cleaned prior to running")
-        res = torch.empty((n, self.cfg.hidden_size), dtype=torch.float32, device=self.device)
-        for sel in self.plan_batches(lens):
-            pb = self.pack([seqs[i] for i in sel], None if pad_left is None else [pad_left[i] for i in sel])
-            emb = self.encode_packed(pb, mode, normalize, layer_idx)
-            res[torch.from_numpy(sel).to(self.device)] = emb          # un-sort (SentenceTransformer.py:205)
-        return res
+        return self._batched(seqs, pad_left, lambda pb, out: self.encode_packed(pb, mode, normalize, layer_idx, out=out))
 
     def token_embeddings(self, seqs: Sequence[Sequence[int]], layer_idx: int = -1,
                          pad_left: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
-        """output_value='token_embeddings' (SentenceTransformer.py:233-241): per-sentence [len,d]."""
-        pb = self.pack(seqs, pad_left)
-        _, hid = self.encode_packed(pb, layer_idx=layer_idx, return_hidden=True)
-        off = pb.seq_off.cpu().tolist()
-        return [hid[off[i]: off[i] + len(s)] for i, s in enumerate(seqs)]
+        """output_value='token_embeddings' (SentenceTransformer.py:233-241): per-sentence [len,d].  Batched by the
+        same token budget as encode_ids, so the fp32 [T_pad, d] hidden buffer stays bounded."""
+        n = len(seqs)
+        lens = np.fromiter(map(len, seqs), dtype=np.int64, count=n)
+        if n == 0 or (lens <= 0).any():
+            raise ValueError("Empty items should be cleaned prior to running")
+        out: List[Optional[torch.Tensor]] = [None] * n
+        for sel in self.plan_batches(lens):
+            sub = [seqs[i] for i in sel]
+            pb = self.pack(sub, None if pad_left is None else [pad_left[i] for i in sel])
+            _, hid = self.encode_packed(pb, layer_idx=layer_idx, return_hidden=True)
+            off = pb.seq_off.cpu().tolist()
+            for j, i in enumerate(sel.tolist()):
+                out[i] = hid[off[j]: off[j] + len(sub[j])].clone()
+        self._check_range()
+        return out
 
 
 class EncodeGraph:
@@ -346,11 +450,19 @@ class EncodeGraph:
         self.model, self.mode, self.normalize, self.layer_idx = model, mode, normalize, layer_idx
         self.pb = model.pack(seqs, pad_left)
         self.out = torch.empty((self.pb.B, model.cfg.hidden_size), dtype=torch.float32, device=model.device)
-        model.encode_packed(self.pb, mode, normalize, layer_idx, out=self.out)       # warm-up outside capture
-        torch.cuda.synchronize(model.device)
+        self._capture()
+
+    def _capture(self):
+        """(Re-)capture.  The captured kernels hold raw pointers into the context's grow-only workspace and the model's
+        learnt-pooling table; `generation` moves whenever the library re-allocates one of them (a larger eager call on
+        the same context, set_position_weights), and replay() re-captures instead of launching into freed memory."""
+        m = self.model
+        m.encode_packed(self.pb, self.mode, self.normalize, self.layer_idx, out=self.out)   # sizes the workspace: hipMalloc is not capturable
+        torch.cuda.synchronize(m.device)
+        self.generation = m.ctx.generation()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            model.encode_packed(self.pb, mode, normalize, layer_idx, out=self.out)
+            m.encode_packed(self.pb, self.mode, self.normalize, self.layer_idx, out=self.out)
 
     @property
     def bucket(self):
@@ -368,8 +480,34 @@ class EncodeGraph:
                 getattr(self.pb, name).copy_(torch.from_numpy(h[name]), non_blocking=False)
             self.pb.max_pos = h["max_pos"]
             self.model._check_learnt(self.mode, self.pb)
+        if self.model.ctx.generation() != self.generation:
+            self._capture()                      # the workspace / pooling table moved since capture: stale pointers
         self.graph.replay()
         return self.out
+
+
+def load_state_dict(root: str) -> Dict[str, torch.Tensor]:
+    """HF checkpoint folder -> state dict: model.safetensors / pytorch_model.bin, or the sharded forms large checkpoints
+    (sgpt-bloom-7b1, SGPT-5.8B) are saved in (`*.index.json` + `model-0000x-of-0000N.safetensors` /
+    `pytorch_model-0000x-of-0000N.bin`).  Pickle files are read with weights_only=True (no code execution)."""
+    def read(path):
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            return load_file(path)
+        return torch.load(path, map_location="cpu", weights_only=True)
+    for single in ("model.safetensors", "pytorch_model.bin"):
+        if os.path.exists(os.path.join(root, single)):
+            return read(os.path.join(root, single))
+    for index in ("model.safetensors.index.json", "pytorch_model.bin.index.json"):
+        ip = os.path.join(root, index)
+        if os.path.exists(ip):
+            with open(ip) as f:
+                shards = sorted(set(json.load(f)["weight_map"].values()))
+            sd: Dict[str, torch.Tensor] = {}
+            for sh in shards:
+                sd.update(read(os.path.join(root, sh)))
+            return sd
+    raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin (single or sharded) under {root}")
 
 
 def alibi_slopes(n_head: int) -> np.ndarray:

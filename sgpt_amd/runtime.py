@@ -8,7 +8,10 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SGPT_BF16, SGPT_F32, POOL_MODES
+from ._lib import SGPT_BF16, SGPT_F16, SGPT_F32, POOL_MODES
+
+# torch dtype <-> element-type code of include/sgpt_hip.h
+DT_CODE = {torch.float32: SGPT_F32, torch.bfloat16: SGPT_BF16, torch.float16: SGPT_F16}
 
 
 def _stream_ptr(device) -> C.c_void_p:
@@ -71,13 +74,13 @@ class Context:
         if mode not in POOL_MODES:
             raise ValueError(f"unknown pooling mode {mode}")
         hidden = hidden.to(self.device)
-        if hidden.dtype not in (torch.float32, torch.bfloat16):
+        if hidden.dtype not in DT_CODE:
             hidden = hidden.float()
         hidden = hidden.contiguous()
         B, S, d = hidden.shape
         m = mask.to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty((B, d), dtype=torch.float32, device=self.device)
-        dt = SGPT_BF16 if hidden.dtype == torch.bfloat16 else SGPT_F32
+        dt = DT_CODE[hidden.dtype]
         if mode == "learntmean":
             if position_weights is None or position_weights.numel() < S:
                 raise ValueError("learntmean needs position_weights covering the sequence length")
@@ -94,17 +97,35 @@ class Context:
         x = self._dev_f32(x)
         n, d = x.shape
         out = torch.empty((n, d), dtype=out_dtype, device=self.device)
-        self._chk(self.lib.sgpt_l2_normalize(self.handle, _p(x), n, d, _p(out),
-                                             SGPT_BF16 if out_dtype == torch.bfloat16 else SGPT_F32,
+        self._chk(self.lib.sgpt_l2_normalize(self.handle, _p(x), n, d, _p(out), DT_CODE[out_dtype],
                                              _stream_ptr(self.device)), "sgpt_l2_normalize")
         return out
 
-    def to_bf16(self, x: torch.Tensor) -> torch.Tensor:
+    def to_16(self, x: torch.Tensor, dtype=torch.float16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """fp32 -> bf16 / f16 (RNE) on the device: the scorer's 16-bit operand format."""
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
-        out = torch.empty(x.shape, dtype=torch.bfloat16, device=self.device)
-        self._chk(self.lib.sgpt_f32_to_bf16(self.handle, _p(x), x.numel(), _p(out), _stream_ptr(self.device)),
-                  "sgpt_f32_to_bf16")
+        if out is None:
+            out = torch.empty(x.shape, dtype=dtype, device=self.device)
+        self._chk(self.lib.sgpt_f32_to_16(self.handle, _p(x), x.numel(), _p(out), DT_CODE[dtype],
+                                          _stream_ptr(self.device)), "sgpt_f32_to_16")
         return out
+
+    def to_bf16(self, x: torch.Tensor) -> torch.Tensor:
+        return self.to_16(x, torch.bfloat16)
+
+    def range_check(self, reset: bool = True) -> bool:
+        """dtype='f16' guard: True when an activation left the half range since the last reset (syncs the stream)."""
+        flagged = C.c_int32(0)
+        self._chk(self.lib.sgpt_range_check(self.handle, C.byref(flagged), 1 if reset else 0, _stream_ptr(self.device)),
+                  "sgpt_range_check")
+        return bool(flagged.value)
+
+    def generation(self) -> int:
+        """Changes when a library-owned buffer captured graphs point into was re-allocated (EncodeGraph)."""
+        return int(self.lib.sgpt_ctx_generation(self.handle))
+
+    def reserve(self, encode_bytes: int = 0, score_bytes: int = 0) -> None:
+        self._chk(self.lib.sgpt_ctx_reserve(self.handle, encode_bytes, score_bytes), "sgpt_ctx_reserve")
 
     # ---- fp8 (e4m3fn, power-of-two per-row scales) weight storage: building blocks of dtype="fp8" models ----
     def fp8_quantize_rows(self, w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -122,15 +143,15 @@ class Context:
         rows, cols = codes.shape
         out = torch.empty((rows, cols), dtype=out_dtype, device=self.device)
         self._chk(self.lib.sgpt_fp8_dequantize_rows(self.handle, _p(codes), _p(scale), rows, cols, _p(out),
-                                                    SGPT_BF16 if out_dtype == torch.bfloat16 else SGPT_F32,
+                                                    DT_CODE[out_dtype],
                                                     _stream_ptr(self.device)), "sgpt_fp8_dequantize_rows")
         return out
 
     def _operand(self, x: torch.Tensor, dtype) -> torch.Tensor:
         if x.dtype == dtype and x.device == self.device and x.is_contiguous():
             return x
-        if dtype == torch.bfloat16:
-            return x if (x.dtype == torch.bfloat16 and x.is_contiguous()) else self.to_bf16(x)
+        if dtype in (torch.bfloat16, torch.float16):
+            return self.to_16(x, dtype)
         return x.to(device=self.device, dtype=torch.float32).contiguous()
 
     # ---- a7: dense score matrix (cos_sim / dot_score) ----
@@ -142,7 +163,7 @@ class Context:
             raise ValueError(f"embedding dims differ: {d} vs {d2}")
         ldo = (nb + 3) // 4 * 4
         out = torch.empty((na, ldo), dtype=torch.float32, device=self.device)
-        self._chk(self.lib.sgpt_scores(self.handle, _p(a), _p(b), SGPT_BF16 if dtype == torch.bfloat16 else SGPT_F32,
+        self._chk(self.lib.sgpt_scores(self.handle, _p(a), _p(b), DT_CODE[dtype],
                                        na, nb, d, _p(out), ldo, _stream_ptr(self.device)), "sgpt_scores")
         return out[:, :nb]
 
@@ -152,7 +173,7 @@ class Context:
                    dtype=None) -> Tuple[torch.Tensor, torch.Tensor, int]:
         """-> (values fp32[nq,k], indices int64[nq,k], n_valid); rows sorted by descending score."""
         if dtype is None:
-            dtype = corpus.dtype if corpus.dtype in (torch.float32, torch.bfloat16) else torch.float32
+            dtype = corpus.dtype if corpus.dtype in DT_CODE else torch.float32
         q, corpus = self._operand(q, dtype), self._operand(corpus, dtype)
         nq, d = q.shape
         N, d2 = corpus.shape
@@ -165,8 +186,7 @@ class Context:
         else:
             val, idx, n_run = run
         n_out = C.c_int32(0)
-        self._chk(self.lib.sgpt_score_topk(self.handle, _p(q), _p(corpus),
-                                           SGPT_BF16 if dtype == torch.bfloat16 else SGPT_F32, nq, N, d, k,
+        self._chk(self.lib.sgpt_score_topk(self.handle, _p(q), _p(corpus), DT_CODE[dtype], nq, N, d, k,
                                            idx_base, _p(val), _p(idx), n_run, C.byref(n_out),
                                            _stream_ptr(self.device)), "sgpt_score_topk")
         return val, idx, int(n_out.value)

@@ -46,7 +46,7 @@ class SentenceTransformerSGPT:
         self.pipe = TextPipeline(tokenizer, max_seq_length, specb=specb)
 
     @classmethod
-    def from_pretrained(cls, path: str, tokenizer=None, device=None, dtype: str = "bf16", specb: bool = False,
+    def from_pretrained(cls, path: str, tokenizer=None, device=None, dtype: str = "f16", specb: bool = False,
                         **model_kw) -> "SentenceTransformerSGPT":
         """SentenceTransformer(model_path) for an SGPT folder (SentenceTransformer._load_sbert_model, :903-936):
         modules.json -> Transformer weights, Pooling / WeightedMeanPooling mode, optional Normalize."""
@@ -57,7 +57,7 @@ class SentenceTransformerSGPT:
             raise ValueError("asymmetric (Asym) folders load through sgpt_amd.beir.SentenceBERTAsym")
         model = SGPTModel.from_pretrained(spec.transformer_dirs[""], device=device, dtype=dtype, **model_kw)
         if spec.position_weights_file:
-            model.set_position_weights(torch.load(spec.position_weights_file, map_location="cpu")["position_weights"])
+            model.set_position_weights(torch.load(spec.position_weights_file, map_location="cpu", weights_only=True)["position_weights"])
         tok = tokenizer if tokenizer is not None else load_tokenizer(spec.transformer_dirs[""])
         return cls(model, tok, max_seq_length=spec.max_seq_length or model.cfg.max_position_embeddings,
                    pooling_mode=spec.pooling_mode, specb=specb, normalize=spec.normalize)

@@ -107,4 +107,28 @@ class TextPipeline:
         return tokens
 
     def batch(self, texts: Sequence[str], is_query: bool) -> List[List[int]]:
-        return [self.ids(t, is_query) for t in texts]
+        """All texts of a call at once.  A HF *fast* tokenizer takes the whole list in ONE call (its Rust core
+        tokenises the batch in parallel and returns the ids directly: the id sequence of
+        `convert_tokens_to_ids(tokenize(t))`, beir_dense_retriever.py:172-173); truncation and brackets are then list
+        slices.  Any other tokenizer object (slow HF tokenizers, SyntheticTokenizer) goes through the per-text calls."""
+        if not getattr(self.tok, "is_fast", False) or len(texts) < 2:
+            return [self.ids(t, is_query) for t in texts]
+        if not self.st_path:
+            texts = [t.replace("\n", " ") for t in texts]                        # :169
+        enc = self.tok(list(texts), add_special_tokens=False, padding=False, truncation=False,
+                       return_attention_mask=False, return_token_type_ids=False)["input_ids"]
+        bracket = self.specb or self.speca
+        out = []
+        lim = self.max_token_len
+        for tokens in enc:
+            n = len(tokens)
+            if n > lim:
+                self.docs_truncated += 1
+                self.toks_truncated += n - lim
+                tokens = tokens[:lim]
+            elif n == 0:
+                raise ValueError("Empty items should be cleaned prior to running")  # :180-181
+            if bracket:                                                             # :186-191
+                tokens = (self.bos_q + tokens + self.eos_q) if is_query else (self.bos_d + tokens + self.eos_d)
+            out.append(tokens)
+        return out
