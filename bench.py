@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric on MI355X: encoded sentences/sec (+ queries/sec @ corpus)
-for SGPT-125M, seq_len 128, bf16, cosine top-10, synthetic corpus (BASELINE configs[1]).
+for SGPT-125M, seq_len 128, 16-bit MFMA operands (f16 by default: same MFMA rate as bf16, 3 more mantissa
+bits -- the mode that meets the 1e-3 parity bar; `--dtype bf16` times the bf16 variant), cosine top-10,
+synthetic corpus (BASELINE configs[1]).
 
 One "step" = one pass of the reference's corpus-chunk loop (custommodels/exact_search.py:80-132)
 over a chunk of `--chunk` synthetic documents already resident in HBM as packed token ids:
     encode (GPT-Neo forward + weighted-mean pool + L2 normalise)  ->  bf16 corpus rows
     score nq pre-encoded queries against the chunk, running top-(k+1) merge.
-N > 1 (torchrun, one rank per GPU): every rank owns its own corpus shard (weak scaling: work per
-GPU fixed); queries are encoded sharded and all-gathered once over RCCL; at the end the per-rank
-top-k lists are all-gathered and merged.  No data-path collective inside a step.
+N > 1 (one rank per GPU; `python bench.py --gpus N` re-launches itself under torch.distributed.run when
+it was not started by it): every rank owns its own corpus shard (weak scaling: work per GPU fixed);
+queries are encoded sharded and all-gathered once over RCCL; at the end the per-rank top-k lists are
+all-gathered and merged.  No data-path collective inside a step.  After the timed region the sharded
+search is checked against a single-rank search over the same documents.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -83,8 +89,10 @@ def flops_per_sentence(S, L=12, d=768):
     return L * 24 * S * d * d + 2 * L * d * S * (S + 1)
 
 
-def hf_cpu_baseline(ocfg, ow, sample, port_emb):
-    """HF GPTNeoModel (fp32, eager attention, eval) on the host cores over the same bounded sample."""
+def hf_cpu_baseline(ocfg, ow, sample, repeats=3):
+    """The code the reference itself runs on a CPU: HF GPTNeoModel (fp32, eager attention, eval -- the
+    un-vendored dependency behind beir_dense_retriever.py:204-205) + the raw weighted-mean pooling of :258-270 +
+    F.normalize, on the host cores over a bounded sample; 1 warm-up + `repeats` timed passes, median."""
     from transformers import GPTNeoConfig, GPTNeoModel
     hc = GPTNeoConfig(vocab_size=ocfg.vocab_size, max_position_embeddings=ocfg.max_position_embeddings,
                       hidden_size=ocfg.hidden_size, num_layers=ocfg.num_layers, num_heads=ocfg.num_heads,
@@ -95,10 +103,8 @@ def hf_cpu_baseline(ocfg, ow, sample, port_emb):
     hc._attn_implementation = "eager"
     hf = GPTNeoModel(hc).eval()
     hf.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ow.items()}, strict=False)
-    threads = min(32, os.cpu_count() or 1)     # 256 threads on a 32-sentence batch only oversubscribe (0.9 sentences/s)
+    threads = min(64, os.cpu_count() or 1)     # more threads than that only oversubscribe a 64-sentence batch
     torch.set_num_threads(threads)
-    sample = sample[:32]
-    port_emb = np.asarray(port_emb)[:32]
     ids = torch.tensor(sample, dtype=torch.long)
     mask = torch.ones_like(ids)
 
@@ -109,12 +115,35 @@ def hf_cpu_baseline(ocfg, ow, sample, port_emb):
             e = (h * w).sum(1) / w.sum(1)
             return torch.nn.functional.normalize(e, dim=1)
     run(ids[:8], mask[:8])                                    # warm-up
-    t = time.perf_counter()
-    emb = run(ids, mask)
-    dt = time.perf_counter() - t
-    return {"value": round(len(sample) / dt, 2), "unit": "sentences/s", "cores": threads,
-            "what": "HF GPTNeoModel fp32 eager + raw weighted-mean pooling + normalise, torch CPU",
-            "seconds": round(dt, 2), "max_abs_diff_vs_port": float(np.abs(emb.numpy() - np.asarray(port_emb)).max())}
+    times = []
+    for _ in range(repeats):
+        t = time.perf_counter()
+        emb = run(ids, mask)
+        times.append(time.perf_counter() - t)
+    dt = float(np.median(times))
+    return emb.numpy(), {"value": round(len(sample) / dt, 2), "unit": "sentences/s", "cores": threads, "kind": "reference",
+                         "sample": f"{len(sample)} sentences x {ids.shape[1]} tokens: HF GPTNeoModel fp32 eager + raw weighted-mean "
+                                   f"pooling + normalise (the reference's CPU path), torch CPU, median of {repeats} passes "
+                                   f"({', '.join(f'{x:.1f}' for x in times)} s)"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_distributed(n):
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) of this same command line."""
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} HIP device(s) visible")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -127,15 +156,21 @@ def main():
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
-                    help="fp8 = e4m3fn weight storage (SURVEY 8d cfg5), bf16 arithmetic")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "fp32", "fp8"],
+                    help="16-bit MFMA operand format (f16: range-guarded, meets the 1e-3 parity bar; bf16); fp32 = exact-fp32 "
+                         "MFMA; fp8 = e4m3fn weight storage (SURVEY 8d cfg5), bf16 arithmetic")
     ap.add_argument("--model", default="125m", choices=sorted(MODELS), help="SGPT size (default: the BASELINE metric's 125M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the queries/sec @ 1M-doc scoring leg")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="sentences in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="sentences in the bounded CPU-baseline sample")
+    ap.add_argument("--no-varlen", action="store_true", help="skip the lengths ~U{16..128} leg")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_distributed(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
@@ -155,7 +190,7 @@ def main():
     del weights
     torch.cuda.empty_cache()
     d, S, k1 = cfg.hidden_size, args.seq, args.topk + 1      # the reference keeps top_k+1 (exact_search.py:104)
-    score_dt = torch.float32 if args.dtype == "fp32" else torch.bfloat16
+    score_dt = {"fp32": torch.float32, "f16": torch.float16}.get(args.dtype, torch.bfloat16)
 
     # ---- synthetic inputs, resident in HBM before the clock starts (ids ~ U{0..50255}) ----
     rng = np.random.default_rng(1000 + rank)
@@ -169,7 +204,7 @@ def main():
             nb = min(args.call, left)
             left -= nb
             ids = rng.integers(0, min(50256, cfg.vocab_size), size=(nb, S), dtype=np.int64)
-            row.append(model.pack([r for r in ids.tolist()]))
+            row.append(model.pack(ids))
         packed.append(row)
     # queries: lengths U{4..32}; encoded sharded by rank, then ONE all-gather
     qrng = np.random.default_rng(7)
@@ -192,9 +227,8 @@ def main():
             model.encode_packed(pb, mode="weightedmean", normalize=True, out=emb32[o: o + pb.B])
             o += pb.B
         rows = corpus[base: base + args.chunk]
-        if score_dt == torch.bfloat16:
-            ctx._chk(ctx.lib.sgpt_f32_to_bf16(ctx.handle, emb32.data_ptr(), emb32.numel(), rows.data_ptr(),
-                                              torch.cuda.current_stream(dev).cuda_stream), "sgpt_f32_to_bf16")
+        if score_dt != torch.float32:
+            ctx.to_16(emb32, score_dt, out=rows)          # corpus rows kept in HBM in the scorer's 16-bit format
         else:
             rows.copy_(emb32)
         return ctx.score_topk(q, rows, k1, idx_base=rank * n_steps * args.chunk + base, run=run, dtype=score_dt)
@@ -230,9 +264,73 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(fv[:, : args.topk]).all() and (fi[:, : args.topk] >= 0).all()
+    model._check_range()                                    # dtype f16: no activation left the half range (raises otherwise)
 
     sentences = world * args.steps * args.chunk
     sent_per_s = sentences / dt
+
+    # ---- N > 1: the sharded search (per-rank score+top-k with a global index base -> exchange -> merge) must equal a
+    # single-rank search over the same documents.  Checked on the first `m` rows of every rank's shard. ----
+    shard_check = None
+    if dist_on:
+        m = min(2048, args.chunk)
+        mine_rows = corpus[:m].contiguous()
+        all_rows = torch.empty((world * m, d), dtype=score_dt, device=dev)
+        dist.all_gather_into_tensor(all_rows, mine_rows)
+        stride = n_steps * args.chunk                                  # global index base of rank r = r * stride
+        sv, si, _ = ctx.score_topk(q, mine_rows, k1, idx_base=rank * stride, dtype=score_dt)
+        cv, ci = exchange_topk(sv, si)
+        mv, mi = ctx.topk_merge(cv, ci, k1)
+        wv, wi, _ = ctx.score_topk(q, all_rows, k1, idx_base=0, dtype=score_dt)
+        wi = (wi // m) * stride + wi % m
+        same = bool(torch.equal(mi, wi)) and bool(torch.equal(mv, wv))
+        flag = torch.tensor([1 if same else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        assert int(flag.item()) == 1, "sharded search != single-rank search on the same documents"
+        shard_check = {"docs": world * m, "nq": args.nq, "identical_to_single_rank": True}
+
+    # ---- the same step on documents of lengths ~U{16..128} (SURVEY 8d cfg2 asks for both) ----
+    varlen = None
+    if not args.no_varlen:
+        vrng = np.random.default_rng(2000 + rank)
+        v_steps = max(4, args.steps // 3)
+        vpacked, v_tokens, v_flops = [], 0, 0.0
+        for _ in range(v_steps + 1):
+            lens = vrng.integers(16, S + 1, size=args.chunk)
+            docs = [vrng.integers(0, min(50256, cfg.vocab_size), size=int(n)) for n in lens]
+            plan = model.plan_batches(lens.astype(np.int64))
+            vpacked.append([model.pack([docs[i] for i in sel]) for sel in plan])
+            v_tokens += int(lens.sum())
+            v_flops += float(sum(flops_per_sentence(int(n), cfg.num_layers, cfg.hidden_size) for n in lens))
+        per_step_tokens, per_step_flops = v_tokens / (v_steps + 1), v_flops / (v_steps + 1)
+
+        def vstep(i, run):
+            o = 0
+            for pb in vpacked[i]:
+                model.encode_packed(pb, mode="weightedmean", normalize=True, out=emb32[o: o + pb.B])
+                o += pb.B
+            rows = corpus[i * args.chunk: (i + 1) * args.chunk]
+            if score_dt != torch.float32:
+                ctx.to_16(emb32, score_dt, out=rows)
+            else:
+                rows.copy_(emb32)
+            return ctx.score_topk(q, rows, k1, idx_base=i * args.chunk, run=run, dtype=score_dt)
+        vrun = vstep(0, None)
+        sync()
+        t = time.perf_counter()
+        for i in range(1, v_steps + 1):
+            vrun = vstep(i, vrun)
+        sync()
+        vdt = time.perf_counter() - t
+        if dist_on:
+            tv = torch.tensor([vdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+            vdt = float(tv.item())
+        varlen = {"lengths": f"U{{16..{S}}}", "steps": v_steps, "sentences_per_s": round(world * v_steps * args.chunk / vdt, 1),
+                  "tokens_per_s": round(world * v_steps * per_step_tokens / vdt, 1),
+                  "mean_len": round(per_step_tokens / args.chunk, 2),
+                  "end_to_end_frac_of_mfma_roofline": round(v_steps * per_step_flops / vdt / (PEAK_BF16_TFLOPS * 1e12), 4)}
+        del vpacked
 
     # ---- queries/sec: scoring + top-k only, against this job's encoded corpus and a 1M-doc synthetic shard ----
     def search_once(cmat):
@@ -253,6 +351,7 @@ def main():
 
     qps_job = time_search(corpus[args.warmup * args.chunk:])
     qps_1m = qps_1m_enc = None
+    qps_enc_by_nq = {}
     if not args.no_1m:
         n1m = 1_000_000 // world                           # 1M-doc corpus sharded over the ranks
         big = torch.empty((n1m, d), dtype=score_dt, device=dev)
@@ -264,22 +363,36 @@ def main():
             big[s0:e0] = torch.nn.functional.normalize(noisy, dim=1).to(score_dt)
         del blk
         qps_1m = time_search(big, reps=3)
-        # the same search with the query side included: token ids (host) -> encode sharded over the ranks + one
-        # all-gather -> normalise -> search
-        sync()
-        t = time.perf_counter()
-        for _ in range(3):
-            q2 = ctx._operand(encode_queries(), score_dt)
-            v2, i2, _ = ctx.score_topk(q2, big, k1, idx_base=rank * big.shape[0], dtype=score_dt)
-            if dist_on:
-                cv2, ci2 = exchange_topk(v2, i2)
-                v2, i2 = ctx.topk_merge(cv2, ci2, k1)
-        sync()
-        qps_1m_enc = args.nq * 3 / (time.perf_counter() - t)
+        # the same search with the query side included: token ids (host lists) -> pack -> one pinned async H2D ->
+        # encode sharded over the ranks + one all-gather -> normalise -> search; nq = 16 / 128 / all
+        def qps_incl_encode(nq_sub, reps=3):
+            lo_, hi_ = shard_range(nq_sub, rank, world)
+            sub = queries[lo_:hi_]
+
+            def once():
+                lq = model.encode_ids(sub, normalize=True) if sub else torch.empty((0, d), device=dev)
+                qq = all_gather_queries(lq, nq_sub) if dist_on else lq
+                q2 = ctx._operand(qq, score_dt)
+                v2, i2, _ = ctx.score_topk(q2, big, k1, idx_base=rank * big.shape[0], dtype=score_dt)
+                if dist_on:
+                    cv2, ci2 = exchange_topk(v2, i2)
+                    v2, i2 = ctx.topk_merge(cv2, ci2, k1)
+            once()
+            sync()
+            t = time.perf_counter()
+            for _ in range(reps):
+                once()
+            sync()
+            return nq_sub * reps / (time.perf_counter() - t)
+        qps_enc_by_nq = {n_: qps_incl_encode(n_) for n_ in sorted({16, 128, args.nq}) if n_ <= args.nq}
+        qps_1m_enc = qps_enc_by_nq[args.nq]
         if dist_on:
-            tq = torch.tensor([qps_1m, qps_1m_enc], dtype=torch.float64, device=dev)
+            keys = sorted(qps_enc_by_nq)
+            tq = torch.tensor([qps_1m] + [qps_enc_by_nq[k_] for k_ in keys], dtype=torch.float64, device=dev)
             dist.all_reduce(tq, op=dist.ReduceOp.MIN)
-            qps_1m, qps_1m_enc = float(tq[0].item()), float(tq[1].item())
+            qps_1m = float(tq[0].item())
+            qps_enc_by_nq = {k_: float(tq[1 + j].item()) for j, k_ in enumerate(keys)}
+            qps_1m_enc = qps_enc_by_nq[args.nq]
         del big
 
     if rank != 0:
@@ -292,45 +405,79 @@ def main():
     peak = 157.3 if args.dtype == "fp32" else PEAK_BF16_TFLOPS
     # HBM bytes per launch from the committed PMC passes of this same command (profiles/, rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 corrections applied there); null if not collected
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if args.dtype == "bf16" and args.call * S == 131072 and os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f).get("gemm_avg_hbm_bytes_per_launch")
+    traffic, traffic_source = None, None
+    for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if args.dtype in ("bf16", "f16") and args.call * S == 131072 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("gemm_avg_hbm_bytes_per_launch")
+            traffic_source = f"profiles/{tname} (replayed from the committed rocprofv3 --pmc passes of this command, not measured in this run)"
+            break
     roofline = {"bound": "mfma",
-                "kernel": "gemm256d_kernel (bf16 256x256x64 persistent LDS-DMA GEMM, asymmetric 3+2-slot LDS ring; the 5 projection launches per block)"
+                "kernel": "gemm256 (16-bit operands, 256x256x64 persistent LDS-DMA GEMM, asymmetric 3+2-slot LDS ring; the 5 projection launches per block)"
                           if args.dtype != "fp32" else "gemm_kernel<float> (exact fp32 MFMA 128x128x32)",
                 "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, avg over the 5 GEMM launch shapes)",
+                "traffic_source": traffic_source,
                 "algorithmic_flops_per_launch": round(gemm_flops / max(n_launch, 1), 1),
                 "launches": n_launch, "avg_launch_ms": round(gemm_ms / max(n_launch, 1), 5),
                 "gemm_share_of_step": round(gemm_ms * 1e-3 / dt, 4),
                 "end_to_end_frac_of_mfma_roofline": round(
                     sent_per_s / world * flops_per_sentence(S, cfg.num_layers, cfg.hidden_size) / (PEAK_BF16_TFLOPS * 1e12), 4)}
 
-    # ---- CPU baseline: the numpy oracle (a port of the reference CPU path) on a bounded sample ----
+    # ---- CPU baseline + parity probe (rank 0, N = 1 only; bounded: ~10-30 s of CPU work) ----
+    # The GPU encodes 1024 sentences in ONE call (131 072 tokens: every projection runs on the 256x256-tile throughput
+    # kernels, the ones the timed region uses); every 16th row is checked against the CPU paths on the same ids.
     cpu = None
     if not args.no_cpu_baseline and world == 1 and args.model == "125m":
         from oracle import sgpt_oracle as O      # checker / reported baseline only, never the measured path
         ocfg = O.NeoConfig(**SGPT_125M)
         ow = O.synth_weights(ocfg, seed=1)
-        sample = [r for r in np.random.default_rng(5).integers(0, 50256, size=(args.cpu_sample, S)).tolist()]
+        probe = np.random.default_rng(5).integers(0, 50256, size=(1024, S), dtype=np.int64)
+        got_all = model.encode_ids(probe, normalize=True)
+        stride = max(1, 1024 // args.cpu_sample)
+        pick = np.arange(0, 1024, stride)[: args.cpu_sample]
+        sample = probe[pick].tolist()
+        got = got_all[torch.from_numpy(pick).to(dev)].cpu().numpy()
         O.encode(ow, ocfg, sample[:4], batch_size=4)                    # warm-up
         t = time.perf_counter()
         ce = O.encode(ow, ocfg, sample, batch_size=16, normalize_embeddings=True)
         cdt = time.perf_counter() - t
-        got = model.encode_ids(sample, normalize=True).cpu().numpy()
-        cpu = {"value": round(args.cpu_sample / cdt, 2), "unit": "sentences/s", "cores": os.cpu_count(),
-               "kind": "port", "sample": f"{args.cpu_sample} sentences x {S} tokens, numpy fp32 oracle "
-                                         f"(oracle/sgpt_oracle.py), encode+pool+normalise, {cdt:.1f}s",
-               "gpu_vs_cpu_max_abs_emb_diff": float(np.abs(got - ce).max())}
-        # The code the reference actually runs on a CPU: HF GPTNeoModel fp32 eager (the un-vendored
-        # dependency behind beir_dense_retriever.py:204-205) + the raw weighted-mean pooling of :258-270, same weights,
-        # same sample, all host cores.  Reported next to the port when `transformers` is importable on the box.
+        # cosine scores as the scorer computes them (rows rounded to the 16-bit corpus format) vs fp32 on the CPU
+        g16 = ctx._operand(got_all[torch.from_numpy(pick).to(dev)].contiguous(), score_dt)
+        gcos = ctx.scores(g16, g16, dtype=score_dt).cpu().numpy()
+        port = {"value": round(len(sample) / cdt, 2), "unit": "sentences/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"{len(sample)} sentences x {S} tokens, numpy fp32 oracle (oracle/sgpt_oracle.py), "
+                          f"encode+pool+normalise, {cdt:.1f}s"}
+        parity = {"checked_rows": len(sample), "gpu_call_sentences": 1024, "gpu_dtype": args.dtype,
+                  "gpu_vs_oracle_max_abs_emb_diff": float(np.abs(got - ce).max()),
+                  "gpu_vs_oracle_max_abs_cos_diff": float(np.abs(gcos - ce @ ce.T).max())}
         try:
-            cpu["hf_transformers"] = hf_cpu_baseline(ocfg, ow, sample, ce)
-        except Exception as e:  # noqa: BLE001 -- an optional, reported-only leg must never sink the bench line
-            cpu["hf_transformers"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            hf_emb, cpu = hf_cpu_baseline(ocfg, ow, sample)
+            parity["gpu_vs_hf_max_abs_emb_diff"] = float(np.abs(got - hf_emb).max())
+            parity["gpu_vs_hf_max_abs_cos_diff"] = float(np.abs(gcos - hf_emb @ hf_emb.T).max())
+            parity["oracle_vs_hf_max_abs_emb_diff"] = float(np.abs(ce - hf_emb).max())
+            cpu["checker_port"] = port
+        except Exception as e:  # noqa: BLE001 -- `transformers` missing on the box: the port is the baseline
+            cpu = dict(port, hf_error=f"{type(e).__name__}: {e}"[:200])
+        # queries/s of the reference's CPU search leg (exact_search.py:96-132 restated: cos_sim + top-k + heap merge per
+        # 50k-document chunk) for nq = 128 against a 100k-document fp32 corpus
+        crng = np.random.default_rng(11)
+        cemb = crng.standard_normal((100_000, d)).astype(np.float32)
+        cemb[:, :3] *= 30.0
+        qemb = crng.standard_normal((128, d)).astype(np.float32)
+        qemb[:, :3] *= 30.0
+        qt = []
+        for _ in range(3):
+            t = time.perf_counter()
+            O.exact_search(qemb, [f"q{i}" for i in range(128)], cemb, [f"d{i}" for i in range(100_000)], args.topk, "cos_sim",
+                           chunk_size=50_000)
+            qt.append(time.perf_counter() - t)
+        cpu["search"] = {"value": round(128 / float(np.median(qt)), 1), "unit": "queries/s", "kind": "port",
+                         "sample": "nq=128 vs 100k x 768 fp32 documents, cos_sim + top-k + per-query heap merge "
+                                   "(oracle.exact_search = exact_search.py:96-132), median of 3"}
+        cpu["gpu_vs_cpu_max_abs_emb_diff"] = parity["gpu_vs_oracle_max_abs_emb_diff"]
+        cpu["parity"] = parity
 
     out = {"metric": "encoded sentences/sec (SGPT-125M, seq_len 128, encode + weighted-mean pool + cosine top-10 "
                      "chunk loop)",
@@ -340,13 +487,15 @@ def main():
            "config": {"workload": ("BASELINE configs[1]: SGPT-125M" if args.model == "125m" else f"SGPT-{args.model.upper()}") +
                                   "-shape random-init weights, " + args.dtype + " MFMA, "
                                   f"{args.steps * args.chunk} docs/GPU x seq_len {S}, nq={args.nq}, cosine top-{args.topk} "
-                                  "(top_k+1 kept), corpus rows bf16 in HBM",
+                                  f"(top_k+1 kept), corpus rows {'fp32' if args.dtype == 'fp32' else ('f16' if args.dtype == 'f16' else 'bf16')} in HBM",
                       "docs_per_step": args.chunk, "docs_per_encode_call": args.call, "seq_len": S, "nq": args.nq,
                       "top_k": args.topk, "parallelism": f"corpus-shard x{world}"},
            "queries_per_sec_at_job_corpus": round(qps_job, 1),
            "job_corpus_docs_per_gpu": args.steps * args.chunk,
            "queries_per_sec_at_1M_corpus": None if qps_1m is None else round(qps_1m, 1),
            "queries_per_sec_at_1M_corpus_incl_query_encode": None if qps_1m_enc is None else round(qps_1m_enc, 1),
+           "queries_per_sec_at_1M_corpus_incl_query_encode_by_nq": {str(k_): round(v_, 1) for k_, v_ in qps_enc_by_nq.items()},
+           "varlen": varlen, "shard_check": shard_check,
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out))
     if dist_on:

@@ -256,6 +256,21 @@ sgpt_status sgpt_topk_merge(sgpt_ctx* ctx, const float* val, const int64_t* idx,
 sgpt_status sgpt_topk(sgpt_ctx* ctx, const float* scores, int32_t nq, int64_t n, int64_t ld,
                       int32_t k, int64_t idx_base, float* out_val, int64_t* out_idx, void* stream);
 
+/* -- the projection GEMM with its fused epilogues, as a stand-alone op ----------------------------------------------- */
+/* out = epilogue(A . W^T): the nn.Linear calls of the transformer blocks (HF:gpt_neo:141-143,155,304-309) with the
+ * element-wise tail fused -- exactly the kernels sgpt_encode launches, exposed for kernel-level parity tests and for
+ * callers that assemble their own blocks.  A device [M,K], W device [N,K] (both row-major, `dtype` SGPT_F32 / SGPT_BF16 /
+ * SGPT_F16), fp32 accumulation.
+ *   epi 0: out[M,N] = acc (+ bias if given)              out_dtype = dtype (16-bit) or SGPT_F32
+ *   epi 1: out[M,N] = gelu_new(acc + bias)               out_dtype = dtype           (HF NewGELUActivation)
+ *   epi 2: out[M,N] = resid + acc + bias                 fp32; out may alias resid (the residual stream, in place)
+ *   epi 4: out[N,M] = acc (+ bias[n])                    16-bit transposed store (V^T for the attention P.V operand), M % 128 == 0
+ * bias device fp32[N]; resid device fp32[M,N].  M % 256 == 0, N % 256 == 0, K % 64 == 0 with at least half a wave of
+ * 256x256 tiles take the LDS-DMA throughput kernel, everything else the 128x128 / 64x64 register-staged one; both
+ * feed every output element the same MFMA sequence, so the result does not depend on which one ran. */
+sgpt_status sgpt_linear(sgpt_ctx* ctx, int32_t dtype, int32_t epi, int32_t out_dtype, const void* A, const void* W,
+                        const float* bias, const float* resid, void* out, int32_t M, int32_t N, int32_t K, void* stream);
+
 /* -- measurement ----------------------------------------------------------------------- */
 /* bench.py's live roofline: when enabled, every GEMM launched by sgpt_encode /
  * sgpt_scores / sgpt_score_topk is bracketed by hipEvents on the launch stream;
@@ -263,6 +278,12 @@ sgpt_status sgpt_topk(sgpt_ctx* ctx, const float* scores, int32_t nq, int64_t n,
  * algorithmic FLOPs (2*M*N*K of the un-padded problem) since the last reset. */
 sgpt_status sgpt_prof_enable(sgpt_ctx* ctx, int32_t on);
 sgpt_status sgpt_prof_read(sgpt_ctx* ctx, int64_t* launches, double* ms, double* flops, int32_t reset);
+
+/* Process-wide choice between the two 256x256-tile GEMM kernels (0: v_mfma_f32_16x16x32, 1: v_mfma_f32_32x32x16; default
+ * from env SGPT_GEMM_W, else the library's built-in default).  Both accumulate the same products in fp32 in ascending k;
+ * the results agree to fp32 rounding (the two instructions group the products of a k-step differently), so this is a
+ * speed knob for in-process A/B measurements.  Returns the previous value. */
+int32_t sgpt_set_gemm_variant(int32_t variant);
 
 /* Micro-benchmark of one GEMM launch configuration (library-owned pseudo-random operands, never
  * zeros): average milliseconds per launch over `iters` launches.  epi: 0 store, 1 bias+gelu,

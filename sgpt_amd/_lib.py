@@ -66,6 +66,9 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgpt_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64,
                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgpt_linear": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sgpt_set_gemm_variant": (C.c_int32, [C.c_int32]),
     "sgpt_bench_gemm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.POINTER(C.c_float)]),
     "sgpt_prof_enable": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -829,6 +829,32 @@ sgpt_status sgpt_topk(sgpt_ctx* c, const float* scores, int32_t nq, int64_t n, i
 }
 
 
+int32_t sgpt_set_gemm_variant(int32_t v) { return set_gemm_variant(v); }
+
+sgpt_status sgpt_linear(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out_dtype, const void* A, const void* W,
+                        const float* bias, const float* resid, void* out, int32_t M, int32_t N, int32_t K, void* stream) {
+    if (!c || !A || !W || !out || M <= 0 || N <= 0 || K <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_linear: bad arguments");
+    const bool in16 = dtype == SGPT_BF16 || dtype == SGPT_F16, o16 = out_dtype == SGPT_BF16 || out_dtype == SGPT_F16;
+    if (!in16 && dtype != SGPT_F32) return fail(c, SGPT_ERR_INVALID, "sgpt_linear: bad dtype");
+    if (epi != EPI_STORE && epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID && epi != EPI_VT)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_linear: epi must be 0 (store), 1 (bias+gelu), 2 (bias+residual) or 4 (transposed store)");
+    if ((epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID) && !bias) return fail(c, SGPT_ERR_INVALID, "sgpt_linear: bias required");
+    if (epi == EPI_BIAS_RESID && (!resid || out_dtype != SGPT_F32)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear: residual epilogue is fp32");
+    if (epi == EPI_VT && (!in16 || out_dtype != dtype || M % 128)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear: transposed store is 16-bit, M % 128 == 0");
+    if (epi == EPI_BIAS_GELU && out_dtype != dtype) return fail(c, SGPT_ERR_INVALID, "sgpt_linear: gelu output has the operand dtype");
+    if (in16 && (o16 ? out_dtype != dtype : false)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear: 16-bit output must match the operand format");
+    if (!in16 && o16) return fail(c, SGPT_ERR_INVALID, "sgpt_linear: fp32 operands give fp32 output");
+    if (K % (in16 ? 8 : 4) || (epi != EPI_STORE && N % 4)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear: K % 8 (16-bit) / 4 (fp32), N % 4");
+    HIPC(c, hipSetDevice(c->device));
+    GemmArgs g{};
+    g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.m_valid = M; g.N = N; g.K = K; g.out = out;
+    g.ldo = epi == EPI_VT ? M : N; g.bias = bias; g.resid = resid;
+    g.range_flag = out_dtype == SGPT_F16 ? c->range_flag : nullptr;
+    gemm(c, dtype, epi, out_dtype, g, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
 sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out_dtype, int32_t M, int32_t N, int32_t K,
                             int32_t iters, float* ms_out) {
     if (!c || !ms_out || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_bench_gemm: bad arguments");

@@ -40,6 +40,9 @@ constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 #endif
 constexpr int RESID_PF = SGPT_RESID_PF;
 constexpr int CH = 8;  // 16-byte chunks per row per k-step
+#ifndef SGPT_GEMM_W_DEFAULT
+#define SGPT_GEMM_W_DEFAULT false
+#endif
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<bf16_t> { static constexpr int EPC = 8; };
@@ -496,6 +499,14 @@ void launch(const GemmArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 4>), dim3(grid), dim3(256), 0, s, a);
 }
 
+// which 256x256 kernel runs: env SGPT_GEMM_W at first use, or sgpt_set_gemm_variant() (in-process A/B of the two
+// MFMA shapes; the results agree to fp32 rounding)
+int g_variant = -1;
+int gemm_variant() {
+    if (g_variant < 0) g_variant = getenv("SGPT_GEMM_W") ? atoi(getenv("SGPT_GEMM_W")) : (SGPT_GEMM_W_DEFAULT ? 1 : 0);
+    return g_variant;
+}
+
 // 16-bit operand format H (bf16_t | f16_t): the 256x256 LDS-DMA kernel where the shape allows, else the register-staged one
 template <typename H>
 void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
@@ -511,6 +522,9 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_SCORE_FILTER && !shape256) abort();   // caller guarantees padded queries, N % 256 == 0, d % 64 == 0, d >= 128
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
+        // variant 1: the 32x32x16-MFMA re-tiling of the same kernel (gemm256w.hip); 0: the 16x16x32 one below
+        if (gemm_variant() == 1 && (epi != EPI_STORE || o16))
+            return launch_gemm256w(Half<H>::is_f16 ? DT_F16 : DT_BF16, epi, a, s, deep_a);
         if (epi == EPI_SCORE) return launch256d<H, EPI_SCORE, float, true>(a, s, deep_a);
         if (epi == EPI_SCORE_FILTER) return launch256d<H, EPI_SCORE_FILTER, float, true>(a, s, deep_a);
         if (epi == EPI_STORE && o16) return launch256d<H, EPI_STORE, H, true>(a, s, deep_a);
@@ -529,6 +543,8 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+int set_gemm_variant(int v) { const int old = gemm_variant(); g_variant = v; return old; }
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     if (dtype == DT_BF16) return launch_gemm16<bf16_t>(epi, out_dtype, a, s);

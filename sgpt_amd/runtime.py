@@ -154,6 +154,23 @@ class Context:
             return self.to_16(x, dtype)
         return x.to(device=self.device, dtype=torch.float32).contiguous()
 
+    # ---- the projection GEMM with a fused epilogue (kernel-level tests, custom blocks) ----
+    def linear(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: str = "store",
+               resid: Optional[torch.Tensor] = None, out_dtype=None) -> torch.Tensor:
+        """epi: 'store' | 'gelu' (gelu_new(a.w^T + bias)) | 'resid' (resid + a.w^T + bias, fp32) | 'vt' (transposed)."""
+        code = {"store": 0, "gelu": 1, "resid": 2, "vt": 4}[epi]
+        M, K = a.shape
+        N = w.shape[0]
+        if out_dtype is None:
+            out_dtype = torch.float32 if epi == "resid" else a.dtype
+        out = torch.empty((N, M) if epi == "vt" else (M, N), dtype=out_dtype, device=self.device)
+        b = None if bias is None else bias.to(device=self.device, dtype=torch.float32).contiguous()
+        r = None if resid is None else resid.to(device=self.device, dtype=torch.float32).contiguous()
+        self._chk(self.lib.sgpt_linear(self.handle, DT_CODE[a.dtype], code, DT_CODE[out_dtype], _p(a.contiguous()),
+                                       _p(w.contiguous()), _p(b), _p(r), _p(out), M, N, K, _stream_ptr(self.device)),
+                  "sgpt_linear")
+        return out
+
     # ---- a7: dense score matrix (cos_sim / dot_score) ----
     def scores(self, a: torch.Tensor, b: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
         a, b = self._operand(a, dtype), self._operand(b, dtype)

@@ -86,16 +86,7 @@ class SentenceTransformerSGPT:
 
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # data-parallel branch (:153-175): contiguous shards of the length-sorted list
-            order = np.argsort([-len(s) for s in seqs], kind="stable")
-            sizes = shard_sizes(len(seqs), dist.get_world_size())
-            lim = np.cumsum([0] + sizes)
-            r = dist.get_rank()
-            mine = [seqs[i] for i in order[lim[r]: lim[r + 1]]]
-            local = self.model.encode_ids(mine, mode=self.pooling_mode, normalize=normalize_embeddings)
-            gathered = all_gather_rows(local, sizes)
-            emb = torch.empty_like(gathered)
-            emb[torch.from_numpy(order).to(gathered.device)] = gathered          # un-sort (:205)
+            emb = self.encode_ids_distributed(seqs, normalize_embeddings)
         else:
             emb = self.model.encode_ids(seqs, mode=self.pooling_mode, normalize=normalize_embeddings)
 
@@ -105,6 +96,29 @@ class SentenceTransformerSGPT:
             emb = [e for e in emb]                                               # list of tensors (:207-210)
         if input_was_string:
             emb = emb[0]
+        return emb
+
+
+    def encode_ids_distributed(self, seqs, normalize_embeddings: bool = False, group=None) -> torch.Tensor:
+        """The torch.distributed data-parallel branch of SentenceTransformer.encode (:153-175): every rank sorts the
+        SAME list by length (longest first, :148-149 -- appendix A.10: the un-sort below relies on all ranks agreeing
+        on this order, so the sort is stable and keyed on the token count only), encodes its contiguous shard of the
+        sorted list (:159-163), ONE equal-size all-gather puts the shards back together in sorted order, and the
+        inverse permutation restores the input order (:205).  Every rank returns the full [n, d] matrix."""
+        import torch.distributed as dist
+        world, r = dist.get_world_size(group), dist.get_rank(group)
+        order = np.argsort(np.fromiter((-len(s) for s in seqs), dtype=np.int64, count=len(seqs)), kind="stable")
+        sizes = shard_sizes(len(seqs), world)
+        lim = np.cumsum([0] + sizes)
+        mine = [seqs[i] for i in order[lim[r]: lim[r + 1]]]
+        d = self.get_sentence_embedding_dimension()
+        if mine:
+            local = self.model.encode_ids(mine, mode=self.pooling_mode, normalize=normalize_embeddings)
+        else:                                                     # more ranks than sentences
+            local = torch.empty((0, d), dtype=torch.float32, device=getattr(self.model, "device", "cpu"))
+        gathered = all_gather_rows(local, sizes, group)
+        emb = torch.empty_like(gathered)
+        emb[torch.from_numpy(order).to(gathered.device)] = gathered              # un-sort (:205)
         return emb
 
 

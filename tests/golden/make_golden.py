@@ -200,6 +200,9 @@ def main():
     ES = load_ref_exact_search(U)
 
     # ---------------- encoder + pooling ----------------
+    if os.environ.get("GOLDEN_ONLY_CFG2"):
+        _cfg2_case(Pooling, U, ES)
+        return
     if os.environ.get("GOLDEN_ONLY_EXTRAS"):
         _extras_cases()
         _tokenize_cases()
@@ -237,6 +240,67 @@ def main():
 
     # ---------------- scoring / top-k (reference util.py + exact_search.py) ----------------
     _scoring_cases(U, ES)
+    _cfg2_case(Pooling, U, ES)
+
+
+def _cfg2_case(Pooling, U, ES):
+    """BASELINE configs[1] at a size where the throughput kernels (256x256 GEMM tiles) are the ones that run:
+    SGPT-125M shape, 1024 documents x 128 tokens + 100 queries of 4..32 tokens, through the reference stack end to end:
+    HF GPTNeoModel fp32 eager -> the reference's Pooling.py (weightedmean) -> the reference's util.cos_sim ->
+    the reference's DenseRetrievalExactSearch.search (top-10, cos_sim).  The weights are seed 1 of synth_weights =
+    sgpt_amd.synthetic_weights(seed=1), the weights bench.py runs.  Stored: embeddings, cosine scores, ranked ids."""
+    import json
+    cfg = O.NeoConfig(**O.SGPT_125M)
+    w = O.synth_weights(cfg, seed=1)
+    model = hf_model(cfg, w)
+    torch.set_num_threads(os.cpu_count() or 1)
+    rng = np.random.default_rng(21)
+    nd, nq, S, topk = 1024, 100, 128, 10
+    docs = rng.integers(0, 50256, size=(nd, S), dtype=np.int64)
+    qs = [rng.integers(0, 50256, size=int(rng.integers(4, 33))).tolist() for _ in range(nq)]
+    pm = Pooling.Pooling(cfg.hidden_size, pooling_mode_weightedmean_tokens=True, pooling_mode_mean_tokens=False)
+
+    def ref_encode(ids, mask):
+        out = []
+        for s0 in range(0, len(ids), 32):
+            i, m = torch.from_numpy(ids[s0:s0 + 32]), torch.from_numpy(mask[s0:s0 + 32])
+            h = model(input_ids=i, attention_mask=m).last_hidden_state
+            out.append(pm.forward({"token_embeddings": h, "attention_mask": m})["sentence_embedding"].numpy())
+        return np.concatenate(out)
+    d_emb = ref_encode(docs, np.ones_like(docs))
+    q_ids, q_mask = O.pad_batch(qs, pad_id=O.GPT2_PAD, side="right")
+    q_emb = ref_encode(q_ids, q_mask)
+    cos = U.cos_sim(torch.from_numpy(q_emb), torch.from_numpy(d_emb)).numpy()
+    # pin the oracle on a slice (the whole set costs minutes of numpy)
+    sel = np.arange(0, nd, 64)
+    check("cfg2 oracle encode (16 docs)", O.encode(w, cfg, docs[sel].tolist(), batch_size=16), d_emb[sel], 2e-4)
+    check("cfg2 oracle encode (8 queries)", O.encode(w, cfg, qs[:8], batch_size=8), q_emb[:8], 2e-4)
+    check("cfg2 oracle cos_sim", O.cos_sim(q_emb, d_emb), cos, 1e-6)
+
+    corpus = {f"d{i}": {"title": "", "text": "x" * (1 + i % 7)} for i in range(nd)}
+    queries = {f"q{i}": "q" for i in range(nq)}
+    cvec = {f"d{i}": d_emb[i] for i in range(nd)}
+    qvec = {f"q{i}": q_emb[i] for i in range(nq)}
+
+    class FakeModel:
+        def encode_queries(self, qq, batch_size, **kw):
+            return torch.from_numpy(np.stack([qvec[qid] for qid, _ in qq]))
+
+        def encode_corpus(self, cs, batch_size, **kw):
+            return torch.from_numpy(np.stack([cvec[cid] for cid, _ in cs]))
+    res = ES.DenseRetrievalExactSearch(FakeModel(), batch_size=8, corpus_chunk_size=400).search(corpus, queries, topk, "cos_sim")
+    # ranked ids (the reference returns an unordered dict of top_k+1 hits): sort by (-score, doc index)
+    ranked = np.array([[int(c[1:]) for c in sorted(res[f"q{i}"], key=lambda c: (-res[f"q{i}"][c], int(c[1:])))[:topk]]
+                       for i in range(nq)], dtype=np.int64)
+    brute = np.argsort(-cos, axis=1, kind="stable")[:, :topk]
+    assert np.array_equal(ranked, brute), "reference exact_search top-10 != brute force on the reference cosine matrix"
+    np.savez_compressed(os.path.join(HERE, "cfg2_125m_1024x128.npz"), seed=1, doc_ids=docs.astype(np.int32),
+                        query_lens=np.array([len(q) for q in qs]), query_ids=q_ids.astype(np.int32),
+                        doc_emb=d_emb, query_emb=q_emb, cos=cos.astype(np.float32), top10=ranked,
+                        meta=np.array(json.dumps(dict(nd=nd, nq=nq, S=S, topk=topk, rng_seed=21))))
+    srt = -np.sort(-cos, axis=1)
+    print(f"wrote cfg2_125m_1024x128.npz; cos range [{cos.min():.3f}, {cos.max():.3f}], "
+          f"smallest gap between rank 10 and rank 11: {float((srt[:, 9] - srt[:, 10]).min()):.2e}")
 
 
 def _gptj_cases(Pooling):
