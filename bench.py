@@ -293,7 +293,7 @@ def main():
     varlen = None
     if not args.no_varlen:
         vrng = np.random.default_rng(2000 + rank)
-        v_steps = max(4, args.steps // 3)
+        v_steps = max(1, min(max(4, args.steps // 3), n_steps - 1))
         vpacked, v_tokens, v_flops = [], 0, 0.0
         for _ in range(v_steps + 1):
             lens = vrng.integers(16, S + 1, size=args.chunk)

@@ -279,7 +279,8 @@ sgpt_status sgpt_linear(sgpt_ctx* ctx, int32_t dtype, int32_t epi, int32_t out_d
 sgpt_status sgpt_prof_enable(sgpt_ctx* ctx, int32_t on);
 sgpt_status sgpt_prof_read(sgpt_ctx* ctx, int64_t* launches, double* ms, double* flops, int32_t reset);
 
-/* Process-wide choice between the two 256x256-tile GEMM kernels (0: v_mfma_f32_16x16x32, 1: v_mfma_f32_32x32x16; default
+/* Process-wide choice between the two 256x256-tile GEMM kernels (bit 0 -- 0: v_mfma_f32_16x16x32, 1: v_mfma_f32_32x32x16;
+ * bit 1: use them even for problems of less than half a wave of tiles, which normally take the small-tile kernel; default
  * from env SGPT_GEMM_W, else the library's built-in default).  Both accumulate the same products in fp32 in ascending k;
  * the results agree to fp32 rounding (the two instructions group the products of a k-step differently), so this is a
  * speed knob for in-process A/B measurements.  Returns the previous value. */

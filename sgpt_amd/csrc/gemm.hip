@@ -500,7 +500,8 @@ void launch(const GemmArgs& a, hipStream_t s) {
 }
 
 // which 256x256 kernel runs: env SGPT_GEMM_W at first use, or sgpt_set_gemm_variant() (in-process A/B of the two
-// MFMA shapes; the results agree to fp32 rounding)
+// MFMA shapes; the results agree to fp32 rounding).  bit 0: 32x32x16-MFMA kernel; bit 1: keep 256x256 tiles for
+// problems the small-tile rule would hand to the register-staged kernel (kernel tests of single-tile shapes)
 int g_variant = -1;
 int gemm_variant() {
     if (g_variant < 0) g_variant = getenv("SGPT_GEMM_W") ? atoi(getenv("SGPT_GEMM_W")) : (SGPT_GEMM_W_DEFAULT ? 1 : 0);
@@ -516,14 +517,14 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     // Bit-identical results (see gemm_kernel), so the embeddings stay batch-invariant.  SGPT_NO_SMALL_TILE=1: A/B.
     static const bool small_tiles = getenv("SGPT_NO_SMALL_TILE") == nullptr;
     const bool scorer = epi == EPI_SCORE || epi == EPI_SCORE_FILTER;
-    const bool few = small_tiles && !scorer && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
+    const bool few = small_tiles && !(gemm_variant() & 2) && !scorer && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
     static const bool use256 = getenv("SGPT_GEMM128") == nullptr;
     const bool shape256 = a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128;
     if (epi == EPI_SCORE_FILTER && !shape256) abort();   // caller guarantees padded queries, N % 256 == 0, d % 64 == 0, d >= 128
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
         // variant 1: the 32x32x16-MFMA re-tiling of the same kernel (gemm256w.hip); 0: the 16x16x32 one below
-        if (gemm_variant() == 1 && (epi != EPI_STORE || o16))
+        if ((gemm_variant() & 1) && (epi != EPI_STORE || o16))
             return launch_gemm256w(Half<H>::is_f16 ? DT_F16 : DT_BF16, epi, a, s, deep_a);
         if (epi == EPI_SCORE) return launch256d<H, EPI_SCORE, float, true>(a, s, deep_a);
         if (epi == EPI_SCORE_FILTER) return launch256d<H, EPI_SCORE_FILTER, float, true>(a, s, deep_a);

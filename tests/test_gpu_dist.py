@@ -1,0 +1,72 @@
+"""-m gpu: the multi-GPU code paths on the real "nccl" backend (= RCCL on ROCm).  One GPU is enough to prove that RCCL
+loads, that all_gather_into_tensor runs on device tensors and that the product's sharding code (sgpt_amd.dist,
+SentenceTransformerSGPT.encode_ids_distributed) gives the single-process result: the process group has world_size 1,
+so every collective degenerates to a copy through RCCL.  The same functions run with world_size 2 on gloo in
+tests/test_dist_gloo.py; bench.py --gpus N is the N-rank run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sgpt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+
+
+def test_rccl_sharded_search_equals_local_search(nccl_group):
+    from sgpt_amd import get_context
+    from sgpt_amd.dist import all_gather_queries, exchange_topk, sharded_score_topk
+    ctx = get_context("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    nq, N, d, k = 100, 20_000, 768, 11
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).cuda()
+    c = torch.nn.functional.normalize(torch.randn(N, d, generator=g), dim=1).cuda().to(torch.float16)
+    assert nccl_group.get_backend() == "nccl"
+    q_all = all_gather_queries(q, nq)                                  # RCCL all_gather_into_tensor
+    assert torch.equal(q_all, q)
+    excl = torch.full((nq,), -1, dtype=torch.int64)
+    excl[4] = 777 + 12
+    fv, fi = sharded_score_topk(ctx, q, nq, c, k, idx_base=777, exclude_idx=excl, dtype=torch.float16)
+    wv, wi, _ = ctx.score_topk(q, c, k, idx_base=777, dtype=torch.float16)
+    mv, mi = ctx.topk_merge(wv, wi, k, exclude_idx=excl)
+    assert torch.equal(fi, mi) and torch.equal(fv, mv)
+    assert (fi[4] != 789).all()
+    cv, ci = exchange_topk(wv, wi)
+    assert torch.equal(cv, wv) and torch.equal(ci, wi)
+
+
+def test_rccl_distributed_encode_equals_local_encode(nccl_group):
+    from helpers import build_model
+    from sgpt_amd.st import SentenceTransformerSGPT
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    kw = dict(vocab_size=211, max_position_embeddings=96, hidden_size=128, num_layers=4, num_heads=2, window_size=8)
+    m = build_model(kw, 11, 0.08, "f16")
+    st = SentenceTransformerSGPT(m, SyntheticTokenizer(211), max_seq_length=64)
+    rng = np.random.default_rng(9)
+    words = ["alpha", "beta", "gamma", "delta", "eps", "zeta", "eta", "theta"]
+    sents = [" ".join(rng.choice(words, size=int(rng.integers(1, 40)))) for _ in range(57)]
+    seqs = st.pipe.batch(sents, True)
+    got = st.encode_ids_distributed(seqs, normalize_embeddings=True)   # shard -> encode -> RCCL all-gather -> un-sort
+    want = m.encode_ids(seqs, normalize=True)
+    assert got.is_cuda and got.shape == want.shape and float((got - want).abs().max()) < 1e-6
+    ref = O.encode(O.synth_weights(O.NeoConfig(**kw), seed=11, std=0.08), O.NeoConfig(**kw), seqs, normalize_embeddings=True)
+    assert np.abs(got.cpu().numpy() - ref).max() < 5e-3

@@ -2,9 +2,12 @@
 (1) the committed golden vectors made by the real reference (HF GPTNeoModel + Pooling.py) and
 (2) the numpy oracle on the same seeded inputs.
 
-Tolerance (BASELINE.json north_star): embeddings within 1e-3 of the reference CPU path in the
-exact-fp32 MFMA mode (the parity gate).  The bf16-MFMA mode is measured against the same
-golden vectors and must stay within the looser, stated bf16 budget."""
+Tolerance (BASELINE.json north_star): embeddings / cosine scores within 1e-3 of the reference CPU path.
+  fp32 mode (exact-fp32 MFMA): held to 1e-3 on raw embeddings (measured ~5e-6).
+  f16 mode (the benchmarked mode; IEEE-half MFMA operands): cosine scores held to 1e-3 (measured ~2e-4; the
+      cfg2-size ranked test is tests/test_gpu_parity_cfg2.py); raw O(1) embeddings within TOL_F16_ABS.
+  bf16 mode: measured 2.2-2.6e-2 on raw embeddings / 1.0-1.5e-3 on cosine scores in round 1; asserted at ~1.5x that
+      (a regression trips), reported, not the gate."""
 import numpy as np
 import pytest
 import torch
@@ -15,8 +18,11 @@ from helpers import build_model, load_case, maxabs, row_cos
 pytestmark = pytest.mark.gpu
 
 TOL_FP32 = 1e-3          # north_star gate
-TOL_BF16_ABS = 6e-2      # bf16 operands, 12 layers, O(1) activations; reported, not the gate
-TOL_BF16_COS = 0.999
+TOL_BF16_ABS = 4e-2      # bf16 operands, 12 layers, O(1) activations (measured 2.6e-2); reported, not the gate
+TOL_BF16_COS = 0.9999    # min row cosine (measured 0.99996)
+TOL_BF16_DCOS = 2.5e-3   # max |cos - cos_ref| between embedding pairs (measured 1.5e-3)
+TOL_F16_ABS = 6e-3       # f16 operands: 8x finer mantissa than bf16 (CPU emulation scripts/numerics_study.py: 1.2e-4 on
+TOL_F16_DCOS = 1e-3      #   normalised embeddings, 2.3e-4 on cosine scores); the cosine bound IS the north_star bar
 
 
 @pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128", "tiny_gptj_right", "tiny_gptj_left",
@@ -84,7 +90,53 @@ def test_encode_bf16_vs_golden(tag):
     # cosine-score deviation of the bf16 path (reported in DESIGN.md)
     dev = maxabs(O.cos_sim(got, got), O.cos_sim(fx["emb_weightedmean"], fx["emb_weightedmean"]))
     print(f"{tag} bf16: max|cos - cos_ref| = {dev:.3e}")
-    assert dev < 1e-2
+    assert dev < TOL_BF16_DCOS
+
+
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_dh128", "cfg1_125m_32x64", "cfg3_125m_specb_s300",
+                                 "tiny_gptj_right", "tiny_gptj_left", "tiny_bloom_left", "tiny_bloom_right"])
+def test_encode_f16_vs_golden(tag):
+    """IEEE-half MFMA operands (weights, LN output, q/k/v, probabilities, context, GELU output), fp32 accumulate /
+    residual / LN / softmax: all three families against the reference's golden vectors, cosine scores at the bar."""
+    fx, cfg_kw, seqs, pad_left, ids, mask = load_case(tag)
+    m = build_model(cfg_kw, int(fx["seed"]), float(fx["std"]), "f16")
+    got = m.encode_ids(seqs, mode="weightedmean", pad_left=pad_left).cpu().numpy()
+    ref = fx["emb_weightedmean"]
+    err = maxabs(got, ref)
+    dev = maxabs(O.cos_sim(got, got), O.cos_sim(ref, ref))
+    print(f"{tag} f16: max|emb - ref| = {err:.3e} (|ref| max {np.abs(ref).max():.2f}), max|cos - cos_ref| = {dev:.3e}")
+    assert np.isfinite(got).all()
+    assert err < TOL_F16_ABS * max(1.0, float(np.abs(ref).max())) and dev < TOL_F16_DCOS
+    for mode in ("mean", "lasttoken"):
+        g2 = m.encode_ids(seqs, mode=mode, pad_left=pad_left).cpu().numpy()
+        assert maxabs(g2, fx[f"emb_{mode}"]) < TOL_F16_ABS * max(1.0, float(np.abs(fx[f"emb_{mode}"]).max())), mode
+
+
+def test_f16_range_guard_fails_loudly():
+    """f16 has 5 exponent bits.  Weights / LayerNorm parameters that cannot be represented are refused at load;
+    an activation that reaches |v| >= 32768 at run time raises from encode_ids (never a silent inf)."""
+    from sgpt_amd import SGPTConfig, SGPTModel
+    from sgpt_amd._lib import SgptRangeError
+    kw = dict(vocab_size=211, max_position_embeddings=96, hidden_size=128, num_layers=2, num_heads=2, window_size=8)
+    base = O.synth_weights(O.NeoConfig(**kw), seed=3, std=0.05)
+    seqs = [[1, 2, 3, 4, 5], [7] * 40]
+    w = dict(base); w["h.1.attn.attention.q_proj.weight"] = base["h.1.attn.attention.q_proj.weight"] * 0 + 1e5
+    with pytest.raises(SgptRangeError):
+        SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
+    w = dict(base); w["h.0.ln_2.weight"] = base["h.0.ln_2.weight"] * 0 + 4000.0          # 4000 * sqrt(128) > 32768
+    with pytest.raises(SgptRangeError):
+        SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
+    w = dict(base); w["h.1.mlp.c_fc.bias"] = base["h.1.mlp.c_fc.bias"] * 0 + 5e4          # gelu_new(5e4) = 5e4 -> f16 h
+    m = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
+    with pytest.raises(SgptRangeError):
+        m.encode_ids(seqs)
+    m.close()
+    mb = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="bf16")                     # bf16 takes the same weights
+    assert torch.isfinite(mb.encode_ids(seqs)).all()
+    mb.close()
+    ok = SGPTModel(SGPTConfig(**kw), base, device="cuda:0", dtype="f16")
+    assert torch.isfinite(ok.encode_ids(seqs)).all()                                       # and the flag was reset
+    ok.close()
 
 
 def test_encode_bf16_vs_oracle_with_dequantised_weights():
@@ -98,7 +150,7 @@ def test_encode_bf16_vs_oracle_with_dequantised_weights():
     assert maxabs(got, want) < TOL_BF16_ABS
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "f16"])
 def test_encode_is_batch_and_order_invariant(dtype):
     """Right padding => an embedding does not depend on its batch: packing,
     batch planning and the un-sort must be transparent.  Size-independent property check."""
@@ -135,11 +187,12 @@ def test_encode_errors():
         m.encode_ids([[1] * 200])                                     # longer than max_position_embeddings (96)
 
 
-def test_cfg2_full_size_properties():
-    """BASELINE config 2 sizes (SGPT-125M bf16, seq_len 128): size-independent properties --
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_cfg2_full_size_properties(dtype):
+    """BASELINE config 2 sizes (SGPT-125M, 16-bit operands, seq_len 128): size-independent properties --
     unit norms, batch invariance across different pack layouts, finite outputs."""
     cfg_kw = dict(O.SGPT_125M)
-    m = build_model(cfg_kw, 1, 0.02, "bf16")
+    m = build_model(cfg_kw, 1, 0.02, dtype)
     rng = np.random.default_rng(1)
     docs = [rng.integers(0, 50256, size=128).tolist() for _ in range(2048)]
     e = m.encode_ids(docs, normalize=True)
@@ -152,8 +205,8 @@ def test_cfg2_full_size_properties():
     e32 = m32.encode_ids(docs[:64], normalize=True)
     dev = torch.max(torch.abs(e[:64] - e32)).item()
     cs = torch.max(torch.abs(e[:64] @ e[:64].T - e32 @ e32.T)).item()
-    print(f"cfg2 bf16 vs fp32: max|emb diff| = {dev:.3e}, max|cos diff| = {cs:.3e}")
-    assert dev < TOL_BF16_ABS and cs < 1e-2
+    print(f"cfg2 {dtype} vs fp32: max|emb diff| = {dev:.3e}, max|cos diff| = {cs:.3e}")
+    assert (dev < 1e-3 and cs < 1e-3) if dtype == "f16" else (dev < 2e-3 and cs < TOL_BF16_DCOS)
 
 
 @pytest.mark.parametrize("name,shape", [("1.3B", dict(hidden_size=2048, num_heads=16)),
@@ -290,7 +343,39 @@ def test_encode_graph_capture_and_replay():
     assert graph < eager * 1.5
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_encode_graph_survives_workspace_growth():
+    """the captured kernels hold raw pointers into the context's grow-only workspace.  A later,
+    larger eager call on the same context frees and re-allocates it; replay() must notice (context generation) and
+    re-capture instead of launching into freed memory.  A private Context makes the growth certain."""
+    from sgpt_amd import EncodeGraph, SGPTConfig, SGPTModel
+    from sgpt_amd.runtime import Context
+    kw = dict(vocab_size=211, max_position_embeddings=96, hidden_size=128, num_layers=2, num_heads=2, window_size=8)
+    w = O.synth_weights(O.NeoConfig(**kw), seed=3, std=0.05)
+    ctx = Context(0)
+    m = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16", ctx=ctx)
+    rng = np.random.default_rng(5)
+    small = [rng.integers(0, 211, size=int(n)).tolist() for n in rng.integers(3, 30, size=8)]
+    g = EncodeGraph(m, small, normalize=True)
+    want = m.encode_ids(small, normalize=True).cpu().numpy()
+    gen0 = ctx.generation()
+    big = [rng.integers(0, 211, size=90).tolist() for _ in range(3000)]           # ~288k tokens: the workspace must grow
+    m.max_tokens_per_call = 1 << 20
+    m.encode_ids(big)
+    assert ctx.generation() != gen0, "the test did not force a re-allocation"
+    torch.cuda.synchronize()
+    got = g.replay().cpu().numpy()                                                  # re-captured, not stale
+    assert g.generation == ctx.generation() and np.array_equal(got, want)
+    m.set_position_weights(np.linspace(0.5, 2.0, 96, dtype=np.float32))            # a new pooling table also moves it
+    g2 = EncodeGraph(m, small, mode="learntmean")
+    a = g2.replay().cpu().numpy()
+    m.set_position_weights(np.linspace(2.0, 0.5, 200, dtype=np.float32))           # larger table -> re-allocated
+    b = g2.replay().cpu().numpy()
+    assert np.array_equal(b, m.encode_ids(small, mode="learntmean").cpu().numpy()) and not np.array_equal(a, b)
+    m.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "f16"])
 def test_encode_long_sequences_full_context(dtype):
     """Sequences up to max_position_embeddings = 2048 (the API limit): 32 key tiles per query block, global and
     256-token sliding-window layers, mixed with short sequences in one packed call."""
@@ -306,6 +391,8 @@ def test_encode_long_sequences_full_context(dtype):
     m.close()
     if dtype == "fp32":
         assert maxabs(got, want) < TOL_FP32
+    elif dtype == "f16":
+        assert np.isfinite(got).all() and maxabs(got, want) < TOL_F16_ABS and float(row_cos(got, want).min()) > 0.99999
     else:
         assert np.isfinite(got).all() and maxabs(got, want) < TOL_BF16_ABS and float(row_cos(got, want).min()) > TOL_BF16_COS
 

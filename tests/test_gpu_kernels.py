@@ -184,13 +184,13 @@ def test_topk_merge_and_exclude(ctx):
 
 
 # ---------------------------------------------------------------- fused score + top-k -----
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_score_topk_vs_torch(ctx, dtype):
     nq, N, d, k = 33, 70001, 768, 11                                 # several internal chunks, ragged tail
     g = torch.Generator(device="cpu").manual_seed(0)
     q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).cuda()
     c = torch.nn.functional.normalize(torch.randn(N, d, generator=g), dim=1).cuda()
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         q, c = q.to(dtype), c.to(dtype)
     val, idx, n = ctx.score_topk(q, c, k, idx_base=5, dtype=dtype)
     assert n == k
@@ -279,14 +279,16 @@ def test_score_topk_ring_depths(ctx, d):
     assert (torch.gather(full, 1, idx) - tv).abs().max().item() < 2e-3 * float(tv.abs().max())
 
 
+@pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("case", ["random", "ascending", "ties", "running"])
-def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case):
+def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case, dt16):
     """Long corpora take the threshold-filtered path (EPI_SCORE_FILTER: chunks after the first only append scores
     above the running k-th best; doubling chunk schedule; predicated classic fallback on candidate overflow).
     It must return exactly what the materialise-and-select chunk loop returns -- same values, same indices,
     same tie order -- including when every document beats the threshold (ascending scores -> overflow -> the
     sync-free fallback) and under massive ties."""
-    nq, d, k = 2048, 64, 10                      # nq = 2048 -> 16 384-document chunks; N >= 32 768 takes the filtered path
+    nq, d, k = 2048, 128, 10                     # nq = 2048 -> 16 384-document chunks; N >= 32 768 takes the filtered path
+                                                 # (d >= 128: two k-steps, the minimum of the LDS-ring kernels)
     g = torch.Generator(device="cpu").manual_seed(3)
     q = torch.randn(nq, d, generator=g)
     if case == "random":
@@ -303,11 +305,11 @@ def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case):
     else:
         N = 70_000
         c = torch.randn(N, d, generator=g)
-    q, c = q.cuda().to(torch.bfloat16), c.cuda().to(torch.bfloat16)
+    q, c = q.cuda().to(dt16), c.cuda().to(dt16)
     run = None
     base = 0
     if case == "running":                        # incoming running best + global index base
-        prev = torch.randn(5000, d, generator=torch.Generator(device="cpu").manual_seed(9)).cuda().to(torch.bfloat16) * 1.5
+        prev = torch.randn(5000, d, generator=torch.Generator(device="cpu").manual_seed(9)).cuda().to(dt16) * 1.5
         v0, i0, n0 = ctx.score_topk(q, prev, k, idx_base=0)
         run, base = (v0.clone(), i0.clone(), n0), 5000
         val, idx, n = ctx.score_topk(q, c, k, idx_base=base, run=(v0, i0, n0))
@@ -324,7 +326,7 @@ def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case):
     if case == "ties":
         # the best document's 80 copies tie: its ten lowest indices p, p + 1024, ..., p + 9 * 1024
         assert torch.equal(idx, idx[:, :1] + 1024 * torch.arange(k, device=idx.device)[None, :]) and (idx[:, 0] < 1024).all()
-    if case == "ascending":              # (bf16 rounds neighbouring documents to equal scores: ties ascend by index)
+    if case == "ascending":              # (16-bit rounding maps neighbouring documents to equal scores: ties ascend by index)
         assert (idx >= N - 64).all() and (val[:, :-1] >= val[:, 1:]).all()
 
 
@@ -359,7 +361,7 @@ def test_score_topk_filtered_large_k(ctx, k):
     """The BEIR driver retrieves top_k = 1000 (k + 1 = 1001 kept, exact_search.py:104): the filtered path covers
     k <= 1024 (candidate capacity min(4k, 2048 - k); chunks grow by half when the capacity is below 2.5 k) and must
     equal the materialise-and-select loop exactly."""
-    nq, N, d = 512, 150_000, 64
+    nq, N, d = 512, 150_000, 128
     g = torch.Generator(device="cpu").manual_seed(k)
     q = torch.randn(nq, d, generator=g).cuda().to(torch.bfloat16)
     c = torch.randn(N, d, generator=g).cuda().to(torch.bfloat16)

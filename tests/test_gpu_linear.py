@@ -1,0 +1,118 @@
+"""-m gpu: the projection GEMM with its fused epilogues (sgpt_linear = the kernels sgpt_encode launches), directly,
+against a plain PyTorch fp32 product of the SAME 16-bit operands: both 256x256 LDS-DMA
+kernels (16x16x32 and 32x32x16 MFMA), bf16 and f16, the ring parities K = 128 / 192 / 320 / 768 / 3072, M = 256
+(single tile row) and the register-staged small-tile kernels.  Tolerance: fp32 accumulation-order noise only,
+1e-3 * sqrt(K / 64) relative to the output scale for fp32 outputs; one rounding to the 16-bit output format on top
+(2^-8 bf16 / 2^-11 f16 relative) for 16-bit outputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HALF = {"bf16": torch.bfloat16, "f16": torch.float16}
+ULP = {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sgpt_amd import get_context
+    return get_context("cuda:0")
+
+
+@pytest.fixture(params=[0, 1, 2, 3], ids=["mfma16", "mfma32", "mfma16-forced256", "mfma32-forced256"])
+def variant(request, ctx):
+    """bit 0: 32x32x16-MFMA kernel; bit 1: 256x256 tiles even when they leave most CUs idle (single-tile cases)."""
+    old = ctx.lib.sgpt_set_gemm_variant(request.param)
+    yield request.param
+    ctx.lib.sgpt_set_gemm_variant(old)
+
+
+def gelu_new(u):
+    return 0.5 * u * (1.0 + torch.tanh(0.7978845608028654 * (u + 0.044715 * u ** 3)))
+
+
+def operands(M, N, K, dt, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn((M, K), generator=g, device="cuda").to(HALF[dt])
+    w = (torch.randn((N, K), generator=g, device="cuda") * (1.0 / math.sqrt(K))).to(HALF[dt])
+    bias = torch.randn((N,), generator=g, device="cuda") * 0.3
+    resid = torch.randn((M, N), generator=g, device="cuda") * 2.0
+    return a, w, bias, resid
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(4096, 2304, 128), (4096, 2304, 192), (2304, 4096, 320), (8192, 768, 768),
+                                   (2048, 768, 3072), (256, 768, 768), (512, 256, 128), (131072 // 8, 1536, 768)])
+def test_linear_epilogues_vs_torch_fp32(ctx, variant, dt, M, N, K):
+    a, w, bias, resid = operands(M, N, K, dt, seed=M + N + K)
+    acc = a.float() @ w.float().T                                    # fp32 reference of the same operands
+    scale = float(acc.abs().max())
+    tol32 = 1e-3 * math.sqrt(K / 64) * scale
+    # bias + residual, in place on the residual stream (out aliases resid)
+    x = resid.clone()
+    ctx._chk(ctx.lib.sgpt_linear(ctx.handle, 1 if dt == "bf16" else 3, 2, 0, a.data_ptr(), w.data_ptr(), bias.data_ptr(),
+                                 x.data_ptr(), x.data_ptr(), M, N, K, None), "sgpt_linear")
+    want = resid + acc + bias
+    assert torch.isfinite(x).all()
+    assert float((x - want).abs().max()) < tol32 + 1e-6 * float(want.abs().max()), "bias + residual"
+    # bias + gelu_new -> 16-bit
+    h = ctx.linear(a, w, bias, epi="gelu")
+    want = gelu_new(acc + bias)
+    err = (h.float() - want).abs()
+    assert float((err - ULP[dt] * want.abs()).max()) < tol32 + 2e-3 * (1.0 if dt == "bf16" else 0.25), "bias + gelu (fast sigmoid form)"
+    # plain store (+ bias) -> 16-bit, and the transposed V^T store
+    s = ctx.linear(a, w, bias, epi="store")
+    want = acc + bias
+    assert float(((s.float() - want).abs() - ULP[dt] * want.abs()).max()) < tol32
+    if M % 128 == 0:
+        vt = ctx.linear(a, w, None, epi="vt")
+        assert vt.shape == (N, M)
+        assert float(((vt.float() - acc.T).abs() - ULP[dt] * acc.T.abs()).max()) < tol32
+        vtb = ctx.linear(a, w, bias, epi="vt")
+        want = (acc + bias).T
+        assert float(((vtb.float() - want).abs() - ULP[dt] * want.abs()).max()) < tol32
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_linear_layout_is_not_transposed(ctx, variant, dt):
+    """A = I-like probe with an ASYMMETRIC weight matrix: a swapped row/column or k-slot map cannot pass."""
+    M = N = 4096
+    K = 256
+    a = torch.zeros((M, K), device="cuda")
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    w = (torch.arange(N, device="cuda")[:, None] * 3 + torch.arange(K, device="cuda")[None, :] * 7) % 61 - 30.0
+    out = ctx.linear(a.to(HALF[dt]), w.to(HALF[dt]), None, epi="store", out_dtype=HALF[dt])
+    want = w[:, torch.arange(M, device="cuda") % K].T                # out[m][n] = w[n][m % K], small integers: exact
+    assert torch.equal(out.float(), want)
+
+
+def test_linear_variants_agree(ctx):
+    """The two MFMA shapes accumulate the same products: fp32 outputs agree to accumulation-order noise."""
+    a, w, bias, resid = operands(4096, 3072, 768, "f16", seed=5)
+    outs = []
+    for v in (0, 1):
+        old = ctx.lib.sgpt_set_gemm_variant(v)
+        outs.append(ctx.linear(a, w, bias, epi="resid", resid=resid))
+        ctx.lib.sgpt_set_gemm_variant(old)
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5 * float(outs[0].abs().max())
+
+
+def test_f16_range_flag_raised_by_store_epilogue(ctx):
+    """|v| >= 32768 rounded to f16 raises the context's range flag; bf16 outputs of the same values do not."""
+    a = torch.full((4096, 128), 16.0, device="cuda").to(torch.float16)
+    w = torch.full((2304, 128), 16.0, device="cuda").to(torch.float16)           # acc = 128 * 256 = 32768
+    assert not ctx.range_check()
+    ctx.linear(a, w, None, epi="store")
+    assert ctx.range_check()                                                     # and it resets
+    assert not ctx.range_check()
+    ctx.linear((a.float() * 0.5).to(torch.float16), w, None, epi="store")         # 16384: inside the guard band
+    assert not ctx.range_check()
+    ctx.linear(a.to(torch.bfloat16), w.to(torch.bfloat16), None, epi="store")
+    assert not ctx.range_check()
+    ctx.linear(a[:256], w[:256], None, epi="store")                               # the small-tile kernel tracks it too
+    assert ctx.range_check()
+    ctx.linear(a[:256], w[:256], None, epi="vt")
+    assert ctx.range_check()

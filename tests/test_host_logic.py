@@ -137,8 +137,12 @@ def test_text_pipeline_matches_reference_tokenisation_golden():
         pipe = TextPipeline(tok, case["max_seq_length"], specb=case["mode"] == "specb", speca=case["mode"] == "speca",
                             st_path=case["path"] == "st")
         strip = (lambda t: str(t).strip()) if case["path"] == "st" else (lambda t: t)
+        assert getattr(tok, "is_fast", False)                     # -> TextPipeline.batch takes the one-call batched path
         assert pipe.batch([strip(q) for q in fx["queries"]], True) == case["query_ids"], case
         assert pipe.batch([strip(t) for t in doc_texts], False) == case["doc_ids"], case
+        # the batched fast-tokenizer path and the per-text reference loop (tokenize + convert_tokens_to_ids) agree
+        assert [pipe.ids(strip(q), True) for q in fx["queries"]] == case["query_ids"], case
+        assert [pipe.ids(strip(t), False) for t in doc_texts] == case["doc_ids"], case
         if case["mode"] == "speca":
             assert len(tok) == case["vocab_len"]        # four added rows, same ids as the reference's add_tokens
 
@@ -254,3 +258,73 @@ def test_crossencoder_host_logic_matches_oracle():
     assert reqs[1][1] == [tok.eos_token_id]                    # empty context -> end-of-text token
     with pytest.raises(AssertionError):
         model_input([1, 2, 3], list(range(50)), 48, 0)         # continuation longer than max_length
+
+
+def test_pack_arena_equals_reference_layout_for_every_input_form():
+    """One-buffer packed layout (ids | pos | seq_off | seq_len | pad_left): lists, lists of ndarrays and a rectangular
+    ndarray give the same image; rows land at seq_off[b] + t, positions are pad_left[b] + t, filler stays 0."""
+    from sgpt_amd.model import ALIGN, TOKEN_TILE, arena_ints, fill_arena, pack_host, pack_layout
+    rng = np.random.default_rng(4)
+    lens = [1, 16, 17, 40, 5, 128]
+    seqs = [rng.integers(1, 1000, size=n).tolist() for n in lens]
+    pl = [3, 0, 7, 0, 0, 1]
+    h = pack_host(seqs, pl)
+    assert h["T_pad"] % TOKEN_TILE == 0 and h["arena"].shape[0] == arena_ints(pack_layout(seqs, pl))
+    off = h["seq_off"]
+    assert (off % ALIGN == 0).all() and off[0] == 0
+    for b, s in enumerate(seqs):
+        assert h["ids"][off[b]: off[b] + len(s)].tolist() == s
+        assert h["pos"][off[b]: off[b] + len(s)].tolist() == list(range(pl[b], pl[b] + len(s)))
+        assert (h["ids"][off[b] + len(s): off[b + 1]] == 0).all()
+    assert h["seq_len"].tolist() == lens and h["pad_left"].tolist() == pl and h["max_pos"] == 128
+    h2 = pack_host([np.asarray(s) for s in seqs], pl)
+    assert np.array_equal(h["arena"], h2["arena"])
+    rect = rng.integers(0, 50000, size=(9, 32))
+    assert np.array_equal(pack_host(rect)["arena"], pack_host(rect.tolist())["arena"])         # aligned fast path
+    rect = rng.integers(0, 50000, size=(5, 20))
+    assert np.array_equal(pack_host(rect)["arena"], pack_host(rect.tolist())["arena"])         # unaligned rectangle
+    lay = pack_layout(seqs, pl)
+    hi, lo = fill_arena(seqs, lay, np.empty(arena_ints(lay) + 7, dtype=np.int32))
+    assert hi == max(max(s) for s in seqs) and lo == min(min(s) for s in seqs)
+    with pytest.raises(ValueError, match="Empty items should be cleaned prior to running"):
+        pack_host([[1], []])
+
+
+def _device_asm(name):
+    import subprocess
+    import sys
+    from sgpt_amd import build as b
+    src = os.path.join(ROOT, "sgpt_amd", "csrc", name)
+    out = subprocess.run([b._hipcc()] + b.FLAGS + ["--cuda-device-only", "-S", src, "-o", "-"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("src", ["gemm.hip", "gemm256w.hip"])
+def test_m0_only_written_by_the_dma_idiom(src):
+    """The LDS-DMA pieces set M0 inside inline asm without declaring it clobbered (hipcc refuses reserved registers on
+    clobber lists).  That is sound only while the compiler itself never keeps a value in M0 across those statements:
+    assert on the generated gfx950 ISA that every instruction naming m0 is the idiom's own `s_mov_b32 m0, <sgpr>` and
+    that each one is followed by its s_nop + global_load_lds_dwordx4."""
+    lines = [ln.split(";")[0].strip() for ln in _device_asm(src).splitlines()]
+    lines = [ln for ln in lines if ln and not ln.startswith((".", "//")) and not ln.endswith(":")]
+    uses = [i for i, ln in enumerate(lines) if re.search(r"\bm0\b", ln)]
+    assert len(uses) > 50
+    for i in uses:
+        assert re.fullmatch(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi|ttmp\d+)", lines[i]), lines[i]
+        assert lines[i + 1] == "s_nop 0" and lines[i + 2].startswith("global_load_lds_dwordx4 "), lines[i:i + 3]
+    # and the kernels issue no other LDS-DMA form that would read M0 implicitly
+    assert sum(ln.startswith("global_load_lds") for ln in lines) == len(uses)
+
+
+def test_wide_gemm_index_model():
+    """scripts/lds_layout_check.py: LDS-DMA fill swizzle vs fragment-read swizzle, the 32x32 C map and the three store
+    epilogues of gemm256w.hip walked on the CPU; the k-loop fragment reads must be bank-conflict free."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_layout_check", os.path.join(ROOT, "scripts", "lds_layout_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    banks = mod.check_banks()
+    assert banks["fragment ds_read_b128"] == 1 and banks["epi32 ds_write_b128"] == 1 and banks["epi32 ds_read_b128"] == 1
+    assert max(banks.values()) <= 2
+    assert mod.walk_tile(K=192, seed=3)
