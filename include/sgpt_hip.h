@@ -285,6 +285,9 @@ sgpt_status sgpt_prof_read(sgpt_ctx* ctx, int64_t* launches, double* ms, double*
  * the results agree to fp32 rounding (the two instructions group the products of a k-step differently), so this is a
  * speed knob for in-process A/B measurements.  Returns the previous value. */
 int32_t sgpt_set_gemm_variant(int32_t variant);
+/* Start-up stagger of the persistent 256x256 GEMM workgroups in shader cycles per phase (4 phases per XCD; 0 = off; default
+ * from env SGPT_SKEW): de-synchronises the CUs' store epilogues.  A speed knob; results are unaffected. */
+int32_t sgpt_set_gemm_skew(int32_t cycles);
 
 /* Micro-benchmark of one GEMM launch configuration (library-owned pseudo-random operands, never
  * zeros): average milliseconds per launch over `iters` launches.  epi: 0 store, 1 bias+gelu,

@@ -17,6 +17,7 @@ ROUNDS = int(os.environ.get("ROUNDS", 5))
 DT = {"bf16": 1, "f16": 3}
 dts = [d for d in os.environ.get("DTYPES", "f16,bf16").split(",") if d]
 variants = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
+skews = [int(v) for v in os.environ.get("SKEWS", "0").split(",")]
 shapes = [("qk    store", 0, True, M, 1536, 768), ("v     vt   ", 4, True, M, 768, 768), ("oproj resid", 2, False, M, 768, 768),
           ("fc1   gelu ", 1, True, M, 3072, 768), ("fc2   resid", 2, False, M, 768, 3072), ("kloop none ", 5, True, M, 3072, 768)]
 if "--big" in sys.argv:
@@ -25,20 +26,23 @@ res = {}
 for rnd in range(ROUNDS):
     for dt in dts:
         for v in variants:
+          for sk in skews:
             ctx.lib.sgpt_set_gemm_variant(v)
+            ctx.lib.sgpt_set_gemm_skew(sk)
             for name, epi, o16, m, n, k in shapes:
                 ms = C.c_float(0)
                 ctx._chk(ctx.lib.sgpt_bench_gemm(ctx.handle, DT[dt], epi, DT[dt] if o16 else 0, m, n, k, 10, C.byref(ms)), "bench_gemm")
-                res.setdefault((dt, v, name), []).append(ms.value)
+                res.setdefault((dt, v, sk, name), []).append(ms.value)
 print(f"M = {M}, {ROUNDS} interleaved rounds x 10 launches; us per launch median (best) -> TFLOP/s at the median")
 for dt in dts:
     for v in variants:
+      for sk in skews:
         tot_ms = tot_fl = 0.0
         for name, epi, o16, m, n, k in shapes:
-            t = res[(dt, v, name)]
+            t = res[(dt, v, sk, name)]
             med, best = statistics.median(t), min(t)
             fl = 2.0 * m * n * k
             if epi != 5 and not name.startswith("1.3b"):
                 tot_ms += med; tot_fl += fl
-            print(f"{dt} mfma{'32' if v & 1 else '16'} {name} N={n} K={k}: {med * 1e3:8.1f} ({best * 1e3:8.1f}) us  {fl / med / 1e9:7.1f} TFLOP/s")
-        print(f"{dt} mfma{'32' if v & 1 else '16'} block total {tot_ms * 1e3:.1f} us -> {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
+            print(f"{dt} mfma{'32' if v & 1 else '16'} skew {sk:6d} {name} N={n} K={k}: {med * 1e3:8.1f} ({best * 1e3:8.1f}) us  {fl / med / 1e9:7.1f} TFLOP/s")
+        print(f"{dt} mfma{'32' if v & 1 else '16'} skew {sk:6d} block total {tot_ms * 1e3:.1f} us -> {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")

@@ -830,6 +830,7 @@ sgpt_status sgpt_topk(sgpt_ctx* c, const float* scores, int32_t nq, int64_t n, i
 
 
 int32_t sgpt_set_gemm_variant(int32_t v) { return set_gemm_variant(v); }
+int32_t sgpt_set_gemm_skew(int32_t cycles) { return set_gemm_skew(cycles); }
 
 sgpt_status sgpt_linear(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out_dtype, const void* A, const void* W,
                         const float* bias, const float* resid, void* out, int32_t M, int32_t N, int32_t K, void* stream) {

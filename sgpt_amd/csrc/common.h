@@ -192,6 +192,7 @@ struct GemmArgs {
 };
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
+int set_gemm_skew(int cycles);  // start-up stagger of the persistent 256^2 kernel (shader cycles per phase); returns the previous value
 int set_gemm_variant(int v);   // 0: 16x16x32-MFMA 256^2 kernel, 1: 32x32x16-MFMA one; returns the previous value
 // gemm256w.hip: the 256x256 LDS-DMA kernel on v_mfma_f32_32x32x16 (16-bit operands and outputs as gemm256d_kernel)
 void launch_gemm256w(int dtype, int epi, const GemmArgs& a, hipStream_t s, bool deep_a);

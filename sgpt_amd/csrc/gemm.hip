@@ -40,6 +40,7 @@ constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 #endif
 constexpr int RESID_PF = SGPT_RESID_PF;
 constexpr int CH = 8;  // 16-byte chunks per row per k-step
+int g_skew = getenv("SGPT_SKEW") ? atoi(getenv("SGPT_SKEW")) : 0;     // start-up stagger of gemm256d_kernel, shader cycles per phase
 #ifndef SGPT_GEMM_W_DEFAULT
 #define SGPT_GEMM_W_DEFAULT false
 #endif
@@ -360,6 +361,14 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
 #define STAMP(k)                                                                                   \
     if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 8) p.dbg[dbg_tile * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
 
+    // Start-up stagger (p.skew shader cycles per phase, 4 phases per XCD): every workgroup walks equally long tiles, so
+    // without it all 256 CUs reach their store / read-modify-write epilogues at the same moment and the chip alternates
+    // between an HBM-bound burst and an MFMA-bound phase.
+    if (p.skew > 0) {
+        const int phase = (blockIdx.x >> 3) & 3;
+        const long until = (long)__builtin_amdgcn_s_memtime() + (long)phase * p.skew;
+        while (phase && (long)__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
     {   // prologue: deep(0), shallow(0), deep(1) -- in the order the waits assume
         const bf16_t* dsrc = DEEP_A ? asrc : wsrc;
         const bf16_t* ssrc = DEEP_A ? wsrc : asrc;
@@ -479,6 +488,7 @@ void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
     const int gm = b.gm > 0 ? b.gm : 4;
     const int tiles_pad = ((AT + 7) / 8 + gm - 1) / gm * gm * 8 * BT;
     const int grid = tiles_pad < ncu ? tiles_pad : ncu;
+    b.skew = tiles_pad >= 4 * grid ? g_skew : 0;       // fewer than ~4 tiles per workgroup: the delay is not amortised
     if (deep_a) hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, true>), dim3(grid), dim3(512), 0, s, b);
     else hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, false>), dim3(grid), dim3(512), 0, s, b);
 }
@@ -546,6 +556,7 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int set_gemm_variant(int v) { const int old = gemm_variant(); g_variant = v; return old; }
+int set_gemm_skew(int cycles) { const int old = g_skew; g_skew = cycles; return old; }
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     if (dtype == DT_BF16) return launch_gemm16<bf16_t>(epi, out_dtype, a, s);
