@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPT_ABI_VERSION 3
+#define SGPT_ABI_VERSION 4
 
 typedef int sgpt_status;
 #define SGPT_OK 0
@@ -47,7 +47,7 @@ typedef int sgpt_status;
 typedef struct sgpt_ctx sgpt_ctx;
 typedef struct sgpt_model sgpt_model;
 
-enum { SGPT_F32 = 0, SGPT_BF16 = 1, SGPT_FP8W = 2, SGPT_F16 = 3 };   /* element types; FP8W: model compute_dtype only */
+enum { SGPT_F32 = 0, SGPT_BF16 = 1, SGPT_FP8W = 2, SGPT_F16 = 3, SGPT_FP8M = 4 };   /* element types; FP8W / FP8M: model compute_dtype only */
 enum { SGPT_ARCH_GPTNEO = 0, SGPT_ARCH_GPTJ = 1, SGPT_ARCH_BLOOM = 2 };
 enum { SGPT_POOL_WEIGHTEDMEAN = 0, SGPT_POOL_MEAN = 1, SGPT_POOL_LASTTOKEN = 2, SGPT_POOL_LEARNTMEAN = 3 };
 enum { SGPT_COS = 0, SGPT_DOT = 1 };
@@ -77,7 +77,16 @@ typedef struct {
                                 SGPT_FP8W: the six matmul weights per block are STORED as OCP e4m3fn with one
                                            power-of-two fp32 scale per output channel (the
                                            reference loads sgpt-bloom-7b1 8-bit through bitsandbytes) and
-                                           de-quantised -- exactly -- to bf16 per block; arithmetic as SGPT_BF16 */
+                                           de-quantised -- exactly -- to bf16 per block; arithmetic as SGPT_BF16;
+                                SGPT_FP8M: weights stored as SGPT_FP8W, and the two MLP projections of every block (2/3 of its
+                                           FLOPs) COMPUTED in fp8: v_mfma_f32_16x16x128_f8f6f4 on e4m3 x e4m3 operands at
+                                           twice the bf16 MFMA rate (BASELINE configs[4]).  The LayerNorm in front of the
+                                           MLP emits e4m3 codes with one power-of-two scale per row, the GELU output is
+                                           re-quantised under one calibrated power-of-two scale per block
+                                           (sgpt_model_calibrate_begin / _end), scales are applied to the fp32 accumulators;
+                                           attention projections stay bf16.  Shapes that do not fit the 256x256x256 fp8 tile
+                                           run the SGPT_FP8W arithmetic.  Cannot meet the 1e-3 bar (3 mantissa bits): the
+                                           tests report max |dcos| and top-10 overlap against the fp32 oracle instead */
     const uint8_t* layer_is_local;  /* host, [n_layers]: 1 = sliding-window layer (HF:gpt_neo:66) */
     int32_t rotary_dim;      /* GPT-J: leading dims of every head that get rotary position embedding (64) */
 } sgpt_model_desc;
@@ -111,6 +120,15 @@ const char* sgpt_last_error(const sgpt_ctx* ctx);
 sgpt_status sgpt_model_load(sgpt_ctx* ctx, const sgpt_model_desc* desc,
                             const sgpt_tensor_view* tensors, size_t n_tensors, sgpt_model** out);
 void sgpt_model_free(sgpt_model* model);
+
+/* SGPT_FP8M activation-scale calibration.  Between _begin and _end every sgpt_encode on the model runs the SGPT_FP8W
+ * arithmetic and records max |gelu output| per block; _end turns the maxima into per-block power-of-two scales
+ * (smallest 2^k with margin * max / 2^k <= 448; margin >= 1, default 2) and returns them (host float[n_layers], may be
+ * NULL).  sgpt_model_set_act_scales installs scales computed elsewhere (powers of two).  A later batch whose GELU
+ * output saturates the e4m3 range raises bit 1 of the flag read by sgpt_range_check. */
+sgpt_status sgpt_model_calibrate_begin(sgpt_model* model);
+sgpt_status sgpt_model_calibrate_end(sgpt_model* model, float margin, float* scales_out);
+sgpt_status sgpt_model_set_act_scales(sgpt_model* model, const float* scales, int32_t n_layers);
 
 /* -- a2+a3+a4: forward + pool --------------------------------------------------------- */
 /* Replaces, in ONE call and with no hidden-state D2H:
@@ -191,7 +209,7 @@ sgpt_status sgpt_f32_to_bf16(sgpt_ctx* ctx, const float* in, int64_t numel, void
 
 /* SGPT_F16 range guard: *flagged = 1 when, since the last reset, a kernel rounded an activation of magnitude >= 32768
  * (or a non-finite one) to f16 -- the results of the affected calls are not trustworthy and the model should be
- * re-loaded with SGPT_BF16.  Synchronises `stream` (one 4-byte read-back); the Python host calls it once per
+ * re-loaded with SGPT_BF16 (bit 0 of *flagged) -- or an SGPT_FP8M GELU output saturated its e4m3 codes (bit 1: re-calibrate).  Synchronises `stream` (one 4-byte read-back); the Python host calls it once per
  * encode_ids() and raises.  The reference's fp32 CPU path has no such failure mode. */
 sgpt_status sgpt_range_check(sgpt_ctx* ctx, int32_t* flagged, int32_t reset, void* stream);
 
@@ -270,6 +288,18 @@ sgpt_status sgpt_topk(sgpt_ctx* ctx, const float* scores, int32_t nq, int64_t n,
  * feed every output element the same MFMA sequence, so the result does not depend on which one ran. */
 sgpt_status sgpt_linear(sgpt_ctx* ctx, int32_t dtype, int32_t epi, int32_t out_dtype, const void* A, const void* W,
                         const float* bias, const float* resid, void* out, int32_t M, int32_t N, int32_t K, void* stream);
+
+/* The fp8-MFMA building blocks of SGPT_FP8M, stand-alone (kernel-level tests, custom blocks).
+ * sgpt_layernorm_fp8: nn.LayerNorm(x)[T,d] -> e4m3fn codes + one power-of-two scale per row (true value = code * scale).
+ * sgpt_linear_fp8:    acc = (A8 . W8^T)[m][n] * a_scale[m] * a_scalar * w_scale[n]   (A8 [M,K], W8 [N,K] e4m3fn codes, fp32
+ *                     accumulate; a_scale NULL = 1; M, N, K multiples of 256)
+ *     epi 1: out u8[M,N] = e4m3( gelu_new(acc + bias) / out_scale ), saturating at +-448
+ *     epi 2: out fp32[M,N] = resid + acc + bias (out may alias resid) */
+sgpt_status sgpt_layernorm_fp8(sgpt_ctx* ctx, const float* x, const float* gamma, const float* beta, int32_t T, int32_t d,
+                               float eps, uint8_t* codes, float* row_scale, void* stream);
+sgpt_status sgpt_linear_fp8(sgpt_ctx* ctx, int32_t epi, const uint8_t* A, const float* a_scale, float a_scalar,
+                            const uint8_t* W, const float* w_scale, const float* bias, const float* resid, void* out,
+                            float out_scale, int32_t M, int32_t N, int32_t K, void* stream);
 
 /* -- measurement ----------------------------------------------------------------------- */
 /* bench.py's live roofline: when enabled, every GEMM launched by sgpt_encode /

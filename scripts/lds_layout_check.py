@@ -63,6 +63,29 @@ def check_banks():
     return res
 
 
+def check_q8():
+    """gemm256q.hip (fp8, 32-byte fragments = chunks 2g and 2g + 1 of row fr): the rotl3(row & 7) swizzle is conflict
+    free for both ds_read_b128 of a fragment; the chunk ^ (row & 7) swizzle of the 16-bit kernels is not."""
+    def rotl3(x):
+        return ((x << 1) & 7) | (x >> 2)
+    out = {}
+    for name, f in (("rotl3(row&7)", rotl3), ("row&7", lambda x: x)):
+        worst = 1
+        for blk, half in itertools.product(range(8), range(2)):
+            def addr(l, blk=blk, half=half):
+                fr, g = l & 15, l >> 4
+                row = blk * 16 + fr
+                return (row * 8 + ((2 * g + half) ^ f(row & 7))) * 16
+            worst = max(worst, conflicts(addr, 16, READ_B128_GROUPS, 64))
+        out[name] = worst
+    # functional: DMA fill (lane l -> row 8q + (l >> 3), slot l & 7 <- global chunk (l & 7) ^ rotl3(l >> 3)) vs fragment read
+    for q, l in itertools.product(range(4), range(64)):
+        row, slot = 8 * q + (l >> 3), l & 7
+        gchunk = slot ^ rotl3(l >> 3)
+        assert gchunk ^ rotl3(row & 7) == slot
+    return out
+
+
 def walk_tile(K=128, seed=0):
     rng = np.random.default_rng(seed)
     M = N = 256
@@ -173,4 +196,6 @@ def walk_tile(K=128, seed=0):
 if __name__ == "__main__":
     for k, v in check_banks().items():
         print(f"{k:26s} worst lanes-per-bank in a service group: {v}")
+    for k, v in check_q8().items():
+        print(f"fp8 fragment reads, swizzle {k:13s} worst lanes-per-bank: {v}")
     print("tile walk (fill swizzle / fragment reads / C maps / three epilogues):", "ok" if walk_tile() else "FAILED")

@@ -7,8 +7,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGPT_HIP_LIB") or os.path.join(HERE, "lib", "libsgpt_hip.so")   # env: A/B builds of the same ABI
 
-SGPT_F32, SGPT_BF16, SGPT_FP8W, SGPT_F16 = 0, 1, 2, 3
-SGPT_ABI_VERSION = 3
+SGPT_F32, SGPT_BF16, SGPT_FP8W, SGPT_F16, SGPT_FP8M = 0, 1, 2, 3, 4
+SGPT_ABI_VERSION = 4
 SGPT_ERR_RANGE = -5
 SGPT_ARCH_GPTNEO, SGPT_ARCH_GPTJ, SGPT_ARCH_BLOOM = 0, 1, 2
 POOL_MODES = {"weightedmean": 0, "mean": 1, "lasttoken": 2, "learntmean": 3}
@@ -68,6 +68,13 @@ SIGNATURES = {
                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgpt_linear": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sgpt_model_calibrate_begin": (C.c_int, [C.c_void_p]),
+    "sgpt_model_calibrate_end": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
+    "sgpt_model_set_act_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "sgpt_layernorm_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "sgpt_linear_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sgpt_set_gemm_variant": (C.c_int32, [C.c_int32]),
     "sgpt_set_gemm_skew": (C.c_int32, [C.c_int32]),
     "sgpt_bench_gemm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -53,7 +53,12 @@ struct sgpt_model {
     float* zero_bias = nullptr;                      // [max(d, ffn)] zeros: bias-free projections (GPT-J out_proj)
     float* pool_w = nullptr; int pool_w_n = 0;       // learntmean position weights (sgpt_model_set_pool_weights)
     float *lm_w = nullptr, *lm_b = nullptr;           // LM head [vocab, d] (+bias): tied to the embedding unless "lm_head.*" was given
-    void* dq[4] = {nullptr, nullptr, nullptr, nullptr};   // SGPT_FP8W: bf16 scratch for the current block's qkv / o / fc / proj
+    void* dq[4] = {nullptr, nullptr, nullptr, nullptr};   // SGPT_FP8W / FP8M: bf16 scratch for the current block's qkv / o / fc / proj
+    // SGPT_FP8M (fp8 MFMA on the MLP projections): per-block power-of-two scale of the GELU output's e4m3 codes, set by
+    // calibration; h_amax = device float bits [n_layers] collected while `calibrating`
+    std::vector<float> act_scale;
+    unsigned* h_amax = nullptr;
+    bool calibrating = false;
     std::vector<void*> allocs;
 };
 
@@ -207,7 +212,7 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     if (dh > 256 || dh % 4) return fail(c, SGPT_ERR_INVALID, "head_dim must be <= 256 and a multiple of 4");
     if (dm > 4096) return fail(c, SGPT_ERR_INVALID, "d_model > 4096 not supported");
     if (d->compute_dtype != SGPT_BF16 && d->compute_dtype != SGPT_F32 && d->compute_dtype != SGPT_FP8W &&
-        d->compute_dtype != SGPT_F16)
+        d->compute_dtype != SGPT_F16 && d->compute_dtype != SGPT_FP8M)
         return fail(c, SGPT_ERR_INVALID, "bad compute_dtype");
     if (gptj && (d->rotary_dim <= 0 || d->rotary_dim > dh || d->rotary_dim % 2))
         return fail(c, SGPT_ERR_INVALID, "GPT-J needs an even rotary_dim in (0, head_dim]");
@@ -218,7 +223,7 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     m->ctx = c;
     m->d = *d;
     m->d.layer_is_local = nullptr;
-    const bool fp8 = d->compute_dtype == SGPT_FP8W;
+    const bool fp8 = d->compute_dtype == SGPT_FP8W || d->compute_dtype == SGPT_FP8M;
     const bool f16 = d->compute_dtype == SGPT_F16;
     const bool bf = d->compute_dtype == SGPT_BF16 || f16;          // 16-bit packed weights
     const size_t esz = fp8 ? 1 : (bf ? 2 : 4);
@@ -349,6 +354,11 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         m->dq[0] = dalloc((size_t)3 * dm * dm * 2); m->dq[1] = dalloc((size_t)dm * dm * 2);
         m->dq[2] = dalloc((size_t)ffn * dm * 2); m->dq[3] = dalloc((size_t)dm * ffn * 2);
     }
+    if (d->compute_dtype == SGPT_FP8M && st == SGPT_OK) {
+        m->act_scale.assign(d->n_layers, 0.0f);               // 0 = not calibrated
+        m->h_amax = (unsigned*)dalloc((size_t)d->n_layers * 4);
+        if (m->h_amax && hipMemsetAsync(m->h_amax, 0, (size_t)d->n_layers * 4, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memset");
+    }
     if (st == SGPT_OK && hipDeviceSynchronize() != hipSuccess) st = fail(c, SGPT_ERR_HIP, "sync after weight pack");
     if (f16) {
         // f16 has 5 exponent bits: refuse a checkpoint whose weights, or whose LayerNorm output bound
@@ -402,7 +412,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     HIPC(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const int dm = m->d.d_model, ffn = m->d.d_ffn, H = m->d.n_heads, dh = dm / H;
-    const bool fp8 = m->d.compute_dtype == SGPT_FP8W;
+    const bool fp8m = m->d.compute_dtype == SGPT_FP8M;
+    const bool fp8 = m->d.compute_dtype == SGPT_FP8W || fp8m;
     const bool bf = m->d.compute_dtype != SGPT_F32;                 // 16-bit MFMA operands (bf16 or f16)
     const int dt = !bf ? SGPT_F32 : (m->d.compute_dtype == SGPT_F16 ? SGPT_F16 : SGPT_BF16);
     const size_t esz = bf ? 2 : 4;
@@ -416,7 +427,19 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     const size_t o_a = carve((size_t)T * dm * esz);                      // LN output (GPT-Neo: also attention ctx)
     const size_t o_c = gptj ? carve((size_t)T * dm * esz) : o_a;         // GPT-J: ctx separate (ln_1 output feeds the MLP too)
     const size_t o_qkv = carve(((size_t)T + SLACK) * 3 * dm * esz);      // bf16: [T][2d] qk + V^T [d][T]; fp32: [T][3d]
-    const size_t o_h = carve((size_t)T * ffn * esz);                     // MLP hidden
+    const size_t o_h = carve((size_t)T * ffn * esz);                     // MLP hidden (FP8M: e4m3 codes in the same region)
+    // FP8M: fp8 MFMA on the MLP projections when the shapes fit the 256x256x128 kernel and the GELU-output scales are
+    // calibrated; otherwise (and while calibrating) the block runs the SGPT_FP8W arithmetic (weights de-quantised to bf16)
+    bool mlp8 = fp8m && !m->calibrating && gemm_fp8_shape_ok(T, ffn, dm) && gemm_fp8_shape_ok(T, dm, ffn);
+    if (fp8m && !m->calibrating)
+        for (int li = 0; li < n_layers_run; ++li)
+            if (!(m->act_scale[li] > 0.f)) {
+                if (gemm_fp8_shape_ok(T, ffn, dm) && gemm_fp8_shape_ok(T, dm, ffn))
+                    return fail(c, SGPT_ERR_INVALID, "SGPT_FP8M: activation scales are not set (sgpt_model_calibrate_begin / _end, or sgpt_model_set_act_scales)");
+                mlp8 = false;
+            }
+    const size_t o_a8 = mlp8 ? carve((size_t)T * dm) : 0;                // FP8M: LayerNorm output as e4m3 codes
+    const size_t o_sa = mlp8 ? carve((size_t)T * 4) : 0;                 //       + one scale per row
     const size_t o_lp = (layer_mean && !layer_out) ? carve((size_t)(m->d.n_layers + 1) * B * dm * 4) : 0;
     sgpt_status st = ensure(c, &c->ws, &c->ws_bytes, off);
     if (st != SGPT_OK) return st;
@@ -447,14 +470,21 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         if (layer_out)   // hidden_states[li] = input of block li (HF:gpt_neo:475-478)
             launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, 0, pool_mode,
                             normalize, m->pool_w, m->pool_w_n, layer_out + (size_t)li * B * dm, s);
+        const void* w_fc8 = l.w_fc; const void* w_proj8 = l.w_proj;       // the e4m3 codes (FP8M feeds them to the MFMA directly)
         if (fp8) {  // this block's weights: e4m3fn codes * 2^k -> bf16, exact; <1 % of the block's time at T >= 16k
             launch_fp8_dequant_rows(l.w_qkv, l.s_qkv, (long)3 * dm, dm, m->dq[0], SGPT_BF16, s);
             launch_fp8_dequant_rows(l.w_o, l.s_o, dm, dm, m->dq[1], SGPT_BF16, s);
-            launch_fp8_dequant_rows(l.w_fc, l.s_fc, ffn, dm, m->dq[2], SGPT_BF16, s);
-            launch_fp8_dequant_rows(l.w_proj, l.s_proj, dm, ffn, m->dq[3], SGPT_BF16, s);
-            l.w_qkv = m->dq[0]; l.w_o = m->dq[1]; l.w_fc = m->dq[2]; l.w_proj = m->dq[3];
+            l.w_qkv = m->dq[0]; l.w_o = m->dq[1];
+            if (!mlp8) {
+                launch_fp8_dequant_rows(l.w_fc, l.s_fc, ffn, dm, m->dq[2], SGPT_BF16, s);
+                launch_fp8_dequant_rows(l.w_proj, l.s_proj, dm, ffn, m->dq[3], SGPT_BF16, s);
+                l.w_fc = m->dq[2]; l.w_proj = m->dq[3];
+            }
         }
-        launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
+        if (mlp8 && gptj)   // GPT-J: ln_1 feeds the attention projections (16 bit) AND the MLP (fp8 codes + row scales)
+            launch_layernorm_q8(x, l.ln1_g, l.ln1_b, base + o_a8, (float*)(base + o_sa), a, dt, T, dm, m->d.ln_eps, s);
+        else
+            launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
         GemmArgs g{};
         g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
         g.range_flag = dt == SGPT_F16 ? c->range_flag : nullptr;
@@ -483,12 +513,28 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         g.A = ctx; g.W = l.w_o; g.N = dm; g.K = dm; g.ldw = dm; g.out = x; g.ldo = dm; g.bias = l.b_o; g.resid = x;
         gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
         // GPT-Neo: x += MLP(LN2(x));  GPT-J (parallel block, HF:gptj:400-411): x += MLP(LN1(x_old)), `a` still holds it
-        if (!gptj) launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s);
-        g.A = a; g.lda = dm; g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
-        gemm(c, dt, EPI_BIAS_GELU, dt, g, s);
-        g.A = h; g.lda = ffn; g.W = l.w_proj; g.N = dm; g.K = ffn; g.ldw = ffn; g.out = x; g.ldo = dm;
-        g.bias = l.b_proj; g.resid = x;
-        gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
+        if (mlp8) {
+            // fp8 MFMA: a8 = e4m3(LN(x) / sa[row]);  h8 = e4m3(gelu(a8 . W1_8^T * sa * s1 + b1) / s_h);  x += h8 . W2_8^T * s_h * s2 + b2
+            if (!gptj) launch_layernorm_q8(x, l.ln2_g, l.ln2_b, base + o_a8, (float*)(base + o_sa), nullptr, dt, T, dm, m->d.ln_eps, s);
+            GemmArgs q{};
+            q.M = T; q.m_valid = T; q.range_flag = c->range_flag;
+            q.A = base + o_a8; q.lda = dm; q.a_scale = (const float*)(base + o_sa); q.a_scalar = 1.0f;
+            q.W = w_fc8; q.ldw = dm; q.w_scale = l.s_fc; q.N = ffn; q.K = dm; q.bias = l.b_fc;
+            q.out = h; q.ldo = ffn; q.out_scale = m->act_scale[li];
+            { Prof pr(c, s, 2.0 * T * (double)ffn * dm); launch_gemm_fp8(EPI_BIAS_GELU, q, s); }
+            q.A = h; q.lda = ffn; q.a_scale = nullptr; q.a_scalar = m->act_scale[li];
+            q.W = w_proj8; q.ldw = ffn; q.w_scale = l.s_proj; q.N = dm; q.K = ffn; q.bias = l.b_proj;
+            q.resid = x; q.out = x; q.ldo = dm;
+            { Prof pr(c, s, 2.0 * T * (double)ffn * dm); launch_gemm_fp8(EPI_BIAS_RESID, q, s); }
+        } else {
+            if (!gptj) launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s);
+            g.A = a; g.lda = dm; g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
+            gemm(c, dt, EPI_BIAS_GELU, dt, g, s);
+            if (m->calibrating) launch_absmax16(h, (long)T * ffn, dt, m->h_amax + li, s);   // FP8M calibration: range of this block's GELU output
+            g.A = h; g.lda = ffn; g.W = l.w_proj; g.N = dm; g.K = ffn; g.ldw = ffn; g.out = x; g.ldo = dm;
+            g.bias = l.b_proj; g.resid = x;
+            gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
+        }
     }
     if (hidden_out) {
         if (apply_final_ln) launch_layernorm(x, m->lnf_g, m->lnf_b, hidden_out, SGPT_F32, T, dm, m->d.ln_eps, s);
@@ -539,6 +585,51 @@ sgpt_status sgpt_model_set_pool_weights(sgpt_model* m, const float* w, int32_t n
     }
     m->pool_w_n = n;
     HIPC(c, hipMemcpy(m->pool_w, w, (size_t)n * 4, hipMemcpyDeviceToDevice));
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_model_calibrate_begin(sgpt_model* m) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (m->d.compute_dtype != SGPT_FP8M) return fail(c, SGPT_ERR_INVALID, "calibration applies to SGPT_FP8M models");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());
+    HIPC(c, hipMemset(m->h_amax, 0, (size_t)m->d.n_layers * 4));
+    m->calibrating = true;
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_model_calibrate_end(sgpt_model* m, float margin, float* scales_out) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (m->d.compute_dtype != SGPT_FP8M || !m->calibrating) return fail(c, SGPT_ERR_INVALID, "sgpt_model_calibrate_end without _begin");
+    m->calibrating = false;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());
+    std::vector<float> amax(m->d.n_layers);
+    HIPC(c, hipMemcpy(amax.data(), m->h_amax, (size_t)m->d.n_layers * 4, hipMemcpyDeviceToHost));
+    if (!(margin >= 1.0f)) margin = 2.0f;
+    for (int i = 0; i < m->d.n_layers; ++i) {
+        // smallest power of two with margin * amax / scale <= 448 (head-room: later batches may exceed the sample's range;
+        // a saturated code raises bit 1 of the range flag)
+        const float need = amax[i] * margin / 448.0f;
+        float sc = 1.0f;
+        if (need > 0.f && std::isfinite(need)) sc = std::exp2(std::ceil(std::log2(need)));
+        m->act_scale[i] = sc;
+        if (scales_out) scales_out[i] = sc;
+    }
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_model_set_act_scales(sgpt_model* m, const float* scales, int32_t n) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (m->d.compute_dtype != SGPT_FP8M || !scales || n != m->d.n_layers) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_act_scales: bad arguments");
+    for (int i = 0; i < n; ++i) {
+        int e = 0;
+        if (!(scales[i] > 0.f) || std::frexp(scales[i], &e) != 0.5f) return fail(c, SGPT_ERR_INVALID, "activation scales must be powers of two");
+        m->act_scale[i] = scales[i];
+    }
     return SGPT_OK;
 }
 
@@ -829,6 +920,34 @@ sgpt_status sgpt_topk(sgpt_ctx* c, const float* scores, int32_t nq, int64_t n, i
 }
 
 
+sgpt_status sgpt_layernorm_fp8(sgpt_ctx* c, const float* x, const float* gamma, const float* beta, int32_t T, int32_t d, float eps,
+                               uint8_t* codes, float* row_scale, void* stream) {
+    if (!c || !x || !gamma || !beta || !codes || !row_scale || T <= 0 || d <= 0 || d % 4 || d > 4096)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_layernorm_fp8: bad arguments (d % 4 == 0, d <= 4096)");
+    HIPC(c, hipSetDevice(c->device));
+    launch_layernorm_q8(x, gamma, beta, codes, row_scale, nullptr, SGPT_BF16, T, d, eps, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_linear_fp8(sgpt_ctx* c, int32_t epi, const uint8_t* A, const float* a_scale, float a_scalar, const uint8_t* W,
+                            const float* w_scale, const float* bias, const float* resid, void* out, float out_scale,
+                            int32_t M, int32_t N, int32_t K, void* stream) {
+    if (!c || !A || !W || !w_scale || !bias || !out || !(a_scalar > 0.f)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: bad arguments");
+    if (!gemm_fp8_shape_ok(M, N, K)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: M, N, K must be multiples of 256");
+    if (epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: epi 1 (bias+gelu -> fp8) or 2 (bias+residual -> fp32)");
+    if (epi == EPI_BIAS_RESID && !resid) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: residual required");
+    if (epi == EPI_BIAS_GELU && !(out_scale > 0.f)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: out_scale required");
+    HIPC(c, hipSetDevice(c->device));
+    GemmArgs q{};
+    q.A = A; q.lda = K; q.W = W; q.ldw = K; q.M = M; q.m_valid = M; q.N = N; q.K = K; q.out = out; q.ldo = N;
+    q.bias = bias; q.resid = resid; q.a_scale = a_scale; q.a_scalar = a_scalar; q.w_scale = w_scale; q.out_scale = out_scale;
+    q.range_flag = c->range_flag;
+    { Prof pr(c, (hipStream_t)stream, 2.0 * M * (double)N * K); launch_gemm_fp8(epi, q, (hipStream_t)stream); }
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
 int32_t sgpt_set_gemm_variant(int32_t v) { return set_gemm_variant(v); }
 int32_t sgpt_set_gemm_skew(int32_t cycles) { return set_gemm_skew(cycles); }
 
@@ -860,6 +979,35 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
                             int32_t iters, float* ms_out) {
     if (!c || !ms_out || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_bench_gemm: bad arguments");
     HIPC(c, hipSetDevice(c->device));
+    if (dtype == SGPT_FP8M) {   // fp8 MFMA kernel: random fp32 operands quantised row-wise to e4m3 codes + power-of-two scales
+        if (!gemm_fp8_shape_ok(M, N, K) || (epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID && epi != EPI_NONE))
+            return fail(c, SGPT_ERR_INVALID, "sgpt_bench_gemm(fp8): shapes % 256, epi 1 | 2 | 5");
+        float *Af = nullptr, *Wf = nullptr, *sa = nullptr, *sw = nullptr, *bias = nullptr; uint8_t *A8 = nullptr, *W8 = nullptr; void* O = nullptr;
+        HIPC(c, hipMalloc((void**)&Af, (size_t)M * K * 4)); HIPC(c, hipMalloc((void**)&Wf, (size_t)N * K * 4));
+        HIPC(c, hipMalloc((void**)&A8, (size_t)M * K)); HIPC(c, hipMalloc((void**)&W8, (size_t)N * K));
+        HIPC(c, hipMalloc((void**)&sa, (size_t)M * 4)); HIPC(c, hipMalloc((void**)&sw, (size_t)N * 4));
+        HIPC(c, hipMalloc((void**)&bias, (size_t)N * 4)); HIPC(c, hipMalloc(&O, (size_t)M * N * 4));
+        launch_fill_rand(Af, (long)M * K, 0, 1u, 1.0f, 0); launch_fill_rand(Wf, (long)N * K, 0, 2u, 0.05f, 0);
+        launch_fill_rand(bias, N, 0, 3u, 0.1f, 0); launch_fill_rand((float*)O, (long)M * N, 0, 4u, 1.0f, 0);
+        launch_fp8_quant_rows(Af, M, K, A8, sa, 0); launch_fp8_quant_rows(Wf, N, K, W8, sw, 0);
+        GemmArgs q{};
+        q.A = A8; q.lda = K; q.W = W8; q.ldw = K; q.M = M; q.m_valid = M; q.N = N; q.K = K; q.out = O; q.ldo = N; q.bias = bias;
+        q.resid = (const float*)O; q.a_scale = sa; q.a_scalar = 1.0f; q.w_scale = sw; q.out_scale = 0.0625f;
+        hipEvent_t e0, e1;
+        HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) launch_gemm_fp8(epi, q, 0);
+        HIPC(c, hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) launch_gemm_fp8(epi, q, 0);
+        HIPC(c, hipEventRecord(e1, 0));
+        HIPC(c, hipEventSynchronize(e1));
+        float ms = 0;
+        HIPC(c, hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        hipFree(Af); hipFree(Wf); hipFree(A8); hipFree(W8); hipFree(sa); hipFree(sw); hipFree(bias); hipFree(O);
+        HIPC(c, hipGetLastError());
+        return SGPT_OK;
+    }
     const size_t esz = dtype == SGPT_F32 ? 4 : 2, osz = out_dtype == SGPT_F32 ? 4 : 2;
     void *A = nullptr, *W = nullptr, *O = nullptr; float* bias = nullptr;
     HIPC(c, hipMalloc(&A, (size_t)M * K * esz));

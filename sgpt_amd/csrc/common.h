@@ -189,11 +189,19 @@ struct GemmArgs {
     long idx_base;      // global index of W row 0
     long long* dbg;     // optional s_memtime stamps of workgroup 0 / wave 0 (micro-benchmark diagnostics)
     int* range_flag;    // f16 outputs: device flag raised when a stored magnitude reaches RANGE_LIMIT (or null)
+    // fp8 operands (gemm256q.hip): C = (A8 . W8^T) * a_scale[m] * a_scalar * w_scale[n]
+    const float* a_scale;   // [M] per-row scale of the A codes, or null (1)
+    const float* w_scale;   // [N] per-output-channel scale of the W codes
+    float a_scalar;         // per-tensor scale of the A codes (1 when a_scale is used)
+    float out_scale;        // EPI_BIAS_GELU: the fp8 output holds gelu(...) / out_scale
 };
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
 int set_gemm_skew(int cycles);  // start-up stagger of the persistent 256^2 kernel (shader cycles per phase); returns the previous value
 int set_gemm_variant(int v);   // 0: 16x16x32-MFMA 256^2 kernel, 1: 32x32x16-MFMA one; returns the previous value
+// gemm256q.hip: fp8 (e4m3fn) x fp8 on v_mfma_f32_16x16x128_f8f6f4; epi = EPI_BIAS_GELU (fp8 out) | EPI_BIAS_RESID (fp32) | EPI_NONE
+bool gemm_fp8_shape_ok(int M, int N, int K);
+void launch_gemm_fp8(int epi, const GemmArgs& a, hipStream_t s);
 // gemm256w.hip: the 256x256 LDS-DMA kernel on v_mfma_f32_32x32x16 (16-bit operands and outputs as gemm256d_kernel)
 void launch_gemm256w(int dtype, int epi, const GemmArgs& a, hipStream_t s, bool deep_a);
 
@@ -218,6 +226,10 @@ void launch_embed(const int* ids, const int* pos, const float* wte, const float*
                   int max_pos, hipStream_t s);
 void launch_layernorm(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
                       float eps, hipStream_t s);
+// LayerNorm -> e4m3fn codes q[T,d] + one power-of-two scale per row (+ optionally the same rows in a 16-bit format)
+void launch_layernorm_q8(const float* x, const float* g, const float* b, void* q, float* scale, void* out16, int out16_dtype,
+                         int T, int d, float eps, hipStream_t s);
+void launch_absmax16(const void* in, long numel, int dtype, unsigned* out_bits, hipStream_t s);   // max|x| of a bf16 / f16 array
 void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,
                      const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize,
                      const float* pos_weights, int pos_weights_n, float* out, hipStream_t s);

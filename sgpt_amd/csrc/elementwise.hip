@@ -106,6 +106,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// LayerNorm whose output feeds an fp8-MFMA GEMM (gemm256q.hip): the normalised row is quantised to OCP e4m3fn codes under
+// ONE power-of-two scale per row -- the smallest 2^k with max|row| / 2^k <= 448 (the rule of fp8_quant_rows_kernel) --
+// which factors out of the GEMM's k-sum and is applied to its accumulators.  Optionally the same row is also written in
+// a 16-bit format (GPT-J: ln_1 feeds the attention projections and the MLP).
+template <int NV, typename H16>
+__global__ __launch_bounds__(256) void layernorm_q8_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           const float* __restrict__ b, uint8_t* __restrict__ q,
+                                                           float* __restrict__ scale, uint16_t* __restrict__ out16, int T,
+                                                           int d, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const int lane = threadIdx.x & 63;
+    RowLN<NV> r;
+    r.load(x + (long)row * d, d, lane);
+    r.normalize(g, b, d, eps, lane);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(r.v[i].x), fabsf(r.v[i].y)), fmaxf(fabsf(r.v[i].z), fabsf(r.v[i].w))));
+    }
+    amax = wave_max(amax);
+    float sc = 1.0f;
+    if (amax > 0.f && amax < 3.0e38f) {
+        const uint32_t u = __float_as_uint(amax);
+        const int e = (int)((u >> 23) & 0xffu) - 127;
+        int k = e - ((u & 0x7fffffu) > 0x600000u ? 7 : 8);               // amax / 2^k in (224, 448]
+        k = k < -126 ? -126 : (k > 127 ? 127 : k);
+        sc = __uint_as_float((uint32_t)(k + 127) << 23);
+    }
+    if (lane == 0) scale[row] = sc;
+    const float inv = 1.0f / sc;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(r.v[i].x * inv, r.v[i].y * inv, 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(r.v[i].z * inv, r.v[i].w * inv, w, true);
+            *reinterpret_cast<uint32_t*>(q + (long)row * d + c) = (uint32_t)w;
+            if (out16 != nullptr)
+                *reinterpret_cast<uint2*>(out16 + (long)row * d + c) =
+                    make_uint2(Half<H16>::pack2(r.v[i].x, r.v[i].y), Half<H16>::pack2(r.v[i].z, r.v[i].w));
+        }
+    }
+}
+
 // ---- ln_f + pooling + optional L2 normalise, one workgroup (4 waves) per sequence ----
 // weightedmean: sum_t (P+t+1) * h_t / clamp(sum_t (P+t+1), 1e-9), P = pad_left
 //   (Pooling.py:99-125; beir_dense_retriever.py:258-270; weights follow the PADDED index)
@@ -432,6 +478,19 @@ __global__ __launch_bounds__(256) void fill_rand_kernel(T* __restrict__ p, long 
     }
 }
 
+// max |x| of a 16-bit array (fp8 activation-scale calibration: the range of a block's GELU output)
+template <typename H>
+__global__ __launch_bounds__(256) void absmax16_kernel(const uint32_t* __restrict__ in, long n2, unsigned* __restrict__ out_bits) {
+    const long stride = (long)gridDim.x * 256;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+        const uint32_t u = in[i];
+        m = fmaxf(m, fmaxf(fabsf(Half<H>::lo(u)), fabsf(Half<H>::hi(u))));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __float_as_uint(m));
+}
+
 inline int cap_grid(long blocks) { return (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks)); }
 
 }  // namespace
@@ -458,6 +517,28 @@ void launch_layernorm(const float* x, const float* g, const float* b, void* out,
     else if (nv <= 4) { LN_CASE(4) } else if (nv <= 8) { LN_CASE(8) } else if (nv <= 10) { LN_CASE(10) }
     else { LN_CASE(16) }
 #undef LN_CASE
+}
+
+void launch_layernorm_q8(const float* x, const float* g, const float* b, void* q, float* scale, void* out16, int out16_dtype,
+                         int T, int d, float eps, hipStream_t s) {
+#define LQ_CASE(NV)                                                                                                  \
+    if (out16_dtype == DT_F16)                                                                                       \
+        hipLaunchKernelGGL((layernorm_q8_kernel<NV, f16_t>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b, (uint8_t*)q, scale, \
+                           (uint16_t*)out16, T, d, eps);                                                             \
+    else                                                                                                             \
+        hipLaunchKernelGGL((layernorm_q8_kernel<NV, bf16_t>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b, (uint8_t*)q, scale, \
+                           (uint16_t*)out16, T, d, eps);
+    const int nv = (d + 255) / 256;
+    if (nv <= 1) { LQ_CASE(1) } else if (nv <= 2) { LQ_CASE(2) } else if (nv <= 3) { LQ_CASE(3) }
+    else if (nv <= 4) { LQ_CASE(4) } else if (nv <= 8) { LQ_CASE(8) } else if (nv <= 10) { LQ_CASE(10) }
+    else { LQ_CASE(16) }
+#undef LQ_CASE
+}
+
+void launch_absmax16(const void* in, long numel, int dtype, unsigned* out_bits, hipStream_t s) {
+    const int grid = cap_grid((numel / 2 + 255) / 256);
+    if (dtype == DT_F16) hipLaunchKernelGGL(absmax16_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const uint32_t*)in, numel / 2, out_bits);
+    else hipLaunchKernelGGL(absmax16_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const uint32_t*)in, numel / 2, out_bits);
 }
 
 void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,

@@ -394,10 +394,13 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         for (int j = 0; j < 4; ++j) wf[0][j] = ld_w(lw, 0, j);
         af[0][0] = ld_a(la, 0, 0); af[0][1] = ld_a(la, 0, 1);
     }
+    // The tile after this one is looked up one tile ahead, inside the k-loop (its integer divisions run in the shadow of
+    // k-step 0's MFMAs instead of sitting between two tiles: ~1 k cycles per tile on the critical path otherwise).
+    int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
+    while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
     while (true) {
-        int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
-        while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
         const bool has_next = ntile < tiles_total;
+        int n2tile = ntile, n2m0 = 0, n2n0 = 0;
         const bf16_t* nasrc = has_next ? Ag + (long)nm0 * p.lda : asrc;   // past the end: harmless re-fetch
         const bf16_t* nwsrc = has_next ? Wg + (long)nn0 * p.ldw : wsrc;
         const bf16_t* d_cur = DEEP_A ? asrc : wsrc, *d_nxt = DEEP_A ? nasrc : nwsrc;
@@ -450,6 +453,10 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
             }
             ss ^= 1;
             sd = sdn;
+            if (kt == 0 && has_next) {          // look up the tile after the next one (wave-uniform scalar work)
+                n2tile = ntile + gridDim.x;
+                while (n2tile < tiles_total && !tile_coords(n2tile, n2m0, n2n0)) n2tile += gridDim.x;
+            }
         }
         STAMP(0);
         STAMP(1);
@@ -464,6 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         __syncthreads();       // every wave is done with its scratch before the next tile's DMA re-uses those slots
         if (!has_next) break;
         tile = ntile; m0 = nm0; n0 = nn0; asrc = nasrc; wsrc = nwsrc;
+        ntile = n2tile; nm0 = n2m0; nn0 = n2n0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead DMA before the LDS is released
     range.finish(p.range_flag);

@@ -1,0 +1,328 @@
+// gemm256q: the 256x256 persistent LDS-DMA GEMM of gemm.hip on fp8 (OCP e4m3fn) operands -- C = (A8 . W8^T) * sa[m] * sw[n].
+// BASELINE configs[4] / SURVEY 8d cfg5: "fp8 weights (CDNA4 fp8 MFMA)".  The MLP projections (2/3 of a block's FLOPs)
+// of dtype="fp8mfma" models run here: v_mfma_f32_16x16x128_f8f6f4 (the un-scaled form of the f8f6f4 instruction,
+// measured 3.5-4.0 PFLOP/s issue rate by scripts/micro/f8_probe.hip = 2x the bf16 MFMA), fp32 accumulation.
+//
+// Same skeleton as gemm256d_kernel (asymmetric 3 + 2 slot LDS ring filled by global_load_lds_dwordx4, one barrier per
+// k-step in front of its last row pair, persistent XCD-aware tile loop, epilogues transposed through LDS).  Differences:
+//   * a k-step is still 128 BYTES of every row, i.e. 128 k-elements = ONE MFMA per fragment pair (8 x 4 = 32 MFMAs per
+//     wave and k-step, the same matrix-pipe time as 64 bf16 MFMAs, twice the FLOPs);
+//   * fragment = 32 bytes per lane: lane (fr = lane & 15, g = lane >> 4) holds k = 32 g .. 32 g + 31 of row fr
+//     (probe-verified), i.e. the 16-byte chunks 2g and 2g + 1: two ds_read_b128.  The chunk swizzle that keeps THIS
+//     access pattern bank-conflict free is physical = logical ^ rotl3(row & 7) (searched over all GF(2)-linear maps,
+//     scripts/lds_layout_check.py::check_q8) -- chunk ^ (row & 7) of the 16-bit kernels is 2-way conflicted here;
+//   * W fragments of a k-step are all needed from its first MFMA on, so they are double-buffered across k-steps (the
+//     k-loop is unrolled by two: K % 256 == 0) and the next step's set is read behind the barrier with the next A rows;
+//   * scaling: A codes carry one power-of-two scale per ROW (a_scale[m], written by the quantising LayerNorm) or one
+//     per tensor (a_scalar: the calibrated scale of the GELU output), W codes one per output channel (w_scale[n],
+//     sgpt_fp8_quantize_rows).  Both factor out of the k-sum and are applied to the accumulators in the epilogue.
+//   * epilogues: bias + gelu_new -> fp8 codes under a per-tensor output scale (saturating at +-448; a saturated value
+//     raises bit 1 of the context's range flag), and bias + residual in fp32 (in place).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CH = 8;
+constexpr int TM = 256, TN = 256;
+constexpr int SLOT = TM * CH;         // uint4 per 32-KiB slot
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+__device__ __forceinline__ f32x4 mfma_f8(const uint4& a_lo, const uint4& a_hi, const uint4& b_lo, const uint4& b_hi, const f32x4& c) {
+    const i32x8 a = {(int)a_lo.x, (int)a_lo.y, (int)a_lo.z, (int)a_lo.w, (int)a_hi.x, (int)a_hi.y, (int)a_hi.z, (int)a_hi.w};
+    const i32x8 b = {(int)b_lo.x, (int)b_lo.y, (int)b_lo.z, (int)b_lo.w, (int)b_hi.x, (int)b_hi.y, (int)b_hi.z, (int)b_hi.w};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);   // cbsz = blgp = 0: e4m3 x e4m3; zero scales: un-scaled opcode
+}
+
+// four fp32 -> four OCP e4m3fn codes (RNE), saturating at +-448
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f); b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+    c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f); d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+
+template <int EPI, bool DEEP_A>
+__global__ __launch_bounds__(512, 2) void gemm256q_kernel(const GemmArgs p) {
+    if (p.pred != nullptr && *p.pred == 0) return;
+    typedef __attribute__((address_space(3))) char* lds_cptr_t;
+    __shared__ __attribute__((aligned(16))) uint4 lds[5 * SLOT];    // [deep 0..2 | shallow 0..1] = 160 KiB
+
+    const int N = p.N, K = p.K;
+    const int MT = p.M / TM, NT = N / TN;
+    const int GM = p.gm > 0 ? p.gm : 4, GN = p.gn > 0 ? p.gn : 8;
+    const bool m_major = MT >= NT;
+    const int AT = m_major ? MT : NT, BT = m_major ? NT : MT;
+    const int per_band = GM * BT;
+    const int tiles_total = ((AT + 7) / 8 + GM - 1) / GM * GM * 8 * BT;
+    auto tile_coords = [&](int tile, int& m0, int& n0) -> bool {
+        const int xcd = tile & 7, local = tile >> 3;
+        const int band = local / per_band, inb = local % per_band;
+        const int ng = inb / (GM * GN);
+        const int gn = (BT - ng * GN) < GN ? (BT - ng * GN) : GN;
+        const int r = inb - ng * GM * GN;
+        const int at = xcd + 8 * (band * GM + r / gn), bt = ng * GN + r % gn;
+        m0 = (m_major ? at : bt) * TM; n0 = (m_major ? bt : at) * TN;
+        return at < AT;
+    };
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, g = lane >> 4;
+
+    const uint8_t* __restrict__ Ag = static_cast<const uint8_t*>(p.A);      // [M][K] bytes
+    const uint8_t* __restrict__ Wg = static_cast<const uint8_t*>(p.W);      // [N][K] bytes
+    const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0]);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // LDS-DMA: lane l of a piece fills LDS (row 8q + (l >> 3), chunk slot l & 7) from global chunk (l & 7) ^ rotl3(l >> 3)
+    const int rw = lane >> 3;
+    const int lchunk = (lane & 7) ^ (((rw << 1) & 7) | (rw >> 2));
+    const unsigned a_loff = (unsigned)(rw * p.lda + lchunk * 16);           // bytes (1-byte elements)
+    const unsigned w_loff = (unsigned)(rw * p.ldw + lchunk * 16);
+    auto dma16 = [&](const uint8_t* base_uniform, unsigned lane_off, unsigned dst_byte) {   // M0: see gemm.hip / the ISA test
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(lane_off), "s"(base_uniform), "s"(dst_byte)
+                     : "memory");
+    };
+    auto deep_off = [&](int sd) { return (unsigned)(sd * SLOT * 16); };
+    auto shal_off = [&](int ss) { return (unsigned)((3 + ss) * SLOT * 16); };
+    auto piece = [&](const uint8_t* src, long ld, unsigned loff, int kt, unsigned slot_off, int q) {
+        const unsigned row_off = (unsigned)((wave_u * 32 + q * 8) * CH * 16);
+        dma16(src + (long)(wave_u * 32 + q * 8) * ld + kt * 128, loff, lds_base + slot_off + row_off);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / 128;   // even, >= 2 (launcher)
+
+    int tile = blockIdx.x, m0 = 0, n0 = 0;
+    while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
+    if (tile >= tiles_total) return;
+    const uint8_t* asrc = Ag + (long)m0 * p.lda;
+    const uint8_t* wsrc = Wg + (long)n0 * p.ldw;
+    const long dld = DEEP_A ? p.lda : p.ldw, sld = DEEP_A ? p.ldw : p.lda;
+    const unsigned dloff = DEEP_A ? a_loff : w_loff, sloff = DEEP_A ? w_loff : a_loff;
+    int sd = 0, ss = 0;
+
+    {   // prologue: deep(0), shallow(0), deep(1)
+        const uint8_t* dsrc = DEEP_A ? asrc : wsrc;
+        const uint8_t* ssrc = DEEP_A ? wsrc : asrc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece(dsrc, dld, dloff, 0, deep_off(0), q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece(ssrc, sld, sloff, 0, shal_off(0), q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece(dsrc, dld, dloff, 1, deep_off(1), q);
+    }
+    // fragment addressing inside a slot (uint4 units): row * 8 + ((2g + half) ^ rotl3(row & 7)); rows of a lane's blocks
+    // differ by multiples of 16, so the swizzle term is a per-lane constant
+    const int swz = ((fr << 1) & 7) | ((fr >> 2) & 1);
+    const int c_lo = (2 * g) ^ swz, c_hi = (2 * g + 1) ^ swz;
+    const int a_row = (wm * 128 + fr) * CH, w_row = (wn * 64 + fr) * CH;
+    uint4 wf[2][4][2], af[2][2][2];
+    auto ld_w = [&](const uint4* lw, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wf[buf][j][0] = lw[w_row + j * 16 * CH + c_lo]; wf[buf][j][1] = lw[w_row + j * 16 * CH + c_hi]; }
+    };
+    auto ld_a = [&](const uint4* la, int pr, int buf) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            af[buf][hh][0] = la[a_row + (2 * pr + hh) * 16 * CH + c_lo];
+            af[buf][hh][1] = la[a_row + (2 * pr + hh) * 16 * CH + c_hi];
+        }
+    };
+    {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // deep(0), shallow(0) landed
+        __syncthreads();
+        const uint4* la = lds + (DEEP_A ? sd * SLOT : (3 + ss) * SLOT);
+        const uint4* lw = lds + (DEEP_A ? (3 + ss) * SLOT : sd * SLOT);
+        ld_w(lw, 0);
+        ld_a(la, 0, 0);
+    }
+    int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
+    while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
+    while (true) {
+        const bool has_next = ntile < tiles_total;
+        int n2tile = ntile, n2m0 = 0, n2n0 = 0;
+        const uint8_t* nasrc = has_next ? Ag + (long)nm0 * p.lda : asrc;
+        const uint8_t* nwsrc = has_next ? Wg + (long)nn0 * p.ldw : wsrc;
+        const uint8_t* d_cur = DEEP_A ? asrc : wsrc, *d_nxt = DEEP_A ? nasrc : nwsrc;
+        const uint8_t* s_cur = DEEP_A ? wsrc : asrc, *s_nxt = DEEP_A ? nwsrc : nasrc;
+        // one k-step with the W-fragment set CB (compile-time), leaving the next step's set in CB ^ 1
+        auto kstep = [&](int kt, auto cb_tag) {
+            constexpr int CB = decltype(cb_tag)::value;
+            if (p.dbg && blockIdx.x == 0 && t == 0 && kt < 12) p.dbg[64 + kt] = (long long)__builtin_amdgcn_s_memtime();
+            const bool s_in = kt + 1 < nk, d_in = kt + 2 < nk;
+            const uint8_t* sp = s_in ? s_cur : s_nxt;  const int skt = s_in ? kt + 1 : 0;
+            const uint8_t* dp = d_in ? d_cur : d_nxt;  const int dkt = d_in ? kt + 2 : kt + 2 - nk;
+            const unsigned s_dst = shal_off(ss ^ 1);
+            const int sd2 = sd + 2 >= 3 ? sd - 1 : sd + 2;
+            const unsigned d_dst = deep_off(sd2);
+            const int sdn = sd + 1 >= 3 ? 0 : sd + 1;
+            const uint4* la = lds + (DEEP_A ? sd * SLOT : (3 + ss) * SLOT);
+            const uint4* nla = lds + (DEEP_A ? sdn * SLOT : (3 + (ss ^ 1)) * SLOT);
+            const uint4* nlw = lds + (DEEP_A ? (3 + (ss ^ 1)) * SLOT : sdn * SLOT);
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                if (pr < 3) {
+                    ld_a(la, pr + 1, (pr + 1) & 1);
+                } else {                        // every read of this stage has returned; stage kt+1 has landed
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");
+                    __syncthreads();
+                    ld_a(nla, 0, 0);
+                    ld_w(nlw, CB ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int i = 2 * pr + hh;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)   // weight fragment = A-operand: lane ends up with one token row and 4 consecutive n
+                        acc[i][j] = mfma_f8(wf[CB][j][0], wf[CB][j][1], af[pr & 1][hh][0], af[pr & 1][hh][1], acc[i][j]);
+                    if (pr < 2) {   // two 1-KiB DMA pieces behind every 4 MFMAs of the first half: shallow x4, then deep x4
+                        const int q0 = 2 * (i & 1);
+                        if (pr == 0) { piece(sp, sld, sloff, skt, s_dst, q0); piece(sp, sld, sloff, skt, s_dst, q0 + 1); }
+                        else { piece(dp, dld, dloff, dkt, d_dst, q0); piece(dp, dld, dloff, dkt, d_dst, q0 + 1); }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ss ^= 1;
+            sd = sdn;
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            kstep(kt, std::integral_constant<int, 0>{});
+            if (kt == 0 && has_next) {          // look up the tile after the next one in the shadow of the first MFMAs
+                n2tile = ntile + gridDim.x;
+                while (n2tile < tiles_total && !tile_coords(n2tile, n2m0, n2n0)) n2tile += gridDim.x;
+            }
+            kstep(kt + 1, std::integral_constant<int, 1>{});
+        }
+        if (p.dbg && blockIdx.x == 0 && t == 0) p.dbg[0] = (long long)__builtin_amdgcn_s_memtime();
+        // ------------------------------------------ epilogue ------------------------------------------
+        {
+            const int sdf = sd + 2 >= 3 ? sd - 1 : sd + 2;
+            char* scr = reinterpret_cast<char*>(lds) + (wave < 4 ? deep_off(sdf) : shal_off(ss ^ 1)) + (wave & 3) * 8192;
+            if constexpr (EPI == EPI_NONE) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { asm volatile("" ::"v"(acc[i][j])); acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                (void)scr;
+            } else {
+                // scales of this lane's accumulators: row factor (per i) x channel factor (per j, 4 consecutive n)
+                float4 sw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sw[j] = *reinterpret_cast<const float4*>(p.w_scale + n0 + wn * 64 + j * 16 + 4 * g);
+                    sw[j].x *= p.a_scalar; sw[j].y *= p.a_scalar; sw[j].z *= p.a_scalar; sw[j].w *= p.a_scalar;
+                }
+                if constexpr (EPI == EPI_BIAS_GELU) {
+                    // gelu_new(acc * sa * sw + bias) / out_scale -> e4m3 codes; 16 rows x 64 B per round, LDS row stride 80 B
+                    constexpr int RS = 80;
+                    float4 bb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 16 + 4 * g);
+                    const float inv = 1.0f / p.out_scale;          // power of two: exact
+                    const int rrow = lane >> 2, rchunk = lane & 3;
+                    char* gp = static_cast<char*>(p.out) + (long)(m0 + wm * 128 + rrow) * p.ldo + n0 + wn * 64 + rchunk * 16;
+                    const long gstep = 16 * p.ldo;
+                    float amax = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float sa = p.a_scale ? p.a_scale[m0 + wm * 128 + i * 16 + fr] : 1.0f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v0 = gelu_new_fast(acc[i][j][0] * (sa * sw[j].x) + bb[j].x) * inv;
+                            const float v1 = gelu_new_fast(acc[i][j][1] * (sa * sw[j].y) + bb[j].y) * inv;
+                            const float v2 = gelu_new_fast(acc[i][j][2] * (sa * sw[j].z) + bb[j].z) * inv;
+                            const float v3 = gelu_new_fast(acc[i][j][3] * (sa * sw[j].w) + bb[j].w) * inv;
+                            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
+                            *reinterpret_cast<uint32_t*>(scr + fr * RS + j * 16 + 4 * g) = pack_fp8x4(v0, v1, v2, v3);
+                            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        const uint4 v = *reinterpret_cast<const uint4_a*>(scr + rrow * RS + rchunk * 16);
+                        gstore16<true>(gp, v);
+                        gp += gstep;
+                    }
+                    if (p.range_flag != nullptr && !(amax <= 448.f)) atomicOr(p.range_flag, 2);   // saturated (or NaN): re-calibrate
+                } else {
+                    // fp32: out = resid + acc * sa * sw + bias (in place on the residual stream); 16 rows x 256 B per round
+                    static_assert(EPI == EPI_BIAS_RESID, "gemm256q: bias+gelu (fp8 out) and bias+residual (fp32) epilogues only");
+                    constexpr int RS = 272;
+                    const int rrow = lane >> 4, rchunk = lane & 15;
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + rchunk * 4);
+                    long goff = (long)(m0 + wm * 128 + rrow) * p.ldo + n0 + wn * 64 + rchunk * 4;
+                    const long gstep4 = 4 * p.ldo;
+                    float* outp = static_cast<float*>(p.out);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float sa = p.a_scale ? p.a_scale[m0 + wm * 128 + i * 16 + fr] : 1.0f;
+                        float4 rr[4];
+#pragma unroll
+                        for (int hh = 0; hh < 4; ++hh) rr[hh] = *reinterpret_cast<const float4*>(p.resid + goff + hh * gstep4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            *reinterpret_cast<float4_a*>(scr + fr * RS + (j * 16 + 4 * g) * 4) =
+                                make_float4(acc[i][j][0] * (sa * sw[j].x), acc[i][j][1] * (sa * sw[j].y),
+                                            acc[i][j][2] * (sa * sw[j].z), acc[i][j][3] * (sa * sw[j].w));
+                            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+#pragma unroll
+                        for (int hh = 0; hh < 4; ++hh) {
+                            float4 v = *reinterpret_cast<const float4_a*>(scr + (hh * 4 + rrow) * RS + rchunk * 16);
+                            v.x += bb.x + rr[hh].x; v.y += bb.y + rr[hh].y; v.z += bb.z + rr[hh].z; v.w += bb.w + rr[hh].w;
+                            gstore16<false>(outp + goff, __builtin_bit_cast(uint4, v));
+                            goff += gstep4;
+                        }
+                    }
+                }
+            }
+        }
+        if (p.dbg && blockIdx.x == 0 && t == 0) p.dbg[1] = (long long)__builtin_amdgcn_s_memtime();
+        __syncthreads();       // every wave is done with its scratch before the next tile's DMA re-uses those slots
+        if (!has_next) break;
+        tile = ntile; m0 = nm0; n0 = nn0; asrc = nasrc; wsrc = nwsrc;
+        ntile = n2tile; nm0 = n2m0; nn0 = n2n0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead DMA before the LDS is released
+}
+
+template <int EPI>
+void launch256q(const GemmArgs& a, hipStream_t s) {
+    const int MT = a.M / 256, NT = a.N / 256;
+    const int AT = MT >= NT ? MT : NT, BT = MT >= NT ? NT : MT;
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n / 8 * 8;
+    }();
+    GemmArgs b = a;
+    const int gm = b.gm > 0 ? b.gm : 4;
+    const int tiles_pad = ((AT + 7) / 8 + gm - 1) / gm * gm * 8 * BT;
+    const int grid = tiles_pad < ncu ? tiles_pad : ncu;
+    if (a.M >= a.N) hipLaunchKernelGGL((gemm256q_kernel<EPI, true>), dim3(grid), dim3(512), 0, s, b);
+    else hipLaunchKernelGGL((gemm256q_kernel<EPI, false>), dim3(grid), dim3(512), 0, s, b);
+}
+
+}  // namespace
+
+// fp8 (e4m3fn) operands, M % 256 == 0, N % 256 == 0, K % 256 == 0; epi: EPI_BIAS_GELU (fp8 out), EPI_BIAS_RESID (fp32 out), EPI_NONE
+bool gemm_fp8_shape_ok(int M, int N, int K) { return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 && K >= 256; }
+
+void launch_gemm_fp8(int epi, const GemmArgs& a, hipStream_t s) {
+    if (!gemm_fp8_shape_ok(a.M, a.N, a.K)) abort();
+    if (epi == EPI_BIAS_GELU) return launch256q<EPI_BIAS_GELU>(a, s);
+    if (epi == EPI_BIAS_RESID) return launch256q<EPI_BIAS_RESID>(a, s);
+    if (epi == EPI_NONE) return launch256q<EPI_NONE>(a, s);
+    abort();
+}

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F16, SGPT_F32, SGPT_FP8W, SgptRangeError
+from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F16, SGPT_F32, SGPT_FP8M, SGPT_FP8W, SgptRangeError
 from .runtime import Context, get_context, _p, _stream_ptr
 
 ALIGN = 16         # sequence starts on the packed token axis (MFMA 16-row tiles; V^T 8-byte loads)
@@ -187,13 +187,14 @@ class SGPTModel:
     """GPT-Neo weights resident on one GPU behind an `sgpt_model*` handle."""
 
     def __init__(self, cfg: SGPTConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device=None,
-                 dtype: str = "f16", ctx: Optional[Context] = None, max_tokens_per_call: int = 32768):
+                 dtype: str = "f16", ctx: Optional[Context] = None, max_tokens_per_call: int = 32768,
+                 calibrate: bool = True):
         if dtype in ("fp16", "float16", "half"):
             dtype = "f16"
-        if dtype not in ("f16", "bf16", "fp32", "fp8"):
+        if dtype not in ("f16", "bf16", "fp32", "fp8", "fp8mfma"):
             raise ValueError("dtype must be 'f16' (IEEE-half MFMA operands, range-guarded: the 1e-3-parity mode), "
-                             "'bf16' (bf16 MFMA operands), 'fp32' (exact fp32 MFMA) or "
-                             "'fp8' (e4m3fn weight storage, bf16 arithmetic)")
+                             "'bf16' (bf16 MFMA operands), 'fp32' (exact fp32 MFMA), "
+                             "'fp8' (e4m3fn weight storage, bf16 arithmetic) or 'fp8mfma' (fp8 storage + fp8 MFMA on the MLP)")
         self.cfg = cfg
         self.ctx = ctx or get_context(device)
         self.device = self.ctx.device
@@ -209,7 +210,8 @@ class SGPTModel:
                          vocab=cfg.vocab_size, max_pos=cfg.max_position_embeddings, window=cfg.window_size,
                          ln_eps=cfg.layer_norm_epsilon,
                          attn_scale=float(1.0 / np.sqrt(np.float32(dh))) if (gptj or bloom) else 1.0,   # HF:gptj:148, HF:bloom:186 / HF:gpt_neo:110
-                         compute_dtype={"f16": SGPT_F16, "bf16": SGPT_BF16, "fp32": SGPT_F32, "fp8": SGPT_FP8W}[dtype],
+                         compute_dtype={"f16": SGPT_F16, "bf16": SGPT_BF16, "fp32": SGPT_F32, "fp8": SGPT_FP8W,
+                                        "fp8mfma": SGPT_FP8M}[dtype],
                          layer_is_local=C.cast(local, C.POINTER(C.c_uint8)), rotary_dim=cfg.rotary_dim if gptj else 0)
         if gptj:
             weights = dict(weights)
@@ -239,9 +241,38 @@ class SGPTModel:
         self.handle = h
         del keep  # the library now owns packed copies
         self._staging = _Staging(self.device)
+        self.act_scales = None
+        if dtype == "fp8mfma" and calibrate:
+            self.calibrate()
         self.position_weights = None
         if "position_weights" in weights:
             self.set_position_weights(weights["position_weights"])
+
+    def calibrate(self, seqs: Optional[Sequence[Sequence[int]]] = None, margin: float = 2.0) -> np.ndarray:
+        """dtype='fp8mfma': fix the per-block power-of-two scale of the GELU output's e4m3 codes from a calibration
+        forward (run in the fp8-storage / bf16-arithmetic mode while the library records max |gelu output| per block).
+        Default sample: 64 deterministic pseudo-random sequences of 64 tokens (reproducible embeddings); pass
+        representative token lists to calibrate on real text.  `margin` = head-room factor over the sample's maximum."""
+        if self.dtype != "fp8mfma":
+            raise ValueError("calibrate() applies to dtype='fp8mfma'")
+        if seqs is None:
+            S = min(64, self.cfg.max_position_embeddings)
+            seqs = np.random.default_rng(1234).integers(0, self.cfg.vocab_size, size=(64, S), dtype=np.int64)
+        lib = self.ctx.lib
+        _lib.check(self.ctx.handle, lib.sgpt_model_calibrate_begin(self.handle), "sgpt_model_calibrate_begin")
+        try:
+            self.encode_ids(seqs)
+        finally:
+            out = (C.c_float * self.cfg.num_layers)()
+            _lib.check(self.ctx.handle, lib.sgpt_model_calibrate_end(self.handle, float(margin), out), "sgpt_model_calibrate_end")
+        self.act_scales = np.array(list(out), dtype=np.float32)
+        return self.act_scales
+
+    def set_act_scales(self, scales) -> None:
+        a = np.ascontiguousarray(scales, dtype=np.float32)
+        _lib.check(self.ctx.handle, self.ctx.lib.sgpt_model_set_act_scales(self.handle, a.ctypes.data_as(C.c_void_p), a.size),
+                   "sgpt_model_set_act_scales")
+        self.act_scales = a
 
     def set_position_weights(self, w) -> None:
         """Trained `position_weights` of models/WeightedMeanPooling.py:16-19 for method 'learntmean'
@@ -373,9 +404,15 @@ class SGPTModel:
 
     def _check_range(self):
         """dtype='f16': fail loudly if an activation left the half range during the calls just issued."""
-        if self.dtype == "f16" and self.ctx.range_check(reset=True):
+        if self.dtype not in ("f16", "fp8mfma"):
+            return
+        flags = self.ctx.range_check(reset=True)
+        if flags & 1:
             raise SgptRangeError("dtype='f16': an activation reached |v| >= 32768 (IEEE-half range); "
                                  "this checkpoint needs dtype='bf16'")
+        if flags & 2:
+            raise SgptRangeError("dtype='fp8mfma': a GELU output saturated its e4m3 codes; re-run calibrate() on "
+                                 "representative inputs (or with a larger margin)")
 
     def _batched(self, seqs, pad_left, run) -> torch.Tensor:
         """Length-sorted token-budget batches -> `run(pb, out_rows)` per batch -> rows back in input order."""

@@ -113,12 +113,13 @@ class Context:
     def to_bf16(self, x: torch.Tensor) -> torch.Tensor:
         return self.to_16(x, torch.bfloat16)
 
-    def range_check(self, reset: bool = True) -> bool:
-        """dtype='f16' guard: True when an activation left the half range since the last reset (syncs the stream)."""
+    def range_check(self, reset: bool = True) -> int:
+        """Range guards (syncs the stream): bit 0 = an f16 activation left the half range, bit 1 = an fp8mfma GELU output
+        saturated its e4m3 codes, since the last reset.  0 = clean."""
         flagged = C.c_int32(0)
         self._chk(self.lib.sgpt_range_check(self.handle, C.byref(flagged), 1 if reset else 0, _stream_ptr(self.device)),
                   "sgpt_range_check")
-        return bool(flagged.value)
+        return int(flagged.value)
 
     def generation(self) -> int:
         """Changes when a library-owned buffer captured graphs point into was re-allocated (EncodeGraph)."""
@@ -169,6 +170,31 @@ class Context:
         self._chk(self.lib.sgpt_linear(self.handle, DT_CODE[a.dtype], code, DT_CODE[out_dtype], _p(a.contiguous()),
                                        _p(w.contiguous()), _p(b), _p(r), _p(out), M, N, K, _stream_ptr(self.device)),
                   "sgpt_linear")
+        return out
+
+    # ---- fp8-MFMA building blocks (dtype='fp8mfma'): quantising LayerNorm, e4m3 x e4m3 projection ----
+    def layernorm_fp8(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        T, d = x.shape
+        codes = torch.empty((T, d), dtype=torch.uint8, device=self.device)
+        scale = torch.empty((T,), dtype=torch.float32, device=self.device)
+        g = gamma.to(device=self.device, dtype=torch.float32).contiguous()
+        b = beta.to(device=self.device, dtype=torch.float32).contiguous()
+        self._chk(self.lib.sgpt_layernorm_fp8(self.handle, _p(x), _p(g), _p(b), T, d, eps, _p(codes), _p(scale),
+                                              _stream_ptr(self.device)), "sgpt_layernorm_fp8")
+        return codes, scale
+
+    def linear_fp8(self, a8: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias: torch.Tensor, epi: str,
+                   a_scale: Optional[torch.Tensor] = None, a_scalar: float = 1.0, resid: Optional[torch.Tensor] = None,
+                   out_scale: float = 1.0) -> torch.Tensor:
+        """epi 'gelu': u8 codes of gelu_new(acc + bias) / out_scale;  'resid': fp32 resid + acc + bias."""
+        M, K = a8.shape
+        N = w8.shape[0]
+        out = torch.empty((M, N), dtype=torch.uint8 if epi == "gelu" else torch.float32, device=self.device)
+        r = None if resid is None else resid.to(device=self.device, dtype=torch.float32).contiguous()
+        self._chk(self.lib.sgpt_linear_fp8(self.handle, 1 if epi == "gelu" else 2, _p(a8.contiguous()), _p(a_scale), a_scalar,
+                                           _p(w8.contiguous()), _p(w_scale.contiguous()), _p(bias.contiguous()), _p(r), _p(out),
+                                           out_scale, M, N, K, _stream_ptr(self.device)), "sgpt_linear_fp8")
         return out
 
     # ---- a7: dense score matrix (cos_sim / dot_score) ----

@@ -300,7 +300,7 @@ def _device_asm(name):
     return out.stdout
 
 
-@pytest.mark.parametrize("src", ["gemm.hip", "gemm256w.hip"])
+@pytest.mark.parametrize("src", ["gemm.hip", "gemm256w.hip", "gemm256q.hip"])
 def test_m0_only_written_by_the_dma_idiom(src):
     """The LDS-DMA pieces set M0 inside inline asm without declaring it clobbered (hipcc refuses reserved registers on
     clobber lists).  That is sound only while the compiler itself never keeps a value in M0 across those statements:
@@ -328,3 +328,12 @@ def test_wide_gemm_index_model():
     assert banks["fragment ds_read_b128"] == 1 and banks["epi32 ds_write_b128"] == 1 and banks["epi32 ds_read_b128"] == 1
     assert max(banks.values()) <= 2
     assert mod.walk_tile(K=192, seed=3)
+
+
+def test_fp8_gemm_swizzle_is_conflict_free():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_layout_check", os.path.join(ROOT, "scripts", "lds_layout_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    q8 = mod.check_q8()
+    assert q8["rotl3(row&7)"] == 1 and q8["row&7"] == 2
