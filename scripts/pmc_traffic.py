@@ -35,9 +35,14 @@ def median(v):
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 
 
+import re  # noqa: E402
+
+
 def pick(table, key, n, phase=None, period=1):
-    names = [k for k in table if "gemm256" in k and key in k]
-    assert len(names) == 1, (key, names)
+    # kernel names: gemm256d_kernel<operand type, EPI, out type, SWAP, DEEP_A>; key = the EPI code
+    names = [k for k in table if re.search(r"gemm256d_kernel<[^,]+, %s," % key, k)]
+    names = sorted(names, key=lambda k: -len(table[k]))[:1]      # the operand type / ring orientation the encoder uses
+    assert len(names) == 1, (key, list(table)[:20])
     vals = table[names[0]][-n:]
     if phase is not None:
         vals = vals[phase::period]
@@ -45,11 +50,11 @@ def pick(table, key, n, phase=None, period=1):
 
 
 shapes = [  # name, kernel-name key, launches to take, (phase, period), algorithmic bytes
-    ("qk_proj  [T,1536]x768 store bf16", "<0,", LAUNCHES, None, T * D * 2 + T * 2 * D * 2 + 2 * D * D * 2),
-    ("v_proj   [T,768]x768  V^T bf16", "<4,", LAUNCHES, None, T * D * 2 + T * D * 2 + D * D * 2),
-    ("out_proj [T,768]x768  +bias+resid fp32", "<2,", 2 * LAUNCHES, (0, 2), T * D * 2 + 2 * T * D * 4 + D * D * 2),
-    ("fc1      [T,3072]x768 +bias+gelu bf16", "<1,", LAUNCHES, None, T * D * 2 + T * FFN * 2 + D * FFN * 2),
-    ("fc2      [T,768]x3072 +bias+resid fp32", "<2,", 2 * LAUNCHES, (1, 2), T * FFN * 2 + 2 * T * D * 4 + D * FFN * 2),
+    ("qk_proj  [T,1536]x768 store 16-bit", "0", LAUNCHES, None, T * D * 2 + T * 2 * D * 2 + 2 * D * D * 2),
+    ("v_proj   [T,768]x768  V^T 16-bit", "4", LAUNCHES, None, T * D * 2 + T * D * 2 + D * D * 2),
+    ("out_proj [T,768]x768  +bias+resid fp32", "2", 2 * LAUNCHES, (0, 2), T * D * 2 + 2 * T * D * 4 + D * D * 2),
+    ("fc1      [T,3072]x768 +bias+gelu 16-bit", "1", LAUNCHES, None, T * D * 2 + T * FFN * 2 + D * FFN * 2),
+    ("fc2      [T,768]x3072 +bias+resid fp32", "2", 2 * LAUNCHES, (1, 2), T * FFN * 2 + 2 * T * D * 4 + D * FFN * 2),
 ]
 per = {}
 for name, key, n, ph, alg in shapes:

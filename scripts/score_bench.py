@@ -1,22 +1,23 @@
 #!/usr/bin/env python3
-"""Scoring-only micro-benchmark: nq queries x N-document bf16 shard, cosine top-(k+1)."""
+"""Scoring-only micro-benchmark: nq queries x N-document 16-bit shard (DT=f16 | bf16), cosine top-(k+1)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sgpt_amd import get_context
 ctx = get_context("cuda:0")
 nq, N, d, k = int(os.environ.get("NQ", 1000)), int(os.environ.get("N", 1000000)), 768, int(os.environ.get("K", 11))
+DT = torch.bfloat16 if os.environ.get("DT", "f16") == "bf16" else torch.float16
 g = torch.Generator(device="cuda").manual_seed(0)
 base = torch.randn(1, d, device="cuda", generator=g) * 3          # anisotropic: shared dominant direction
-c = torch.nn.functional.normalize(base + torch.randn(N, d, device="cuda", generator=g), dim=1).to(torch.bfloat16)
-q = torch.nn.functional.normalize(base + torch.randn(nq, d, device="cuda", generator=g), dim=1).to(torch.bfloat16)
+c = torch.nn.functional.normalize(base + torch.randn(N, d, device="cuda", generator=g), dim=1).to(DT)
+q = torch.nn.functional.normalize(base + torch.randn(nq, d, device="cuda", generator=g), dim=1).to(DT)
 for _ in range(2):
-    ctx.score_topk(q, c, k, dtype=torch.bfloat16)
+    ctx.score_topk(q, c, k, dtype=DT)
 torch.cuda.synchronize()
 t = time.perf_counter()
 reps = 5
 for _ in range(reps):
-    ctx.score_topk(q, c, k, dtype=torch.bfloat16)
+    ctx.score_topk(q, c, k, dtype=DT)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / reps
 print(f"nq={nq} N={N} k={k}: {dt*1e3:.2f} ms per pass -> {nq/dt:,.0f} queries/s; corpus stream {N*d*2/dt/1e12:.2f} TB/s; {2*nq*N*d/dt/1e12:.0f} TFLOP/s")
