@@ -174,7 +174,9 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    # SGPT_BENCH_FORCE_DIST=1 (with torchrun --nproc-per-node 1): run the N > 1 code path -- RCCL init, query all-gather,
+    # top-k exchange, shard check -- with a world of one, on a single-GPU box
+    dist_on = world > 1 or (os.environ.get("SGPT_BENCH_FORCE_DIST") == "1" and "WORLD_SIZE" in os.environ)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:

@@ -70,3 +70,39 @@ def test_rccl_distributed_encode_equals_local_encode(nccl_group):
     assert got.is_cuda and got.shape == want.shape and float((got - want).abs().max()) < 1e-6
     ref = O.encode(O.synth_weights(O.NeoConfig(**kw), seed=11, std=0.08), O.NeoConfig(**kw), seqs, normalize_embeddings=True)
     assert np.abs(got.cpu().numpy() - ref).max() < 5e-3
+
+
+def _run_bench(args, env_extra, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable] + args, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(900)
+def test_bench_distributed_path_on_rccl_world_one():
+    """bench.py's N > 1 code path (RCCL init, sharded query encode + all-gather, top-k exchange + merge, the
+    sharded-vs-single-rank check, max-over-ranks timing) under torchrun with a world of one."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--chunk", "1024",
+                    "--nq", "64", "--no-cpu-baseline", "--no-1m", "--no-varlen"], {"SGPT_BENCH_FORCE_DIST": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["shard_check"]["identical_to_single_rank"] is True
+
+
+def test_bench_gpus_more_than_visible_fails_loudly():
+    """`python bench.py --gpus N` outside torchrun spawns N ranks itself; with fewer devices it must refuse, not run 1."""
+    import torch as _t
+    n = _t.cuda.device_count() + 1
+    r = _run_bench(["bench.py", "--gpus", str(n), "--steps", "1"], {}, timeout=120)
+    assert r.returncode != 0 and "HIP device(s) visible" in (r.stdout + r.stderr)
