@@ -405,9 +405,8 @@ def main():
 
     # ---- roofline of the dominant kernel (the MFMA GEMM) from live hipEvent timings ----
     gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    # fp8mfma: the MLP projections (2/3 of the GEMM FLOPs) run on the fp8 MFMA (dense peak 5 PFLOP/s), the attention
-    # projections on bf16 (2.5): the time-weighted peak of that mix is 1 / (2/3 / 5000 + 1/3 / 2500) = 3750 TFLOP/s
-    peak = 157.3 if args.dtype == "fp32" else (3750.0 if args.dtype == "fp8mfma" else PEAK_BF16_TFLOPS)
+    # fp8mfma: all four projections run on the fp8 MFMA (dense peak 5 PFLOP/s, MI355X_MICROARCH.md)
+    peak = 157.3 if args.dtype == "fp32" else (5000.0 if args.dtype == "fp8mfma" else PEAK_BF16_TFLOPS)
     # HBM bytes per launch from the committed PMC passes of this same command (profiles/, rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 corrections applied there); null if not collected
     traffic, traffic_source = None, None

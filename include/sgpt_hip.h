@@ -78,13 +78,13 @@ typedef struct {
                                            power-of-two fp32 scale per output channel (the
                                            reference loads sgpt-bloom-7b1 8-bit through bitsandbytes) and
                                            de-quantised -- exactly -- to bf16 per block; arithmetic as SGPT_BF16;
-                                SGPT_FP8M: weights stored as SGPT_FP8W, and the two MLP projections of every block (2/3 of its
-                                           FLOPs) COMPUTED in fp8: v_mfma_f32_16x16x128_f8f6f4 on e4m3 x e4m3 operands at
-                                           twice the bf16 MFMA rate (BASELINE configs[4]).  The LayerNorm in front of the
-                                           MLP emits e4m3 codes with one power-of-two scale per row, the GELU output is
-                                           re-quantised under one calibrated power-of-two scale per block
-                                           (sgpt_model_calibrate_begin / _end), scales are applied to the fp32 accumulators;
-                                           attention projections stay bf16.  Shapes that do not fit the 256x256x256 fp8 tile
+                                SGPT_FP8M: weights stored as SGPT_FP8W, and the four projections of every block COMPUTED in fp8:
+                                           v_mfma_f32_16x16x128_f8f6f4 on e4m3 x e4m3 operands at twice the bf16 MFMA rate
+                                           (BASELINE configs[4]).  The LayerNorms emit e4m3 codes with one power-of-two scale
+                                           per row, the GELU output and the attention context are re-quantised under one
+                                           calibrated power-of-two scale per block (sgpt_model_calibrate_begin / _end), scales
+                                           are applied to the fp32 accumulators; q / k / V^T, softmax and P.V stay bf16 / fp32,
+                                           the residual stream fp32.  Shapes that do not fit the 256x256x256 fp8 tile
                                            run the SGPT_FP8W arithmetic.  Cannot meet the 1e-3 bar (3 mantissa bits): the
                                            tests report max |dcos| and top-10 overlap against the fp32 oracle instead */
     const uint8_t* layer_is_local;  /* host, [n_layers]: 1 = sliding-window layer (HF:gpt_neo:66) */
@@ -122,13 +122,14 @@ sgpt_status sgpt_model_load(sgpt_ctx* ctx, const sgpt_model_desc* desc,
 void sgpt_model_free(sgpt_model* model);
 
 /* SGPT_FP8M activation-scale calibration.  Between _begin and _end every sgpt_encode on the model runs the SGPT_FP8W
- * arithmetic and records max |gelu output| per block; _end turns the maxima into per-block power-of-two scales
- * (smallest 2^k with margin * max / 2^k <= 448; margin >= 1, default 2) and returns them (host float[n_layers], may be
- * NULL).  sgpt_model_set_act_scales installs scales computed elsewhere (powers of two).  A later batch whose GELU
- * output saturates the e4m3 range raises bit 1 of the flag read by sgpt_range_check. */
+ * arithmetic and records max |gelu output| and max |attention context| per block; _end turns the maxima into per-block
+ * power-of-two scales (smallest 2^k with margin * max / 2^k <= 448; margin >= 1, default 2) and returns them (host
+ * float[2 * n_layers]: the GELU-output scales, then the context scales; may be NULL).  sgpt_model_set_act_scales installs
+ * scales computed elsewhere (2 * n_layers powers of two).  A later batch that saturates the e4m3 range raises bit 1 of the
+ * flag read by sgpt_range_check. */
 sgpt_status sgpt_model_calibrate_begin(sgpt_model* model);
 sgpt_status sgpt_model_calibrate_end(sgpt_model* model, float margin, float* scales_out);
-sgpt_status sgpt_model_set_act_scales(sgpt_model* model, const float* scales, int32_t n_layers);
+sgpt_status sgpt_model_set_act_scales(sgpt_model* model, const float* scales, int32_t n_scales);
 
 /* -- a2+a3+a4: forward + pool --------------------------------------------------------- */
 /* Replaces, in ONE call and with no hidden-state D2H:
@@ -293,13 +294,15 @@ sgpt_status sgpt_linear(sgpt_ctx* ctx, int32_t dtype, int32_t epi, int32_t out_d
  * sgpt_layernorm_fp8: nn.LayerNorm(x)[T,d] -> e4m3fn codes + one power-of-two scale per row (true value = code * scale).
  * sgpt_linear_fp8:    acc = (A8 . W8^T)[m][n] * a_scale[m] * a_scalar * w_scale[n]   (A8 [M,K], W8 [N,K] e4m3fn codes, fp32
  *                     accumulate; a_scale NULL = 1; M, N, K multiples of 256)
+ *     epi 0: out 16-bit[M,N] = acc (+ bias if given)          (out_dtype SGPT_BF16 | SGPT_F16)
  *     epi 1: out u8[M,N] = e4m3( gelu_new(acc + bias) / out_scale ), saturating at +-448
- *     epi 2: out fp32[M,N] = resid + acc + bias (out may alias resid) */
+ *     epi 2: out fp32[M,N] = resid + acc + bias (out may alias resid)
+ *     epi 4: out 16-bit[N,M] = acc (+ bias[n])                (transposed store: V^T) */
 sgpt_status sgpt_layernorm_fp8(sgpt_ctx* ctx, const float* x, const float* gamma, const float* beta, int32_t T, int32_t d,
                                float eps, uint8_t* codes, float* row_scale, void* stream);
-sgpt_status sgpt_linear_fp8(sgpt_ctx* ctx, int32_t epi, const uint8_t* A, const float* a_scale, float a_scalar,
-                            const uint8_t* W, const float* w_scale, const float* bias, const float* resid, void* out,
-                            float out_scale, int32_t M, int32_t N, int32_t K, void* stream);
+sgpt_status sgpt_linear_fp8(sgpt_ctx* ctx, int32_t epi, int32_t out_dtype, const uint8_t* A, const float* a_scale,
+                            float a_scalar, const uint8_t* W, const float* w_scale, const float* bias, const float* resid,
+                            void* out, float out_scale, int32_t M, int32_t N, int32_t K, void* stream);
 
 /* -- measurement ----------------------------------------------------------------------- */
 /* bench.py's live roofline: when enabled, every GEMM launched by sgpt_encode /

@@ -73,8 +73,8 @@ SIGNATURES = {
     "sgpt_model_set_act_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "sgpt_layernorm_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
-    "sgpt_linear_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sgpt_linear_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sgpt_set_gemm_variant": (C.c_int32, [C.c_int32]),
     "sgpt_set_gemm_skew": (C.c_int32, [C.c_int32]),
     "sgpt_bench_gemm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -56,8 +56,8 @@ struct sgpt_model {
     void* dq[4] = {nullptr, nullptr, nullptr, nullptr};   // SGPT_FP8W / FP8M: bf16 scratch for the current block's qkv / o / fc / proj
     // SGPT_FP8M (fp8 MFMA on the MLP projections): per-block power-of-two scale of the GELU output's e4m3 codes, set by
     // calibration; h_amax = device float bits [n_layers] collected while `calibrating`
-    std::vector<float> act_scale;
-    unsigned* h_amax = nullptr;
+    std::vector<float> act_scale;      // [2 * n_layers]: GELU-output scales, then attention-context scales
+    unsigned* h_amax = nullptr;        // device float bits [2 * n_layers], same order
     bool calibrating = false;
     std::vector<void*> allocs;
 };
@@ -355,9 +355,9 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         m->dq[2] = dalloc((size_t)ffn * dm * 2); m->dq[3] = dalloc((size_t)dm * ffn * 2);
     }
     if (d->compute_dtype == SGPT_FP8M && st == SGPT_OK) {
-        m->act_scale.assign(d->n_layers, 0.0f);               // 0 = not calibrated
-        m->h_amax = (unsigned*)dalloc((size_t)d->n_layers * 4);
-        if (m->h_amax && hipMemsetAsync(m->h_amax, 0, (size_t)d->n_layers * 4, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memset");
+        m->act_scale.assign(2 * (size_t)d->n_layers, 0.0f);   // 0 = not calibrated
+        m->h_amax = (unsigned*)dalloc((size_t)d->n_layers * 8);
+        if (m->h_amax && hipMemsetAsync(m->h_amax, 0, (size_t)d->n_layers * 8, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memset");
     }
     if (st == SGPT_OK && hipDeviceSynchronize() != hipSuccess) st = fail(c, SGPT_ERR_HIP, "sync after weight pack");
     if (f16) {
@@ -428,16 +428,14 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     const size_t o_c = gptj ? carve((size_t)T * dm * esz) : o_a;         // GPT-J: ctx separate (ln_1 output feeds the MLP too)
     const size_t o_qkv = carve(((size_t)T + SLACK) * 3 * dm * esz);      // bf16: [T][2d] qk + V^T [d][T]; fp32: [T][3d]
     const size_t o_h = carve((size_t)T * ffn * esz);                     // MLP hidden (FP8M: e4m3 codes in the same region)
-    // FP8M: fp8 MFMA on the MLP projections when the shapes fit the 256x256x128 kernel and the GELU-output scales are
+    // FP8M: fp8 MFMA on all four projections when the shapes fit the 256x256x128 kernel and the activation scales are
     // calibrated; otherwise (and while calibrating) the block runs the SGPT_FP8W arithmetic (weights de-quantised to bf16)
-    bool mlp8 = fp8m && !m->calibrating && gemm_fp8_shape_ok(T, ffn, dm) && gemm_fp8_shape_ok(T, dm, ffn);
-    if (fp8m && !m->calibrating)
+    const bool shapes8 = gemm_fp8_shape_ok(T, ffn, dm) && gemm_fp8_shape_ok(T, dm, ffn) && gemm_fp8_shape_ok(T, 2 * dm, dm);
+    bool mlp8 = fp8m && !m->calibrating && shapes8;
+    if (mlp8)
         for (int li = 0; li < n_layers_run; ++li)
-            if (!(m->act_scale[li] > 0.f)) {
-                if (gemm_fp8_shape_ok(T, ffn, dm) && gemm_fp8_shape_ok(T, dm, ffn))
-                    return fail(c, SGPT_ERR_INVALID, "SGPT_FP8M: activation scales are not set (sgpt_model_calibrate_begin / _end, or sgpt_model_set_act_scales)");
-                mlp8 = false;
-            }
+            if (!(m->act_scale[li] > 0.f) || !(m->act_scale[m->d.n_layers + li] > 0.f))
+                return fail(c, SGPT_ERR_INVALID, "SGPT_FP8M: activation scales are not set (sgpt_model_calibrate_begin / _end, or sgpt_model_set_act_scales)");
     const size_t o_a8 = mlp8 ? carve((size_t)T * dm) : 0;                // FP8M: LayerNorm output as e4m3 codes
     const size_t o_sa = mlp8 ? carve((size_t)T * 4) : 0;                 //       + one scale per row
     const size_t o_lp = (layer_mean && !layer_out) ? carve((size_t)(m->d.n_layers + 1) * B * dm * 4) : 0;
@@ -462,7 +460,7 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     } else {
         HIPC(c, hipMemsetAsync((float*)qkv + (size_t)T * 3 * dm, 0, SLACK * 3 * dm * esz, s));
     }
-    if (gptj) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz, s));
+    if (gptj || mlp8) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz, s));   // (fp8: stale bytes would decode to NaN codes)
     launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, m->d.vocab, m->d.max_pos, s);
     if (m->emb_ln_g) launch_layernorm(x, m->emb_ln_g, m->emb_ln_b, x, SGPT_F32, T, dm, m->d.ln_eps, s);   // BLOOM :499
     for (int li = 0; li < n_layers_run; ++li) {
@@ -471,20 +469,14 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, 0, pool_mode,
                             normalize, m->pool_w, m->pool_w_n, layer_out + (size_t)li * B * dm, s);
         const void* w_fc8 = l.w_fc; const void* w_proj8 = l.w_proj;       // the e4m3 codes (FP8M feeds them to the MFMA directly)
-        if (fp8) {  // this block's weights: e4m3fn codes * 2^k -> bf16, exact; <1 % of the block's time at T >= 16k
+        const void* w_qkv8 = l.w_qkv; const void* w_o8 = l.w_o;
+        if (fp8 && !mlp8) {  // this block's weights: e4m3fn codes * 2^k -> bf16, exact; <1 % of the block's time at T >= 16k
             launch_fp8_dequant_rows(l.w_qkv, l.s_qkv, (long)3 * dm, dm, m->dq[0], SGPT_BF16, s);
             launch_fp8_dequant_rows(l.w_o, l.s_o, dm, dm, m->dq[1], SGPT_BF16, s);
-            l.w_qkv = m->dq[0]; l.w_o = m->dq[1];
-            if (!mlp8) {
-                launch_fp8_dequant_rows(l.w_fc, l.s_fc, ffn, dm, m->dq[2], SGPT_BF16, s);
-                launch_fp8_dequant_rows(l.w_proj, l.s_proj, dm, ffn, m->dq[3], SGPT_BF16, s);
-                l.w_fc = m->dq[2]; l.w_proj = m->dq[3];
-            }
+            launch_fp8_dequant_rows(l.w_fc, l.s_fc, ffn, dm, m->dq[2], SGPT_BF16, s);
+            launch_fp8_dequant_rows(l.w_proj, l.s_proj, dm, ffn, m->dq[3], SGPT_BF16, s);
+            l.w_qkv = m->dq[0]; l.w_o = m->dq[1]; l.w_fc = m->dq[2]; l.w_proj = m->dq[3];
         }
-        if (mlp8 && gptj)   // GPT-J: ln_1 feeds the attention projections (16 bit) AND the MLP (fp8 codes + row scales)
-            launch_layernorm_q8(x, l.ln1_g, l.ln1_b, base + o_a8, (float*)(base + o_sa), a, dt, T, dm, m->d.ln_eps, s);
-        else
-            launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
         GemmArgs g{};
         g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
         g.range_flag = dt == SGPT_F16 ? c->range_flag : nullptr;
@@ -492,6 +484,27 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         at.dtype = dt;
         at.seq_off = seq_off; at.B = B; at.H = H; at.dh = dh; at.window = l.is_local ? m->d.window : 0;
         at.scale = m->d.attn_scale; at.max_alloc_len = max_alloc; at.ctx = ctx; at.ldo = dm; at.alibi = m->alibi;
+        GemmArgs q{};      // fp8 projections
+        q.M = T; q.m_valid = T; q.range_flag = c->range_flag;
+        if (mlp8) {
+            // ---- attention projections on the fp8 MFMA: a8 = e4m3(LN1(x) / sa[row]) feeds Q, K (row-major bf16) and V^T ----
+            launch_layernorm_q8(x, l.ln1_g, l.ln1_b, base + o_a8, (float*)(base + o_sa), nullptr, dt, T, dm, m->d.ln_eps, s);
+            q.A = base + o_a8; q.lda = dm; q.a_scale = (const float*)(base + o_sa); q.a_scalar = 1.0f; q.K = dm; q.ldw = dm;
+            q.W = w_qkv8; q.w_scale = l.s_qkv; q.N = 2 * dm; q.bias = l.b_qkv; q.out = qkv; q.ldo = 2 * dm;
+            { Prof pr(c, s, 2.0 * T * 2.0 * dm * dm); launch_gemm_fp8(EPI_STORE, dt, q, s); }
+            q.W = (const uint8_t*)w_qkv8 + (size_t)2 * dm * dm; q.w_scale = l.s_qkv + 2 * dm; q.N = dm;
+            q.bias = l.b_qkv ? l.b_qkv + 2 * dm : nullptr; q.out = vt; q.ldo = T;
+            { Prof pr(c, s, 2.0 * T * (double)dm * dm); launch_gemm_fp8(EPI_VT, dt, q, s); }
+            if (gptj) launch_rope(qkv, dt, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
+            at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
+            at.out_fp8 = 1; at.out_scale = m->act_scale[m->d.n_layers + li]; at.range_flag = c->range_flag;
+            launch_attn_bf16(at, s);                         // context as e4m3 codes of ctx / s_c, [T][dm] bytes
+            q.A = ctx; q.lda = dm; q.a_scale = nullptr; q.a_scalar = m->act_scale[m->d.n_layers + li];
+            q.W = w_o8; q.w_scale = l.s_o; q.N = dm; q.K = dm; q.ldw = dm; q.bias = l.b_o; q.resid = x; q.out = x; q.ldo = dm;
+            { Prof pr(c, s, 2.0 * T * (double)dm * dm); launch_gemm_fp8(EPI_BIAS_RESID, 0, q, s); }
+            q.resid = nullptr;
+        } else {
+        launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
         if (bf) {
             // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]
             g.W = l.w_qkv; g.N = 2 * dm; g.out = qkv; g.ldo = 2 * dm; g.bias = l.b_qkv;            // bias: BLOOM only
@@ -502,6 +515,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             if (gptj) launch_rope(qkv, dt, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
             at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
             launch_attn_bf16(at, s);
+            if (m->calibrating)   // FP8M calibration: range of this block's attention context
+                launch_absmax16(ctx, (long)T * dm, dt, m->h_amax + m->d.n_layers + li, s);
         } else {
             g.W = l.w_qkv; g.N = 3 * dm; g.out = qkv; g.ldo = 3 * dm; g.bias = l.b_qkv;
             gemm(c, dt, EPI_STORE, SGPT_F32, g, s);
@@ -512,20 +527,19 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         // x += ctx . Wo^T (+ bo)
         g.A = ctx; g.W = l.w_o; g.N = dm; g.K = dm; g.ldw = dm; g.out = x; g.ldo = dm; g.bias = l.b_o; g.resid = x;
         gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
+        }
         // GPT-Neo: x += MLP(LN2(x));  GPT-J (parallel block, HF:gptj:400-411): x += MLP(LN1(x_old)), `a` still holds it
         if (mlp8) {
             // fp8 MFMA: a8 = e4m3(LN(x) / sa[row]);  h8 = e4m3(gelu(a8 . W1_8^T * sa * s1 + b1) / s_h);  x += h8 . W2_8^T * s_h * s2 + b2
             if (!gptj) launch_layernorm_q8(x, l.ln2_g, l.ln2_b, base + o_a8, (float*)(base + o_sa), nullptr, dt, T, dm, m->d.ln_eps, s);
-            GemmArgs q{};
-            q.M = T; q.m_valid = T; q.range_flag = c->range_flag;
             q.A = base + o_a8; q.lda = dm; q.a_scale = (const float*)(base + o_sa); q.a_scalar = 1.0f;
             q.W = w_fc8; q.ldw = dm; q.w_scale = l.s_fc; q.N = ffn; q.K = dm; q.bias = l.b_fc;
             q.out = h; q.ldo = ffn; q.out_scale = m->act_scale[li];
-            { Prof pr(c, s, 2.0 * T * (double)ffn * dm); launch_gemm_fp8(EPI_BIAS_GELU, q, s); }
+            { Prof pr(c, s, 2.0 * T * (double)ffn * dm); launch_gemm_fp8(EPI_BIAS_GELU, 0, q, s); }
             q.A = h; q.lda = ffn; q.a_scale = nullptr; q.a_scalar = m->act_scale[li];
             q.W = w_proj8; q.ldw = ffn; q.w_scale = l.s_proj; q.N = dm; q.K = ffn; q.bias = l.b_proj;
             q.resid = x; q.out = x; q.ldo = dm;
-            { Prof pr(c, s, 2.0 * T * (double)ffn * dm); launch_gemm_fp8(EPI_BIAS_RESID, q, s); }
+            { Prof pr(c, s, 2.0 * T * (double)ffn * dm); launch_gemm_fp8(EPI_BIAS_RESID, 0, q, s); }
         } else {
             if (!gptj) launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s);
             g.A = a; g.lda = dm; g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
@@ -594,7 +608,7 @@ sgpt_status sgpt_model_calibrate_begin(sgpt_model* m) {
     if (m->d.compute_dtype != SGPT_FP8M) return fail(c, SGPT_ERR_INVALID, "calibration applies to SGPT_FP8M models");
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipDeviceSynchronize());
-    HIPC(c, hipMemset(m->h_amax, 0, (size_t)m->d.n_layers * 4));
+    HIPC(c, hipMemset(m->h_amax, 0, (size_t)m->d.n_layers * 8));
     m->calibrating = true;
     return SGPT_OK;
 }
@@ -606,10 +620,11 @@ sgpt_status sgpt_model_calibrate_end(sgpt_model* m, float margin, float* scales_
     m->calibrating = false;
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipDeviceSynchronize());
-    std::vector<float> amax(m->d.n_layers);
-    HIPC(c, hipMemcpy(amax.data(), m->h_amax, (size_t)m->d.n_layers * 4, hipMemcpyDeviceToHost));
+    const int ns = 2 * m->d.n_layers;
+    std::vector<float> amax(ns);
+    HIPC(c, hipMemcpy(amax.data(), m->h_amax, (size_t)ns * 4, hipMemcpyDeviceToHost));
     if (!(margin >= 1.0f)) margin = 2.0f;
-    for (int i = 0; i < m->d.n_layers; ++i) {
+    for (int i = 0; i < ns; ++i) {
         // smallest power of two with margin * amax / scale <= 448 (head-room: later batches may exceed the sample's range;
         // a saturated code raises bit 1 of the range flag)
         const float need = amax[i] * margin / 448.0f;
@@ -624,7 +639,7 @@ sgpt_status sgpt_model_calibrate_end(sgpt_model* m, float margin, float* scales_
 sgpt_status sgpt_model_set_act_scales(sgpt_model* m, const float* scales, int32_t n) {
     if (!m) return SGPT_ERR_INVALID;
     sgpt_ctx* c = m->ctx;
-    if (m->d.compute_dtype != SGPT_FP8M || !scales || n != m->d.n_layers) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_act_scales: bad arguments");
+    if (m->d.compute_dtype != SGPT_FP8M || !scales || n != 2 * m->d.n_layers) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_act_scales: needs 2 * n_layers scales");
     for (int i = 0; i < n; ++i) {
         int e = 0;
         if (!(scales[i] > 0.f) || std::frexp(scales[i], &e) != 0.5f) return fail(c, SGPT_ERR_INVALID, "activation scales must be powers of two");
@@ -930,20 +945,24 @@ sgpt_status sgpt_layernorm_fp8(sgpt_ctx* c, const float* x, const float* gamma, 
     return SGPT_OK;
 }
 
-sgpt_status sgpt_linear_fp8(sgpt_ctx* c, int32_t epi, const uint8_t* A, const float* a_scale, float a_scalar, const uint8_t* W,
-                            const float* w_scale, const float* bias, const float* resid, void* out, float out_scale,
-                            int32_t M, int32_t N, int32_t K, void* stream) {
-    if (!c || !A || !W || !w_scale || !bias || !out || !(a_scalar > 0.f)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: bad arguments");
+sgpt_status sgpt_linear_fp8(sgpt_ctx* c, int32_t epi, int32_t out_dtype, const uint8_t* A, const float* a_scale, float a_scalar,
+                            const uint8_t* W, const float* w_scale, const float* bias, const float* resid, void* out,
+                            float out_scale, int32_t M, int32_t N, int32_t K, void* stream) {
+    if (!c || !A || !W || !w_scale || !out || !(a_scalar > 0.f)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: bad arguments");
     if (!gemm_fp8_shape_ok(M, N, K)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: M, N, K must be multiples of 256");
-    if (epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: epi 1 (bias+gelu -> fp8) or 2 (bias+residual -> fp32)");
+    if (epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID && epi != EPI_STORE && epi != EPI_VT)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: epi 0 (store 16-bit), 1 (bias+gelu -> fp8), 2 (bias+residual -> fp32) or 4 (transposed 16-bit)");
+    if ((epi == EPI_STORE || epi == EPI_VT) && out_dtype != SGPT_BF16 && out_dtype != SGPT_F16)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: store epilogues write bf16 or f16");
+    if ((epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID) && !bias) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: bias required");
     if (epi == EPI_BIAS_RESID && !resid) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: residual required");
     if (epi == EPI_BIAS_GELU && !(out_scale > 0.f)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_fp8: out_scale required");
     HIPC(c, hipSetDevice(c->device));
     GemmArgs q{};
-    q.A = A; q.lda = K; q.W = W; q.ldw = K; q.M = M; q.m_valid = M; q.N = N; q.K = K; q.out = out; q.ldo = N;
+    q.A = A; q.lda = K; q.W = W; q.ldw = K; q.M = M; q.m_valid = M; q.N = N; q.K = K; q.out = out; q.ldo = epi == EPI_VT ? M : N;
     q.bias = bias; q.resid = resid; q.a_scale = a_scale; q.a_scalar = a_scalar; q.w_scale = w_scale; q.out_scale = out_scale;
     q.range_flag = c->range_flag;
-    { Prof pr(c, (hipStream_t)stream, 2.0 * M * (double)N * K); launch_gemm_fp8(epi, q, (hipStream_t)stream); }
+    { Prof pr(c, (hipStream_t)stream, 2.0 * M * (double)N * K); launch_gemm_fp8(epi, out_dtype, q, (hipStream_t)stream); }
     HIPC(c, hipGetLastError());
     return SGPT_OK;
 }
@@ -995,9 +1014,9 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
         q.resid = (const float*)O; q.a_scale = sa; q.a_scalar = 1.0f; q.w_scale = sw; q.out_scale = 0.0625f;
         hipEvent_t e0, e1;
         HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) launch_gemm_fp8(epi, q, 0);
+        for (int i = 0; i < 3; ++i) launch_gemm_fp8(epi, out_dtype, q, 0);
         HIPC(c, hipEventRecord(e0, 0));
-        for (int i = 0; i < iters; ++i) launch_gemm_fp8(epi, q, 0);
+        for (int i = 0; i < iters; ++i) launch_gemm_fp8(epi, out_dtype, q, 0);
         HIPC(c, hipEventRecord(e1, 0));
         HIPC(c, hipEventSynchronize(e1));
         float ms = 0;

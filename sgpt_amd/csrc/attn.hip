@@ -41,7 +41,8 @@ constexpr bool ATTN_NT = SGPT_ATTN_NT != 0;
 //     Vs[DH][64 keys]   (same swizzle; ds_read_b64 pairs for the permuted k-slots)
 // and every wave takes its MFMA operands from there.  Same math / lane maps as above.
 // H = bf16_t | f16_t: the 16-bit format of q / k / V^T, of the probabilities fed to the P.V MFMA and of the context
-template <typename H, int DH>
+// OUT8: the context leaves as e4m3 codes of ctx / out_scale (fp8 out-projection operand) instead of the 16-bit format
+template <typename H, int DH, bool OUT8>
 __global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
     constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
     constexpr int NT = 512, QB = 128;                          // 8 waves x 16 queries per block
@@ -172,21 +173,41 @@ __global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_run;
     // O^T tile dt: lane holds head-dim elements dt*16 + 4g + r of query fr.  Transpose through a per-wave
-    // LDS slice so every store instruction writes whole 2*DH-byte rows with 16 B per lane (the direct
+    // LDS slice so every store instruction writes whole rows with 16 B per lane (the direct
     // 8-B-per-lane form wrote 3.6x the bytes: 32-B pieces of 16 different lines per instruction).
     char* os = Os[wave];
+    if constexpr (OUT8) {
+        constexpr int ORS8 = DH + 16, CPR8 = DH / 16, RPI8 = 64 / CPR8;
+        const float sc = inv / p.out_scale;
+        float amax = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-        *reinterpret_cast<uint2_a*>(os + fr * ORS + (dt * 16 + 4 * g) * 2) =
-            make_uint2(Half<H>::pack2(o[dt][0] * inv, o[dt][1] * inv), Half<H>::pack2(o[dt][2] * inv, o[dt][3] * inv));   // a convex
-    // combination of V rows: bounded by max|V|, which the V projection's epilogue already range-checked (f16)
-    constexpr int RPI = 64 / CPR;                    // rows per store instruction
-    bf16_t* obase = static_cast<bf16_t*>(p.ctx) + (long)(s0 + q0) * p.ldo + (long)head * DH;
+        for (int dt = 0; dt < DT; ++dt) {
+            const float v0 = o[dt][0] * sc, v1 = o[dt][1] * sc, v2 = o[dt][2] * sc, v3 = o[dt][3] * sc;
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
+            *reinterpret_cast<uint32_t*>(os + fr * ORS8 + dt * 16 + 4 * g) = pack_fp8x4(v0, v1, v2, v3);
+        }
+        if (p.range_flag != nullptr && !(amax <= 448.f)) atomicOr(p.range_flag, 2);
+        uint8_t* obase = static_cast<uint8_t*>(p.ctx) + (long)(s0 + q0) * p.ldo + (long)head * DH;
 #pragma unroll
-    for (int h = 0; h < 16 / RPI; ++h) {
-        const int row = h * RPI + lane / CPR, ch = lane % CPR;
-        const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
-        gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);
+        for (int h = 0; h < 16 / RPI8; ++h) {
+            const int row = h * RPI8 + lane / CPR8, ch = lane % CPR8;
+            const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS8 + ch * 16);
+            gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 16, v);
+        }
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            *reinterpret_cast<uint2_a*>(os + fr * ORS + (dt * 16 + 4 * g) * 2) =
+                make_uint2(Half<H>::pack2(o[dt][0] * inv, o[dt][1] * inv), Half<H>::pack2(o[dt][2] * inv, o[dt][3] * inv));   // a convex
+        // combination of V rows: bounded by max|V|, which the V projection's epilogue already range-checked (f16)
+        constexpr int RPI = 64 / CPR;                    // rows per store instruction
+        bf16_t* obase = static_cast<bf16_t*>(p.ctx) + (long)(s0 + q0) * p.ldo + (long)head * DH;
+#pragma unroll
+        for (int h = 0; h < 16 / RPI; ++h) {
+            const int row = h * RPI + lane / CPR, ch = lane % CPR;
+            const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
+            gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);
+        }
     }
 }
 
@@ -244,12 +265,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
 
 void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.max_alloc_len + 127) / 128, a.H, a.B);
-#define ATTN_CASE(H)                                                                                       \
-    if (a.dh == 64) hipLaunchKernelGGL((attn16_lds_kernel<H, 64>), grid, dim3(512), 0, s, a);              \
-    else if (a.dh == 128) hipLaunchKernelGGL((attn16_lds_kernel<H, 128>), grid, dim3(512), 0, s, a);       \
-    else if (a.dh == 256) hipLaunchKernelGGL((attn16_lds_kernel<H, 256>), grid, dim3(512), 0, s, a);       \
+#define ATTN_CASE(H, O8)                                                                                   \
+    if (a.dh == 64) hipLaunchKernelGGL((attn16_lds_kernel<H, 64, O8>), grid, dim3(512), 0, s, a);          \
+    else if (a.dh == 128) hipLaunchKernelGGL((attn16_lds_kernel<H, 128, O8>), grid, dim3(512), 0, s, a);   \
+    else if (a.dh == 256) hipLaunchKernelGGL((attn16_lds_kernel<H, 256, O8>), grid, dim3(512), 0, s, a);   \
     else abort();
-    if (a.dtype == DT_F16) { ATTN_CASE(f16_t) } else { ATTN_CASE(bf16_t) }
+    if (a.out_fp8) { ATTN_CASE(bf16_t, true) }
+    else if (a.dtype == DT_F16) { ATTN_CASE(f16_t, false) } else { ATTN_CASE(bf16_t, false) }
 #undef ATTN_CASE
 }
 

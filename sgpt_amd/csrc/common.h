@@ -44,6 +44,15 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
 }
 
+// four fp32 -> four OCP e4m3fn codes (RNE, v_cvt_pk_fp8_f32), saturating at +-448
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f); b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+    c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f); d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+
 // 16-bit operand format traits: H = bf16_t | f16_t
 template <typename H> struct Half;
 template <> struct Half<bf16_t> {
@@ -199,9 +208,10 @@ struct GemmArgs {
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
 int set_gemm_skew(int cycles);  // start-up stagger of the persistent 256^2 kernel (shader cycles per phase); returns the previous value
 int set_gemm_variant(int v);   // 0: 16x16x32-MFMA 256^2 kernel, 1: 32x32x16-MFMA one; returns the previous value
-// gemm256q.hip: fp8 (e4m3fn) x fp8 on v_mfma_f32_16x16x128_f8f6f4; epi = EPI_BIAS_GELU (fp8 out) | EPI_BIAS_RESID (fp32) | EPI_NONE
+// gemm256q.hip: fp8 (e4m3fn) x fp8 on v_mfma_f32_16x16x128_f8f6f4; epi = EPI_BIAS_GELU (fp8 out) | EPI_BIAS_RESID (fp32) |
+// EPI_STORE / EPI_VT (16-bit out) | EPI_NONE
 bool gemm_fp8_shape_ok(int M, int N, int K);
-void launch_gemm_fp8(int epi, const GemmArgs& a, hipStream_t s);
+void launch_gemm_fp8(int epi, int out_dtype, const GemmArgs& a, hipStream_t s);   // out_dtype: EPI_STORE / EPI_VT only
 // gemm256w.hip: the 256x256 LDS-DMA kernel on v_mfma_f32_32x32x16 (16-bit operands and outputs as gemm256d_kernel)
 void launch_gemm256w(int dtype, int epi, const GemmArgs& a, hipStream_t s, bool deep_a);
 
@@ -218,6 +228,11 @@ struct AttnArgs {
     int max_alloc_len;
     const float* alibi;  // [H] ALiBi slopes (BLOOM) or null: score += slope_h * key_index (HF:bloom:45-89)
     int dtype;           // DT_BF16 | DT_F16 (16-bit path)
+    // SGPT_FP8M: the context is written as e4m3 codes of ctx / out_scale ([T][ldo] bytes: the A operand of the fp8
+    // out-projection); a saturated code raises bit 1 of *range_flag
+    int out_fp8;
+    float out_scale;
+    int* range_flag;
 };
 void launch_attn_bf16(const AttnArgs& a, hipStream_t s);   // 16-bit MFMA path (bf16 or f16 by a.dtype)
 void launch_attn_f32(const AttnArgs& a, hipStream_t s);

@@ -36,16 +36,14 @@ __device__ __forceinline__ f32x4 mfma_f8(const uint4& a_lo, const uint4& a_hi, c
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);   // cbsz = blgp = 0: e4m3 x e4m3; zero scales: un-scaled opcode
 }
 
-// four fp32 -> four OCP e4m3fn codes (RNE), saturating at +-448
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-    a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f); b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
-    c = __builtin_fminf(__builtin_fmaxf(c, -448.f), 448.f); d = __builtin_fminf(__builtin_fmaxf(d, -448.f), 448.f);
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return (uint32_t)w;
-}
+constexpr bool RESID_NT = false, RESID_LD_NT = false;   // names used by the shared epilogue's fp32 branch (not instantiated here)
 
-template <int EPI, bool DEEP_A>
+template <typename OutT> struct OutRange { typedef RangeTrack<bf16_t> type; };
+template <> struct OutRange<f16_t> { typedef RangeTrack<f16_t> type; };
+
+// SWAP = true: weight fragment as the MFMA A-operand (a lane ends up with one token row and 4 consecutive n: row-major
+// outputs); SWAP = false: activation fragment as the A-operand (4 consecutive tokens for one n: the transposed V^T store)
+template <int EPI, typename OutT, bool SWAP, bool DEEP_A>
 __global__ __launch_bounds__(512, 2) void gemm256q_kernel(const GemmArgs p) {
     if (p.pred != nullptr && *p.pred == 0) return;
     typedef __attribute__((address_space(3))) char* lds_cptr_t;
@@ -185,8 +183,10 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(const GemmArgs p) {
                 for (int hh = 0; hh < 2; ++hh) {
                     const int i = 2 * pr + hh;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)   // weight fragment = A-operand: lane ends up with one token row and 4 consecutive n
-                        acc[i][j] = mfma_f8(wf[CB][j][0], wf[CB][j][1], af[pr & 1][hh][0], af[pr & 1][hh][1], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (SWAP) acc[i][j] = mfma_f8(wf[CB][j][0], wf[CB][j][1], af[pr & 1][hh][0], af[pr & 1][hh][1], acc[i][j]);
+                        else acc[i][j] = mfma_f8(af[pr & 1][hh][0], af[pr & 1][hh][1], wf[CB][j][0], wf[CB][j][1], acc[i][j]);
+                    }
                     if (pr < 2) {   // two 1-KiB DMA pieces behind every 4 MFMAs of the first half: shallow x4, then deep x4
                         const int q0 = 2 * (i & 1);
                         if (pr == 0) { piece(sp, sld, sloff, skt, s_dst, q0); piece(sp, sld, sloff, skt, s_dst, q0 + 1); }
@@ -217,6 +217,35 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { asm volatile("" ::"v"(acc[i][j])); acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 (void)scr;
+            } else if constexpr (EPI == EPI_STORE || EPI == EPI_VT) {
+                // 16-bit outputs (q / k row-major, V^T transposed): scale the accumulators in place, then the store
+                // epilogues of the 16-bit kernel (bias, pack, LDS transpose, whole-row non-temporal stores)
+                if constexpr (SWAP) {      // lane: row m = fr of block i, columns 4g .. 4g+3 of block j
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float sa = (p.a_scale ? p.a_scale[m0 + wm * 128 + i * 16 + fr] : 1.0f) * p.a_scalar;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float4 sw = *reinterpret_cast<const float4*>(p.w_scale + n0 + wn * 64 + j * 16 + 4 * g);
+                            acc[i][j][0] *= sa * sw.x; acc[i][j][1] *= sa * sw.y; acc[i][j][2] *= sa * sw.z; acc[i][j][3] *= sa * sw.w;
+                        }
+                    }
+                } else {                   // lane: rows m = 4g .. 4g+3 of block i, column n = fr of block j
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float sw = p.w_scale[n0 + wn * 64 + j * 16 + fr] * p.a_scalar;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            float4 sa = make_float4(1.f, 1.f, 1.f, 1.f);
+                            if (p.a_scale) sa = *reinterpret_cast<const float4*>(p.a_scale + m0 + wm * 128 + i * 16 + 4 * g);
+                            acc[i][j][0] *= sa.x * sw; acc[i][j][1] *= sa.y * sw; acc[i][j][2] *= sa.z * sw; acc[i][j][3] *= sa.w * sw;
+                        }
+                    }
+                }
+                OutT* out = static_cast<OutT*>(p.out);
+                typename OutRange<OutT>::type range;
+#include "gemm256_epilogue.inc"
+                range.finish(p.range_flag);
             } else {
                 // scales of this lane's accumulators: row factor (per i) x channel factor (per j, 4 consecutive n)
                 float4 sw[4];
@@ -296,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(const GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead DMA before the LDS is released
 }
 
-template <int EPI>
+template <int EPI, typename OutT, bool SWAP>
 void launch256q(const GemmArgs& a, hipStream_t s) {
     const int MT = a.M / 256, NT = a.N / 256;
     const int AT = MT >= NT ? MT : NT, BT = MT >= NT ? NT : MT;
@@ -310,19 +339,24 @@ void launch256q(const GemmArgs& a, hipStream_t s) {
     const int gm = b.gm > 0 ? b.gm : 4;
     const int tiles_pad = ((AT + 7) / 8 + gm - 1) / gm * gm * 8 * BT;
     const int grid = tiles_pad < ncu ? tiles_pad : ncu;
-    if (a.M >= a.N) hipLaunchKernelGGL((gemm256q_kernel<EPI, true>), dim3(grid), dim3(512), 0, s, b);
-    else hipLaunchKernelGGL((gemm256q_kernel<EPI, false>), dim3(grid), dim3(512), 0, s, b);
+    if (a.M >= a.N) hipLaunchKernelGGL((gemm256q_kernel<EPI, OutT, SWAP, true>), dim3(grid), dim3(512), 0, s, b);
+    else hipLaunchKernelGGL((gemm256q_kernel<EPI, OutT, SWAP, false>), dim3(grid), dim3(512), 0, s, b);
 }
 
 }  // namespace
 
-// fp8 (e4m3fn) operands, M % 256 == 0, N % 256 == 0, K % 256 == 0; epi: EPI_BIAS_GELU (fp8 out), EPI_BIAS_RESID (fp32 out), EPI_NONE
+// fp8 (e4m3fn) operands, M % 256 == 0, N % 256 == 0, K % 256 == 0; epi: EPI_BIAS_GELU (fp8 out), EPI_BIAS_RESID (fp32 out),
+// EPI_STORE / EPI_VT (out_dtype DT_BF16 | DT_F16, row-major / transposed), EPI_NONE
 bool gemm_fp8_shape_ok(int M, int N, int K) { return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 && K >= 256; }
 
-void launch_gemm_fp8(int epi, const GemmArgs& a, hipStream_t s) {
+void launch_gemm_fp8(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     if (!gemm_fp8_shape_ok(a.M, a.N, a.K)) abort();
-    if (epi == EPI_BIAS_GELU) return launch256q<EPI_BIAS_GELU>(a, s);
-    if (epi == EPI_BIAS_RESID) return launch256q<EPI_BIAS_RESID>(a, s);
-    if (epi == EPI_NONE) return launch256q<EPI_NONE>(a, s);
+    if (epi == EPI_BIAS_GELU) return launch256q<EPI_BIAS_GELU, bf16_t, true>(a, s);
+    if (epi == EPI_BIAS_RESID) return launch256q<EPI_BIAS_RESID, bf16_t, true>(a, s);
+    if (epi == EPI_NONE) return launch256q<EPI_NONE, bf16_t, true>(a, s);
+    if (epi == EPI_STORE && out_dtype == DT_F16) return launch256q<EPI_STORE, f16_t, true>(a, s);
+    if (epi == EPI_STORE) return launch256q<EPI_STORE, bf16_t, true>(a, s);
+    if (epi == EPI_VT && out_dtype == DT_F16) return launch256q<EPI_VT, f16_t, false>(a, s);
+    if (epi == EPI_VT) return launch256q<EPI_VT, bf16_t, false>(a, s);
     abort();
 }

@@ -249,8 +249,9 @@ class SGPTModel:
             self.set_position_weights(weights["position_weights"])
 
     def calibrate(self, seqs: Optional[Sequence[Sequence[int]]] = None, margin: float = 2.0) -> np.ndarray:
-        """dtype='fp8mfma': fix the per-block power-of-two scale of the GELU output's e4m3 codes from a calibration
-        forward (run in the fp8-storage / bf16-arithmetic mode while the library records max |gelu output| per block).
+        """dtype='fp8mfma': fix the per-block power-of-two scales of the e4m3 codes of the GELU output and of the attention
+        context from a calibration forward (run in the fp8-storage / bf16-arithmetic mode while the library records the two
+        maxima per block).  Returns the 2 * num_layers scales (GELU outputs, then contexts).
         Default sample: 64 deterministic pseudo-random sequences of 64 tokens (reproducible embeddings); pass
         representative token lists to calibrate on real text.  `margin` = head-room factor over the sample's maximum."""
         if self.dtype != "fp8mfma":
@@ -263,7 +264,7 @@ class SGPTModel:
         try:
             self.encode_ids(seqs)
         finally:
-            out = (C.c_float * self.cfg.num_layers)()
+            out = (C.c_float * (2 * self.cfg.num_layers))()
             _lib.check(self.ctx.handle, lib.sgpt_model_calibrate_end(self.handle, float(margin), out), "sgpt_model_calibrate_end")
         self.act_scales = np.array(list(out), dtype=np.float32)
         return self.act_scales

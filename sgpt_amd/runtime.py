@@ -186,14 +186,18 @@ class Context:
 
     def linear_fp8(self, a8: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias: torch.Tensor, epi: str,
                    a_scale: Optional[torch.Tensor] = None, a_scalar: float = 1.0, resid: Optional[torch.Tensor] = None,
-                   out_scale: float = 1.0) -> torch.Tensor:
-        """epi 'gelu': u8 codes of gelu_new(acc + bias) / out_scale;  'resid': fp32 resid + acc + bias."""
+                   out_scale: float = 1.0, out_dtype=None) -> torch.Tensor:
+        """epi 'gelu': u8 codes of gelu_new(acc + bias) / out_scale;  'resid': fp32 resid + acc + bias;
+        'store' / 'vt': 16-bit (out_dtype) acc (+ bias), row-major / transposed."""
         M, K = a8.shape
         N = w8.shape[0]
-        out = torch.empty((M, N), dtype=torch.uint8 if epi == "gelu" else torch.float32, device=self.device)
+        code = {"store": 0, "gelu": 1, "resid": 2, "vt": 4}[epi]
+        odt = {"gelu": torch.uint8, "resid": torch.float32}.get(epi, out_dtype if out_dtype is not None else torch.bfloat16)
+        out = torch.empty((N, M) if epi == "vt" else (M, N), dtype=odt, device=self.device)
         r = None if resid is None else resid.to(device=self.device, dtype=torch.float32).contiguous()
-        self._chk(self.lib.sgpt_linear_fp8(self.handle, 1 if epi == "gelu" else 2, _p(a8.contiguous()), _p(a_scale), a_scalar,
-                                           _p(w8.contiguous()), _p(w_scale.contiguous()), _p(bias.contiguous()), _p(r), _p(out),
+        b = None if bias is None else bias.contiguous()
+        self._chk(self.lib.sgpt_linear_fp8(self.handle, code, DT_CODE.get(odt, 0), _p(a8.contiguous()), _p(a_scale), a_scalar,
+                                           _p(w8.contiguous()), _p(w_scale.contiguous()), _p(b), _p(r), _p(out),
                                            out_scale, M, N, K, _stream_ptr(self.device)), "sgpt_linear_fp8")
         return out
 

@@ -45,7 +45,7 @@ def test_linear_fp8_equals_fp32_product_of_dequantised_operands(ctx, M, N, K):
     acc = dq(a8, sa) @ dq(w8, sw).T                        # exact products, fp32 accumulation
     tol = 1e-3 * math.sqrt(K / 64) * float(acc.abs().max())
     x = resid.clone()
-    ctx._chk(ctx.lib.sgpt_linear_fp8(ctx.handle, 2, a8.data_ptr(), sa.data_ptr(), 1.0, w8.data_ptr(), sw.data_ptr(), bias.data_ptr(),
+    ctx._chk(ctx.lib.sgpt_linear_fp8(ctx.handle, 2, 0, a8.data_ptr(), sa.data_ptr(), 1.0, w8.data_ptr(), sw.data_ptr(), bias.data_ptr(),
                                      x.data_ptr(), x.data_ptr(), 1.0, M, N, K, None), "sgpt_linear_fp8")     # in place
     assert float((x - (resid + acc + bias)).abs().max()) < tol
     # per-tensor A scale instead of per-row scales (the GELU-output operand of the second MLP projection)
@@ -64,6 +64,12 @@ def test_linear_fp8_equals_fp32_product_of_dequantised_operands(ctx, M, N, K):
     # one e4m3 step = 2^-3 relative (2^-9 * s_out absolute for subnormals); accumulation noise may flip a rounding
     step = torch.maximum(want.abs() * 2.0 ** -3, torch.tensor(2.0 ** -9 * s_out, device="cuda"))
     assert float(((got - want).abs() - step).max()) < tol and same > 0.98, same
+    # 16-bit store epilogues of the attention projections: row-major (+ bias) and transposed (V^T)
+    for odt, ulp in ((torch.bfloat16, 2.0 ** -8), (torch.float16, 2.0 ** -11)):
+        st = ctx.linear_fp8(a8, w8, sw, bias, "store", a_scale=sa, out_dtype=odt)
+        assert float(((st.float() - (acc + bias)).abs() - ulp * (acc + bias).abs()).max()) < tol
+        vt = ctx.linear_fp8(a8, w8, sw, None, "vt", a_scale=sa, out_dtype=odt)
+        assert vt.shape == (N, M) and float(((vt.float() - acc.T).abs() - ulp * acc.T.abs()).max()) < tol
     # saturation raises bit 1 of the range flag
     ctx.linear_fp8(a8, w8, sw, bias + 100.0, "gelu", a_scale=sa, out_scale=2.0 ** -8)
     assert ctx.range_check() == 2 and ctx.range_check() == 0
