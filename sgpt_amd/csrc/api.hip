@@ -772,7 +772,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // chunk the corpus so the fp32 score tile [nq, chunk] stays resident in the 256 MiB Infinity Cache, and so
     // that the score GEMM has a whole number of 256-CU waves of 256x256 tiles (query tiles x document tiles)
     const size_t budget = (size_t)160 << 20;
-    const int mtq = (nq + 255) / 256;
+    const int mtq = (nq + 255) / 256;                 // (short query batches, nq <= 64: one 64-row tile, see below)
     long unit = 256;                                  // documents per chunk granule
     { int g = mtq, h = 256; while (h) { int r = g % h; g = h; h = r; } unit = 256L * (256 / g); }
     long chunk = (long)(budget / ((size_t)nq * 4));
@@ -784,7 +784,9 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // never stored) and d % 64 == 0; chunks that are multiples of 256 documents take it, the ragged tail and
     // fp32 go through the 128^2 kernel.
     const bool fast = dtype != SGPT_F32 && d % 64 == 0 && d >= 128;
-    const int nq_pad = (nq + 255) / 256 * 256;
+    // nq <= 64: the 64-query-row scorer tile (score64_kernel) instead of 256 padded rows -- the pass is HBM-bound there
+    static const bool no_small_q = getenv("SGPT_SCORE_NO64") != nullptr;      // A/B switch
+    const int nq_pad = (fast && nq <= 64 && !no_small_q) ? 64 : (nq + 255) / 256 * 256;
     // Threshold-filtered chunks (after the first): see EPI_SCORE_FILTER.  Candidate capacity per query and chunk;
     // the doubling schedule below keeps the expected count at ~k.
     static const bool classic_only = getenv("SGPT_SCORE_CLASSIC") != nullptr;

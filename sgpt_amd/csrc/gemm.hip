@@ -502,6 +502,167 @@ void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Scorer tile for SHORT query batches (nq <= 64): 64 query rows x 256 documents per workgroup.
+// With the 256-row tile above a 16-query search pays for 256 padded query rows -- 16x the MFMA work of a pass that is
+// HBM-bound by nature (1 M x 768 x 2 B = 1.5 GB of corpus per pass: 0.3 ms at 5 TB/s; measured 0.76 ms).
+// Here a wave owns 32 documents (all 64 queries: 4 x 2 fragments, 16 MFMAs per k-step), the corpus streams through
+// the same three 32-KiB slots two k-steps ahead, the queries (8 KiB per k-step, L2-resident) through two small slots.
+// Scores leave the registers directly (one query row, 4 consecutive documents per lane): EPI_SCORE stores them,
+// EPI_SCORE_FILTER appends the ones above the running k-th best to the candidate lists.  Same MFMA sequence per
+// output element as every other kernel in this file.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
+    if (p.pred != nullptr && *p.pred == 0) return;
+    typedef __attribute__((address_space(3))) char* lds_cptr_t;
+    constexpr int DSLOT = 256 * CH, QSLOT = 64 * CH;                           // uint4 per slot
+    __shared__ __attribute__((aligned(16))) uint4 lds[3 * DSLOT + 2 * QSLOT];  // 96 + 16 KiB
+    const int K = p.K, nk = K / 64, NT = p.N / 256;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const bf16_t* __restrict__ Qg = static_cast<const bf16_t*>(p.A);          // [64][K] (padded query rows)
+    const bf16_t* __restrict__ Dg = static_cast<const bf16_t*>(p.W);          // [N][K] documents
+    const unsigned lds_base = (unsigned)(size_t)(lds_cptr_t)(&lds[0]);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int lchunk = (lane & 7) ^ (lane >> 3);
+    const unsigned q_loff = (unsigned)(((lane >> 3) * p.lda + lchunk * 8) * 2);
+    const unsigned d_loff = (unsigned)(((lane >> 3) * p.ldw + lchunk * 8) * 2);
+    auto dma16 = [&](const char* base_uniform, unsigned lane_off, unsigned dst_byte) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(lane_off), "s"(base_uniform), "s"(dst_byte)
+                     : "memory");
+    };
+    auto doc_pieces = [&](const bf16_t* dsrc, int kt, int slot) {             // this wave's own 32 document rows
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dma16(reinterpret_cast<const char*>(dsrc + (long)(wave_u * 32 + q * 8) * p.ldw + kt * 64), d_loff,
+                  lds_base + (unsigned)((slot * DSLOT + (wave_u * 32 + q * 8) * CH) * 16));
+    };
+    auto qry_piece = [&](int kt, int slot) {                                   // query rows 8w .. 8w+7
+        dma16(reinterpret_cast<const char*>(Qg + (long)(wave_u * 8) * p.lda + kt * 64), q_loff,
+              lds_base + (unsigned)((3 * DSLOT + slot * QSLOT + wave_u * 8 * CH) * 16));
+    };
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int tile = blockIdx.x;
+    if (tile >= NT) return;
+    const bf16_t* dsrc = Dg + (long)tile * 256 * p.ldw;
+    // prologue, in the order the waits assume: docs(0), queries(0), docs(1)
+    doc_pieces(dsrc, 0, 0);
+    qry_piece(0, 0);
+    doc_pieces(dsrc, 1, 1);
+    int sd = 0, ss = 0;
+    while (true) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < NT;
+        const bf16_t* ndsrc = has_next ? Dg + (long)ntile * 256 * p.ldw : dsrc;
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt has landed: everything but the newest four pieces (docs(kt+1)) is complete
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();                                   // ... for every wave; the slots of stage kt-1 are free
+            {   // prefetch: queries(kt+1) then docs(kt+2) -- across the tile boundary into the next tile's first steps
+                const bool q_in = kt + 1 < nk, d_in = kt + 2 < nk;
+                qry_piece(q_in ? kt + 1 : 0, ss ^ 1);
+                doc_pieces(d_in ? dsrc : ndsrc, d_in ? kt + 2 : kt + 2 - nk, sd + 2 >= 3 ? sd - 1 : sd + 2);
+            }
+            const uint4* lq = lds + 3 * DSLOT + ss * QSLOT;
+            const uint4* ld = lds + sd * DSLOT;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 qf[4], df[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wave * 32 + j * 16 + fr;
+                    df[j] = ld[row * CH + ((4 * ks + g) ^ (row & 7))];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 16 + fr;
+                    qf[i] = lq[row * CH + ((4 * ks + g) ^ (row & 7))];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma<T, true>(acc[i][j], qf[i], df[j]);   // document fragment = A-operand
+            }
+            ss ^= 1;
+            sd = sd + 1 >= 3 ? 0 : sd + 1;
+        }
+        // ---- epilogue, straight from the registers: lane = query row i*16 + fr, documents n0 + 32 w + 16 j + 4 g .. + 3 ----
+        const long n0 = (long)tile * 256 + wave * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = i * 16 + fr;
+            if constexpr (EPI == EPI_SCORE_FILTER) {
+                const float th = m < p.m_valid ? p.thr[(long)m * p.thr_ld] : INFINITY;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][r];
+                        v = v != v ? -1.0f : v;                      // cos_scores[isnan] = -1 (exact_search.py:99)
+                        acc[i][j][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                if (mx > th) {
+                    int c = 0;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) c += acc[i][j][r] > th ? 1 : 0;
+                    int slot = atomicAdd(p.cand_cnt + m, c);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[i][j][r];
+                            if (v > th) {
+                                if (slot < p.cand_cap) {
+                                    p.cand_val[(long)m * p.cand_cap + slot] = v;
+                                    p.cand_idx[(long)m * p.cand_cap + slot] = p.idx_base + n0 + j * 16 + 4 * g + r;
+                                }
+                                ++slot;
+                            }
+                        }
+                }
+            } else {
+                if (m < p.m_valid) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                        v.x = v.x != v.x ? -1.0f : v.x; v.y = v.y != v.y ? -1.0f : v.y;
+                        v.z = v.z != v.z ? -1.0f : v.z; v.w = v.w != v.w ? -1.0f : v.w;
+                        *reinterpret_cast<float4*>(static_cast<float*>(p.out) + (long)m * p.ldo + n0 + j * 16 + 4 * g) = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!has_next) break;
+        tile = ntile; dsrc = ndsrc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead DMA before the LDS is released
+}
+
+template <typename T, int EPI>
+void launch_score64(const GemmArgs& a, hipStream_t s) {
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    const int NT = a.N / 256;
+    hipLaunchKernelGGL((score64_kernel<T, EPI>), dim3(NT < ncu ? NT : ncu), dim3(512), 0, s, a);
+}
+
 template <typename T, int EPI, typename OutT, bool SWAP>
 void launch(const GemmArgs& a, hipStream_t s) {
     // 64x64 tiles when 128x128 ones would leave most of the 256 CUs idle (short query batches, USEB's 21-32 sentence
@@ -538,6 +699,11 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     const bool few = small_tiles && !(gemm_variant() & 2) && !scorer && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
     static const bool use256 = getenv("SGPT_GEMM128") == nullptr;
     const bool shape256 = a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128;
+    // short query batches: the 64-row scorer tile (M = 64 padded query rows, N % 256 == 0, K % 64 == 0, K >= 128)
+    if (scorer && a.M == 64 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128) {
+        if (epi == EPI_SCORE) return launch_score64<H, EPI_SCORE>(a, s);
+        return launch_score64<H, EPI_SCORE_FILTER>(a, s);
+    }
     if (epi == EPI_SCORE_FILTER && !shape256) abort();   // caller guarantees padded queries, N % 256 == 0, d % 64 == 0, d >= 128
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)

@@ -372,3 +372,26 @@ def test_score_topk_filtered_large_k(ctx, k):
     tv, _ = torch.topk(q.float() @ c.float().T, k, dim=1)
     assert torch.max(torch.abs(val - tv)).item() < 1e-3 * float(tv.abs().max())
     assert (val[:, :-1] >= val[:, 1:]).all() and (idx >= 7).all()
+
+
+@pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("nq", [1, 16, 33, 64])
+def test_score_topk_short_query_batches_use_the_64_row_tile_exactly(ctx, nq, dt16):
+    """nq <= 64 takes score64_kernel (64 query rows x 256 documents per workgroup) for the materialised first chunk and
+    the threshold-filtered chunks: identical values and indices to the 256-row path's answer for the same queries
+    (computed by padding the batch to 65 queries, which takes the 256-row tile), ragged tail included."""
+    d, N, k = 768, 200_037, 11
+    g = torch.Generator(device="cpu").manual_seed(nq)
+    q = torch.nn.functional.normalize(torch.randn(65, d, generator=g), dim=1).cuda().to(dt16)
+    base = torch.randn(1, d, generator=g) * 2
+    c = torch.nn.functional.normalize(base + torch.randn(N, d, generator=g), dim=1).cuda().to(dt16)
+    val, idx, n = ctx.score_topk(q[:nq].contiguous(), c, k, idx_base=3, dtype=dt16)
+    wv, wi, wn = ctx.score_topk(q, c, k, idx_base=3, dtype=dt16)            # 65 queries -> 256-row tile
+    assert n == wn == k
+    assert torch.equal(val, wv[:nq]) and torch.equal(idx, wi[:nq])
+    tv, ti = torch.topk(q[:nq].float() @ c.float().T, k, dim=1)
+    assert torch.max(torch.abs(val - tv)).item() < 1e-3
+    # running merge across calls with the small tile
+    v1, i1, n1 = ctx.score_topk(q[:nq].contiguous(), c[:70_000].contiguous(), k, idx_base=3, dtype=dt16)
+    v2, i2, n2 = ctx.score_topk(q[:nq].contiguous(), c[70_000:].contiguous(), k, idx_base=70_003, run=(v1, i1, n1), dtype=dt16)
+    assert torch.equal(v2, val) and torch.equal(i2, idx)
