@@ -77,6 +77,7 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sgpt_set_gemm_variant": (C.c_int32, [C.c_int32]),
     "sgpt_set_gemm_skew": (C.c_int32, [C.c_int32]),
+    "sgpt_set_gemm_kgroups": (C.c_int32, [C.c_int32]),
     "sgpt_bench_gemm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.POINTER(C.c_float)]),
     "sgpt_prof_enable": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -971,6 +971,7 @@ sgpt_status sgpt_linear_fp8(sgpt_ctx* c, int32_t epi, int32_t out_dtype, const u
 
 int32_t sgpt_set_gemm_variant(int32_t v) { return set_gemm_variant(v); }
 int32_t sgpt_set_gemm_skew(int32_t cycles) { return set_gemm_skew(cycles); }
+int32_t sgpt_set_gemm_kgroups(int32_t groups) { return set_gemm_kgroups(groups); }
 
 sgpt_status sgpt_linear(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out_dtype, const void* A, const void* W,
                         const float* bias, const float* resid, void* out, int32_t M, int32_t N, int32_t K, void* stream) {

@@ -207,6 +207,7 @@ struct GemmArgs {
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
 int set_gemm_skew(int cycles);  // start-up stagger of the persistent 256^2 kernel (shader cycles per phase); returns the previous value
+int set_gemm_kgroups(int g);    // 1: off; 2: k-groups for under-filled small-tile launches (gemm.hip); returns the previous value
 int set_gemm_variant(int v);   // 0: 16x16x32-MFMA 256^2 kernel, 1: 32x32x16-MFMA one; returns the previous value
 // gemm256q.hip: fp8 (e4m3fn) x fp8 on v_mfma_f32_16x16x128_f8f6f4; epi = EPI_BIAS_GELU (fp8 out) | EPI_BIAS_RESID (fp32) |
 // EPI_STORE / EPI_VT (16-bit out) | EPI_NONE

@@ -39,6 +39,9 @@ constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 #define SGPT_RESID_PF 0      // residual-epilogue prefetch distance in rounds (16 VGPRs each); 0, 1, 2 measured equal, 3 spills
 #endif
 constexpr int RESID_PF = SGPT_RESID_PF;
+#ifndef SGPT_SMALL_PF
+#define SGPT_SMALL_PF 2
+#endif
 constexpr int CH = 8;  // 16-byte chunks per row per k-step
 int g_skew = getenv("SGPT_SKEW") ? atoi(getenv("SGPT_SKEW")) : 0;     // start-up stagger of gemm256d_kernel, shader cycles per phase
 #ifndef SGPT_GEMM_W_DEFAULT
@@ -89,14 +92,27 @@ template <> struct OutRange<f16_t> { typedef RangeTrack<f16_t> type; };
 // NI = 16-row MFMA fragments per wave and dimension: 4 -> 128x128 tile (64x64 per wave), 2 -> 64x64 tile (32x32 per wave)
 // for problems too small to fill the chip with larger tiles.  Every GEMM kernel in this file feeds each output element the
 // same sequence of v_mfma_f32_16x16x32_bf16 operations (k ascending, same k-slot mapping) and the same epilogue
-// arithmetic, so the choice of kernel / tile never changes a bit of the result (batch invariance of the embeddings).
-template <typename T, int EPI, typename OutT, bool SWAP, int NI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+// arithmetic, so the choice of kernel / tile never changes a bit of the result (batch invariance of the embeddings) --
+// with the one opt-in exception of the k-groups below.
+//
+// KG = k-groups per workgroup (split-K inside the workgroup).  A query-sized launch has fewer tiles than the chip has
+// CUs and a long serial k-loop per tile (16 queries, fc2: 96 tiles x 48 k-steps, each step a load -> LDS -> MFMA
+// round trip of ~0.7 us that nothing overlaps).  With KG > 1 the workgroup carries KG groups of 4 waves, each with its
+// own double-buffered LDS stage, walking its own contiguous 1/KG of the k-steps concurrently; at the end groups 1..KG-1
+// park their fp32 accumulators in LDS and group 0 adds them in group order and runs the epilogue.  Deterministic (fixed
+// order, no atomics, nothing leaves the CU); the sum differs from the k-ascending one only by fp32 rounding.
+// (A split over several workgroups per tile with a ticket counter was tried first: the device-scope fences it needs
+// write back the XCD's L2 once per workgroup and cost 58 us per launch -- 4x slower than not splitting.)
+template <typename T, int EPI, typename OutT, bool SWAP, int NI, int KG>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const GemmArgs p) {
     constexpr int BM = 32 * NI, BN = 32 * NI;
     if (p.pred != nullptr && *p.pred == 0) return;   // predicated (fallback) launch that is not needed
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = CH * EPC;
-    __shared__ __attribute__((aligned(16))) uint4 lds[2][2][BM * CH];  // 64 KiB
+    static_assert(KG == 1 || NI == 2, "k-groups are for the 64x64 tile (32 KiB of LDS per group)");
+    __shared__ __attribute__((aligned(16))) uint4 lds_all[KG][2][2][BM * CH];  // 64 KiB (128x128) / 32 KiB per group (64x64)
+    const int kg = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
+    auto& lds = lds_all[kg];
 
     const int M = p.M, N = p.N, K = p.K;
     const int MT = (M + BM - 1) / BM, NT = (N + BN - 1) / BN;
@@ -116,10 +132,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     if (mt >= MT) return;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     const int lr = t >> 3, lc = t & 7;
     const T* __restrict__ Ag = static_cast<const T*>(p.A);
     const T* __restrict__ Wg = static_cast<const T*>(p.W);
+    // group kg covers k-steps [kb, kb + nk); the launcher picks KG > 1 only when the steps divide evenly, so every group
+    // runs the same number of barriers
+    const int nk = (K + BK - 1) / BK / KG;
+    const int kb = kg * nk;
 
     long arow[NI], wrow[NI];
 #pragma unroll
@@ -130,31 +150,45 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         wrow[i] = (long)rw * p.ldw;
     }
 
-    uint4 ra_[NI], rw_[NI];
-    auto gload = [&](int kt) {
+    // PF k-steps of global loads in flight per thread (register sets used round-robin).  The small-problem launches this
+    // kernel serves run <= 1 workgroup per CU, so nothing else hides the ~1.3 us global-load round trip: with one step
+    // in flight every k-step cost exactly that (fc2 at 512 tokens: 48 steps = 63 us for 2.4 GFLOP); with PF in flight
+    // the steady state is latency / PF.  Order of the MFMA operations per output element is unchanged (k ascending).
+    constexpr int PF = SGPT_SMALL_PF;
+    uint4 ra_[PF][NI], rw_[PF][NI];
+    auto gload = [&](int set, int kt) {
+        kt += kb;
         const int kc = kt * BK + lc * EPC;
         if (kt * BK + BK <= K) {  // block-uniform: full k-step (every encoder GEMM)
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                ra_[i] = *reinterpret_cast<const uint4*>(Ag + arow[i] + kc);
-                rw_[i] = *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc);
+                ra_[set][i] = *reinterpret_cast<const uint4*>(Ag + arow[i] + kc);
+                rw_[set][i] = *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc);
             }
         } else {  // K tail (scoring with d not a multiple of the k-step): zero-fill chunks past K
             const bool ok = kc < K;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                ra_[i] = ok ? *reinterpret_cast<const uint4*>(Ag + arow[i] + kc) : make_uint4(0, 0, 0, 0);
-                rw_[i] = ok ? *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc) : make_uint4(0, 0, 0, 0);
+                ra_[set][i] = ok ? *reinterpret_cast<const uint4*>(Ag + arow[i] + kc) : make_uint4(0, 0, 0, 0);
+                rw_[set][i] = ok ? *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc) : make_uint4(0, 0, 0, 0);
             }
         }
     };
-    auto lstore = [&](int buf) {
+    auto gload_full = [&](int set, int kt) {
+        const int kc = (kb + kt) * BK + lc * EPC;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            ra_[set][i] = *reinterpret_cast<const uint4*>(Ag + arow[i] + kc);
+            rw_[set][i] = *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc);
+        }
+    };
+    auto lstore = [&](int set, int buf) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int row = lr + 32 * i;
             const int off = row * CH + (lc ^ (row & 7));
-            lds[buf][0][off] = ra_[i];
-            lds[buf][1][off] = rw_[i];
+            lds[buf][0][off] = ra_[set][i];
+            lds[buf][1][off] = rw_[set][i];
         }
     };
 
@@ -189,16 +223,58 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         }
     };
 
-    const int nk = (K + BK - 1) / BK;
-    gload(0);
-    lstore(0);
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+        if (d < nk) gload(d, d);
+    lstore(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
-        compute(kt & 1);
-        if (more) lstore((kt + 1) & 1);
+    int k0 = 0;
+    // steady state: every step prefetches a full k-step and hands one to LDS -- no conditions inside, so the compiler's
+    // s_waitcnt placement stays counted (vmcnt(2 * NI * (PF - 1))) instead of collapsing to vmcnt(0) at block merges
+    for (; k0 + 2 * PF < nk; k0 += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {        // register-set indices are compile-time after unrolling
+            gload_full(d, k0 + d + PF);       // set d went to LDS during the previous step: free again
+            compute((k0 + d) & 1);
+            lstore((d + 1) % PF, (k0 + d + 1) & 1);
+            __syncthreads();
+        }
+    }
+    for (; k0 < nk; k0 += PF) {               // drain (and the K tail, if any)
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int kt = k0 + d;
+            if (kt < nk) {
+                if (kt + PF < nk) gload(d, kt + PF);
+                compute(kt & 1);
+                if (kt + 1 < nk) lstore((d + 1) % PF, (kt + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---------------- k-groups: group 0 collects the other groups' accumulators in group order ----------------
+    if constexpr (KG > 1) {
+        f32x4* stage = reinterpret_cast<f32x4*>(&lds_all[kg][0][0][0]);     // this group's LDS stage is free after the last barrier
+        if (kg != 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) stage[(i * NI + j) * 256 + t] = acc[i][j];
+        }
         __syncthreads();
+        if (kg != 0) return;
+#pragma unroll
+        for (int g2 = 1; g2 < KG; ++g2) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(&lds_all[g2][0][0][0]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const f32x4 u = src[(i * NI + j) * 256 + t];
+                    acc[i][j][0] += u[0]; acc[i][j][1] += u[1]; acc[i][j][2] += u[2]; acc[i][j][3] += u[3];
+                }
+        }
     }
 
     // ---------------- epilogue ----------------
@@ -663,6 +739,13 @@ void launch_score64(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((score64_kernel<T, EPI>), dim3(NT < ncu ? NT : ncu), dim3(512), 0, s, a);
 }
 
+// low-latency k-groups for under-filled small-tile launches: env SGPT_KGROUPS at first use, or sgpt_set_gemm_kgroups()
+int g_kgroups = -1;
+int gemm_kgroups() {
+    if (g_kgroups < 0) g_kgroups = getenv("SGPT_KGROUPS") ? atoi(getenv("SGPT_KGROUPS")) : 1;
+    return g_kgroups;
+}
+
 template <typename T, int EPI, typename OutT, bool SWAP>
 void launch(const GemmArgs& a, hipStream_t s) {
     // 64x64 tiles when 128x128 ones would leave most of the 256 CUs idle (short query batches, USEB's 21-32 sentence
@@ -674,8 +757,21 @@ void launch(const GemmArgs& a, hipStream_t s) {
     const int mt_per_xcd = (MT + 7) / 8;
     const int bands = (mt_per_xcd + 7) / 8;
     const int grid = 8 * bands * 8 * NT;
-    if (small) hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 2>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 4>), dim3(grid), dim3(256), 0, s, a);
+    // two k-groups (split-K inside the workgroup, see gemm_kernel) when the 64x64 tiles leave workgroup slots empty (two
+    // 512-thread workgroups fit a CU); each group keeps >= 3 k-steps.  Measured on a 16-query encode (512 token rows):
+    // 1.05 -> 0.88 ms; four groups (one 1024-thread workgroup per CU) gave 0.90.  OFF by default: it trades the
+    // bit-identical-across-batch-sizes property for latency (sgpt_set_gemm_kgroups / env SGPT_KGROUPS=2).
+    const int kgmax = gemm_kgroups();
+    constexpr bool splittable = EPI != EPI_SCORE && EPI != EPI_SCORE_FILTER;
+    const int nkt = (a.K + CH * ElemTraits<T>::EPC - 1) / (CH * ElemTraits<T>::EPC);
+    const long tiles = (long)MT * NT;
+    int KG = 1;
+    if (small && splittable && kgmax >= 2 && tiles <= 512 && nkt % 2 == 0 && nkt / 2 >= 3) KG = 2;
+    if constexpr (splittable) {
+        if (KG == 2) { hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 2, 2>), dim3(grid), dim3(512), 0, s, a); return; }
+    }
+    if (small) hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 2, 1>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 4, 1>), dim3(grid), dim3(256), 0, s, a);
 }
 
 // which 256x256 kernel runs: env SGPT_GEMM_W at first use, or sgpt_set_gemm_variant() (in-process A/B of the two
@@ -730,6 +826,7 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int set_gemm_variant(int v) { const int old = gemm_variant(); g_variant = v; return old; }
+int set_gemm_kgroups(int g) { const int old = gemm_kgroups(); g_kgroups = g < 1 ? 1 : g; return old; }
 int set_gemm_skew(int cycles) { const int old = g_skew; g_skew = cycles; return old; }
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {

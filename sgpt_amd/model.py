@@ -9,7 +9,7 @@ import itertools
 import json
 import os
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -84,6 +84,8 @@ class PackedBatch:
     max_alloc: int
     n_tokens: int  # real tokens (for throughput accounting)
     max_pos: int = 0  # largest position id (pad_left + len - 1): bounds the learntmean weight table
+    arena: Optional[torch.Tensor] = None  # the one int32 device buffer the five views above slice (graph replays refill it in one copy)
+    n_real: int = 0  # sequences that are the caller's (B minus the bucket's filler sequences)
 
 
 def _flatten(seqs, total: int) -> np.ndarray:
@@ -96,8 +98,11 @@ def _flatten(seqs, total: int) -> np.ndarray:
     return np.fromiter(itertools.chain.from_iterable(seqs), dtype=np.int32, count=total)
 
 
-def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None) -> dict:
-    """Sizes and offsets of the packed layout (no token data yet)."""
+def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None, bucket: Optional[Tuple[int, int, int]] = None) -> dict:
+    """Sizes and offsets of the packed layout (no token data yet).
+    bucket = (B_cap, T_cap, A_cap): pad the layout to that capacity -- B_cap - B one-token filler sequences behind the real
+    ones, T_pad = T_cap, max_alloc = A_cap -- so that every batch of the bucket launches the same grids (hipGraph replay).
+    The filler rows are computed and dropped; `n_real` says how many output rows are the caller's."""
     B = len(seqs)
     if isinstance(seqs, np.ndarray) and seqs.ndim == 2:
         lens = np.full(B, seqs.shape[1], dtype=np.int64)
@@ -105,13 +110,27 @@ def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None) -> dict:
         lens = np.fromiter(map(len, seqs), dtype=np.int64, count=B)
     if B == 0 or (lens <= 0).any():
         raise ValueError("Empty items should be cleaned prior to running")  # beir_dense_retriever.py:180-181
+    pl = np.zeros(B, dtype=np.int32) if pad_left is None else np.asarray(pad_left, dtype=np.int32)
+    n_real, n_tokens = B, int(lens.sum())
+    max_pos = int((lens + pl.astype(np.int64)).max()) - 1
+    if bucket is not None:
+        B_cap, T_cap, A_cap = bucket
+        if B_cap < B or T_cap % TOKEN_TILE or A_cap % ALIGN:
+            raise ValueError(f"bucket {bucket} cannot hold {B} sequences (T_cap % {TOKEN_TILE}, A_cap % {ALIGN})")
+        lens = np.concatenate([lens, np.ones(B_cap - B, dtype=np.int64)])
+        pl = np.concatenate([pl, np.zeros(B_cap - B, dtype=np.int32)])
+        B = B_cap
     alloc = (lens + ALIGN - 1) // ALIGN * ALIGN
     off = np.zeros(B + 1, dtype=np.int64)
     np.cumsum(alloc, out=off[1:])
     T_pad = (int(off[-1]) + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE
-    pl = np.zeros(B, dtype=np.int32) if pad_left is None else np.asarray(pad_left, dtype=np.int32)
-    return dict(B=B, lens=lens, alloc=alloc, off=off, T_pad=T_pad, pl=pl, n_tokens=int(lens.sum()),
-                max_alloc=int(alloc.max()), max_pos=int((lens + pl.astype(np.int64)).max()) - 1)
+    max_alloc = int(alloc.max())
+    if bucket is not None:
+        if T_pad > bucket[1] or max_alloc > bucket[2]:
+            raise ValueError(f"packed layout (T_pad {T_pad}, max_alloc {max_alloc}) does not fit bucket {bucket}")
+        T_pad, max_alloc = bucket[1], bucket[2]
+    return dict(B=B, lens=lens, alloc=alloc, off=off, T_pad=T_pad, pl=pl, n_tokens=n_tokens, n_real=n_real,
+                max_alloc=max_alloc, max_pos=max_pos)
 
 
 def arena_ints(lay: dict) -> int:
@@ -130,6 +149,10 @@ def fill_arena(seqs, lay: dict, arena: np.ndarray):
     flat = _flatten(seqs, n)
     if flat.shape[0] != n:
         raise ValueError("ragged token input does not match its lengths")
+    hi_lo = (int(flat.max()), int(flat.min()))
+    if B > lay["n_real"]:                                     # bucket fillers: one token (id 0) each
+        flat = np.concatenate([flat, np.zeros(B - lay["n_real"], dtype=np.int32)])
+        n = flat.shape[0]
     if (lens == lens[0]).all() and lens[0] % ALIGN == 0:      # rectangular, aligned: rows are already in place
         ids[:n] = flat
         pos[:n] = (np.arange(n, dtype=np.int64) % lens[0] + np.repeat(pl.astype(np.int64), lens)).astype(np.int32)
@@ -142,19 +165,20 @@ def fill_arena(seqs, lay: dict, arena: np.ndarray):
     arena[o: o + B + 1] = off
     arena[o + B + 1: o + 2 * B + 1] = lens
     arena[o + 2 * B + 1: o + 3 * B + 1] = pl
-    return int(flat.max()), int(flat.min())
+    return hi_lo
 
 
-def pack_host(seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None):
-    """Token lists -> numpy arrays of the packed layout (host side; the dict form used by tests and EncodeGraph)."""
-    lay = pack_layout(seqs, pad_left)
+def pack_host(seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None,
+              bucket: Optional[Tuple[int, int, int]] = None):
+    """Token lists -> numpy arrays of the packed layout (host side; the dict form used by tests)."""
+    lay = pack_layout(seqs, pad_left, bucket)
     arena = np.empty(arena_ints(lay), dtype=np.int32)
     fill_arena(seqs, lay, arena)
     B, T_pad = lay["B"], lay["T_pad"]
     o = 2 * T_pad
     return dict(ids=arena[:T_pad], pos=arena[T_pad:o], seq_off=arena[o: o + B + 1], seq_len=arena[o + B + 1: o + 2 * B + 1],
                 pad_left=arena[o + 2 * B + 1: o + 3 * B + 1], B=B, T_pad=T_pad, max_alloc=lay["max_alloc"],
-                n_tokens=lay["n_tokens"], max_pos=lay["max_pos"], arena=arena)
+                n_tokens=lay["n_tokens"], max_pos=lay["max_pos"], n_real=lay["n_real"], arena=arena)
 
 
 class _Staging:
@@ -307,23 +331,33 @@ class SGPTModel:
         return model
 
     # ---- packing ----
-    def pack(self, seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None) -> PackedBatch:
-        """Token lists -> device-resident packed batch: ONE pinned, non-blocking H2D copy of the whole layout."""
-        lay = pack_layout(seqs, pad_left)
+    def pack(self, seqs: Sequence[Sequence[int]], pad_left: Optional[Sequence[int]] = None,
+             bucket: Optional[Tuple[int, int, int]] = None, into: Optional[PackedBatch] = None) -> PackedBatch:
+        """Token lists -> device-resident packed batch: ONE pinned, non-blocking H2D copy of the whole layout.
+        bucket: pad the layout to a capacity (pack_layout); into: refill that batch's device arena (same bucket) instead of
+        allocating a new one -- the form hipGraph replays use, whose kernels hold the arena's addresses."""
+        lay = pack_layout(seqs, pad_left, bucket)
         if lay["max_alloc"] > 2048 or lay["max_pos"] >= self.cfg.max_position_embeddings:
             raise ValueError("sequence longer than max_position_embeddings")
         n_int = arena_ints(lay)
+        B, T = lay["B"], lay["T_pad"]
+        if into is not None and (into.arena is None or (into.B, into.T_pad, into.max_alloc) != (B, T, lay["max_alloc"])):
+            raise ValueError(f"packed layout {(B, T, lay['max_alloc'])} does not match the batch being refilled "
+                             f"{(into.B, into.T_pad, into.max_alloc)}")
         slot, host = self._staging.acquire(n_int)
         hi, lo = fill_arena(seqs, lay, host.numpy())
         if lo < 0 or hi >= self.cfg.vocab_size:
             raise ValueError(f"token id out of range [0, {self.cfg.vocab_size})")
-        dev = torch.empty(n_int, dtype=torch.int32, device=self.device)
+        dev = into.arena if into is not None else torch.empty(n_int, dtype=torch.int32, device=self.device)
         dev.copy_(host[:n_int], non_blocking=True)
         self._staging.release(slot)
-        B, T = lay["B"], lay["T_pad"]
+        if into is not None:
+            into.n_tokens, into.max_pos, into.n_real = lay["n_tokens"], lay["max_pos"], lay["n_real"]
+            return into
         o = 2 * T
         return PackedBatch(dev[:T], dev[T:o], dev[o: o + B + 1], dev[o + B + 1: o + 2 * B + 1],
-                           dev[o + 2 * B + 1: o + 3 * B + 1], B, T, lay["max_alloc"], lay["n_tokens"], lay["max_pos"])
+                           dev[o + 2 * B + 1: o + 3 * B + 1], B, T, lay["max_alloc"], lay["n_tokens"], lay["max_pos"],
+                           arena=dev, n_real=lay["n_real"])
 
     # ---- one C call: forward + pool ----
     def encode_packed(self, pb: PackedBatch, mode: str = "weightedmean", normalize: bool = False,
@@ -477,16 +511,22 @@ class SGPTModel:
 
 class EncodeGraph:
     """One sgpt_encode call captured as a hipGraph (via torch.cuda.CUDAGraph: every kernel and memset of the call
-    is issued on the capturing stream, nothing else) and replayed for new token ids of the same packed-layout
-    bucket (B, T_pad, max_alloc).  A 12-block forward is ~110 launches; for the small batches of the USEB
-    evaluators (21-32 sentences, useb/evaluators/base.py:33) and for query encoding the launches cost more than
-    the kernels, so replay removes most of the latency.  The workspace is sized by a warm-up call before capture
-    (hipMalloc is not capturable)."""
+    is issued on the capturing stream, nothing else) and replayed for new token ids: of the same packed layout
+    (B, T_pad, max_alloc), or -- with bucket=(B_cap, T_cap, A_cap) -- of any batch that fits that capacity (padded with
+    one-token filler sequences whose output rows are dropped, pack_layout).  Replay refills the captured token arena with
+    one pinned copy.  The workspace is sized by a warm-up call before capture (hipMalloc is not capturable).
+    What it buys, measured on MI355X: host time only.  A 12-block forward is ~110 launches; eager, the host enqueues them
+    in ~0.5 ms while the GPU needs 0.9-1.5 ms for a 16-32 query batch (each small kernel is a serial load -> LDS -> MFMA
+    chain), so GPU time is unchanged by replay (32 queries: 1.579 ms eager, 1.586 ms replay).  Use it when the host
+    thread is the scarce resource (many models / streams driven from one Python thread); the GPU-side latency of small
+    batches is addressed in the kernels (k-groups in gemm.hip)."""
 
     def __init__(self, model: "SGPTModel", seqs: Sequence[Sequence[int]], mode: str = "weightedmean",
-                 normalize: bool = False, layer_idx: int = -1, pad_left: Optional[Sequence[int]] = None):
+                 normalize: bool = False, layer_idx: int = -1, pad_left: Optional[Sequence[int]] = None,
+                 bucket: Optional[Tuple[int, int, int]] = None):
         self.model, self.mode, self.normalize, self.layer_idx = model, mode, normalize, layer_idx
-        self.pb = model.pack(seqs, pad_left)
+        self.capacity = bucket               # None: exact layouts only; else batches are padded to this capacity
+        self.pb = model.pack(seqs, pad_left, bucket)
         self.out = torch.empty((self.pb.B, model.cfg.hidden_size), dtype=torch.float32, device=model.device)
         self._capture()
 
@@ -509,14 +549,12 @@ class EncodeGraph:
     def replay(self, seqs: Optional[Sequence[Sequence[int]]] = None,
                pad_left: Optional[Sequence[int]] = None) -> torch.Tensor:
         """Re-run on new sentences whose packed layout falls in the same bucket (None: same inputs again).
-        The returned tensor is the graph's static output buffer."""
+        The returned tensor is the graph's static output buffer (rows past `pb.n_real` belong to bucket fillers)."""
         if seqs is not None:
-            h = pack_host(seqs, pad_left)
-            if (h["B"], h["T_pad"], h["max_alloc"]) != self.bucket:
-                raise ValueError(f"packed layout {(h['B'], h['T_pad'], h['max_alloc'])} is not this graph's bucket {self.bucket}")
-            for name in ("ids", "pos", "seq_off", "seq_len", "pad_left"):
-                getattr(self.pb, name).copy_(torch.from_numpy(h[name]), non_blocking=False)
-            self.pb.max_pos = h["max_pos"]
+            try:
+                self.model.pack(seqs, pad_left, self.capacity, into=self.pb)   # one pinned copy into the captured arena
+            except ValueError as e:
+                raise ValueError(f"{e}: not this graph's bucket {self.bucket}") from None
             self.model._check_learnt(self.mode, self.pb)
         if self.model.ctx.generation() != self.generation:
             self._capture()                      # the workspace / pooling table moved since capture: stale pointers

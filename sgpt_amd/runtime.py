@@ -125,6 +125,11 @@ class Context:
         """Changes when a library-owned buffer captured graphs point into was re-allocated (EncodeGraph)."""
         return int(self.lib.sgpt_ctx_generation(self.handle))
 
+    def set_low_latency(self, on: bool) -> bool:
+        """Process-wide: k-groups for query-sized GEMM launches (include/sgpt_hip.h::sgpt_set_gemm_kgroups): ~16 % off a
+        16-query encode, at the price of bit-identical embeddings across batch sizes.  Returns the previous setting."""
+        return int(self.lib.sgpt_set_gemm_kgroups(2 if on else 1)) > 1
+
     def reserve(self, encode_bytes: int = 0, score_bytes: int = 0) -> None:
         self._chk(self.lib.sgpt_ctx_reserve(self.handle, encode_bytes, score_bytes), "sgpt_ctx_reserve")
 

@@ -326,6 +326,16 @@ def test_encode_graph_capture_and_replay():
     assert not np.array_equal(got_b, m.encode_packed(m.pack(a), normalize=True).cpu().numpy())
     with pytest.raises(ValueError):
         g.replay(a[:-1])
+    # capacity bucket: any batch that fits (fewer / shorter / differently shaped sequences) replays the same graph
+    gb = EncodeGraph(m, a, normalize=True, bucket=(64, 2048, 64))
+    for n, hi in ((32, 33), (5, 60), (64, 17), (1, 2)):
+        q = [rng.integers(0, 50256, size=int(k)).tolist() for k in rng.integers(1, hi, size=n)]
+        got = gb.replay(q)[:n].cpu().numpy()
+        assert gb.pb.n_real == n and np.abs(got - m.encode_ids(q, normalize=True).cpu().numpy()).max() < 1e-6
+    with pytest.raises(ValueError):
+        gb.replay([rng.integers(0, 50256, size=70).tolist()])       # longer than the bucket's A_cap
+    with pytest.raises(ValueError):
+        gb.replay([[1, 2, 3]] * 65)                                 # more sequences than B_cap
     # latency of a 32-query batch: eager launches vs graph replay (reported, not asserted beyond sanity)
     pb = m.pack(a)
     torch.cuda.synchronize()

@@ -116,3 +116,53 @@ def test_f16_range_flag_raised_by_store_epilogue(ctx):
     assert ctx.range_check()
     ctx.linear(a[:256], w[:256], None, epi="vt")
     assert ctx.range_check()
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (512, 768, 3072), (512, 768, 768), (512, 3072, 768), (128, 1536, 768),
+                                   (3328, 768, 3072), (3328, 768, 768), (1024, 768, 2048 + 64)])
+def test_k_group_launches_are_deterministic_and_match_the_unsplit_kernel(ctx, dt, M, N, K):
+    """Query-sized launches (fewer 64x64 tiles than CUs, long k) run 2 or 4 k-groups per workgroup, each walking its own
+    part of the k range; group 0 adds the fp32 accumulators in group order (no atomics) and runs the epilogue.  So:
+    identical bits from run to run, and agreement with the un-split 256x256 kernel to accumulation-order noise, for
+    every epilogue, in place on the residual stream included.  (M = 3328: too many tiles, one group -- the control.)"""
+    a, w, bias, resid = operands(M, N, K, dt, seed=7 * M + N + K)
+    acc = a.float() @ w.float().T
+    scale = float(acc.abs().max())
+    tol32 = 1e-3 * math.sqrt(K / 64) * scale
+    off = ctx.linear(a, w, bias, epi="resid", resid=resid)          # mode off (default): one group
+    old_kg = ctx.lib.sgpt_set_gemm_kgroups(2)
+    try:
+        _k_group_checks(ctx, dt, M, N, K, a, w, bias, resid, acc, tol32, off)
+    finally:
+        ctx.lib.sgpt_set_gemm_kgroups(old_kg)
+
+
+def _k_group_checks(ctx, dt, M, N, K, a, w, bias, resid, acc, tol32, off):
+    runs = []
+    for rep in range(3):
+        x = resid.clone()
+        ctx._chk(ctx.lib.sgpt_linear(ctx.handle, 1 if dt == "bf16" else 3, 2, 0, a.data_ptr(), w.data_ptr(), bias.data_ptr(),
+                                     x.data_ptr(), x.data_ptr(), M, N, K, None), "sgpt_linear")
+        h = ctx.linear(a, w, bias, epi="gelu")
+        s = ctx.linear(a, w, bias, epi="store")
+        vt = ctx.linear(a, w, bias, epi="vt") if M % 128 == 0 else s
+        runs.append((x, h, s, vt))
+    for r in runs[1:]:
+        assert all(torch.equal(u, v) for u, v in zip(runs[0], r)), "k-group result changed between identical launches"
+    x, h, s, vt = runs[0]
+    assert float((x - (resid + acc + bias)).abs().max()) < tol32 + 1e-6 * float(resid.abs().max())
+    want = gelu_new(acc + bias)
+    assert float(((h.float() - want).abs() - ULP[dt] * want.abs()).max()) < tol32 + 2e-3 * (1.0 if dt == "bf16" else 0.25)
+    want = acc + bias
+    assert float(((s.float() - want).abs() - ULP[dt] * want.abs()).max()) < tol32
+    if M % 128 == 0:
+        assert float(((vt.float() - want.T).abs() - ULP[dt] * want.T.abs()).max()) < tol32
+    if M % 256 == 0 and N % 256 == 0 and K % 64 == 0:
+        old = ctx.lib.sgpt_set_gemm_variant(2)                       # 256x256 tiles, one workgroup per tile, k ascending
+        ref = ctx.linear(a, w, bias, epi="resid", resid=resid)
+        ctx.lib.sgpt_set_gemm_variant(old)
+        assert float((x - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+        assert torch.equal(off, ref), "with the mode off every kernel produces the k-ascending sum, bit for bit"
+        if M <= 1024:
+            assert not torch.equal(x, ref), "the k-group path did not run (the test would be vacuous)"

@@ -260,6 +260,34 @@ def test_crossencoder_host_logic_matches_oracle():
         model_input([1, 2, 3], list(range(50)), 48, 0)         # continuation longer than max_length
 
 
+def test_bucketed_layout_keeps_the_real_rows_and_appends_one_token_fillers():
+    """pack_layout(bucket=(B_cap, T_cap, A_cap)) (EncodeGraph capacity buckets): the caller's sequences sit exactly where
+    the un-bucketed layout puts them; fillers are one-token sequences on their own 16-row allocations behind them."""
+    from sgpt_amd.model import pack_host
+    rng = np.random.default_rng(0)
+    for n in (1, 11, 16, 17, 40):
+        seqs = [rng.integers(1, 100, size=int(rng.integers(1, 40))).tolist() for _ in range(n)]
+        h0 = pack_host(seqs)
+        al = [(len(q) + 15) // 16 * 16 for q in seqs]
+        b = (max(16, 1 << (n - 1).bit_length()), (sum(al) + 16 * 64 + 255) // 256 * 256, max(32, 1 << (max(al) - 1).bit_length()))
+        h = pack_host(seqs, bucket=b)
+        assert (h["B"], h["T_pad"], h["max_alloc"], h["n_real"], h["n_tokens"]) == (b[0], b[1], b[2], n, h0["n_tokens"])
+        assert (h["seq_off"][: n + 1] == h0["seq_off"]).all() and (h["seq_len"][:n] == h0["seq_len"]).all()
+        n0 = int(h0["seq_off"][-1])
+        assert (h["ids"][:n0] == h0["ids"][:n0]).all() and (h["pos"][:n0] == h0["pos"][:n0]).all()
+        assert (h["ids"][n0:] == 0).all() and (h["pos"][n0:] == 0).all()
+        assert (h["seq_len"][n:] == 1).all() and (np.diff(h["seq_off"][n:]) == 16).all() and h["seq_off"][-1] <= b[1]
+        pl = list(range(n))
+        h2 = pack_host(seqs, pl, bucket=b)
+        assert (h2["pad_left"][:n] == pl).all() and (h2["pad_left"][n:] == 0).all() and h2["max_pos"] == pack_host(seqs, pl)["max_pos"]
+    with pytest.raises(ValueError):
+        pack_host(seqs, bucket=(8, 1024, 64))          # fewer slots than sequences
+    with pytest.raises(ValueError):
+        pack_host(seqs, bucket=(64, 256, 64))          # token rows do not fit
+    with pytest.raises(ValueError):
+        pack_host(seqs, bucket=(64, 2048, 16))         # longest sequence does not fit
+
+
 def test_pack_arena_equals_reference_layout_for_every_input_form():
     """One-buffer packed layout (ids | pos | seq_off | seq_len | pad_left): lists, lists of ndarrays and a rectangular
     ndarray give the same image; rows land at seq_off[b] + t, positions are pad_left[b] + t, filler stays 0."""
