@@ -20,6 +20,8 @@ variants = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
 skews = [int(v) for v in os.environ.get("SKEWS", "0").split(",")]
 shapes = [("qk    store", 0, True, M, 1536, 768), ("v     vt   ", 4, True, M, 768, 768), ("oproj resid", 2, False, M, 768, 768),
           ("fc1   gelu ", 1, True, M, 3072, 768), ("fc2   resid", 2, False, M, 768, 3072), ("kloop none ", 5, True, M, 3072, 768)]
+if os.environ.get("SGPT_GEMM128") or (M // 256) * 3 * 2 <= 256:
+    shapes = [sh for sh in shapes if sh[1] != 5]      # the bare k-loop probe exists only in the 256x256 kernels
 if "--big" in sys.argv:
     shapes += [("1.3b fc1   ", 1, True, 65536, 8192, 2048), ("1.3b fc2   ", 2, False, 65536, 2048, 8192)]
 res = {}
