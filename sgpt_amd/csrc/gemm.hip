@@ -515,6 +515,20 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
                     for (int j = 0; j < 4; ++j) wf[0][j] = ld_w(nlw, 0, j);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef SGPT_PROBE_OVERLAP
+                // experiment (not in the product build): a store epilogue's worth of HBM writes (128 KiB per tile) issued
+                // from inside the k-loop of the no-store variant -- does the k-loop keep its rate with stores riding along?
+                if constexpr (EPI == EPI_NONE) {
+                    if (q == 3 || (q == 6 && kt % 3 == 0)) {
+                        char* dst = reinterpret_cast<char*>(p.out) + ((long)(m0 / 256) * (N / 256) + n0 / 256) * 131072;
+                        const int cnt = kt + (q == 6 ? nk + kt / 3 : 0);
+                        const long off = ((long)cnt * 8 + wave) * 1024 + lane * 16;
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 pv = {wf[0][0].x, wf[0][0].y, wf[0][0].z, wf[0][0].w};
+                        if (off < 131072) __builtin_nontemporal_store(pv, reinterpret_cast<u32x4*>(dst + off));
+                    }
+                }
+#endif
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int i = 2 * pr + h;
