@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "fp32", "fp8", "fp8mfma"],
                     help="16-bit MFMA operand format (f16: range-guarded, meets the 1e-3 parity bar; bf16); fp32 = exact-fp32 "
                          "MFMA; fp8 = e4m3fn weight storage (SURVEY 8d cfg5), bf16 arithmetic; fp8mfma = fp8 storage + fp8 MFMA "
-                         "(v_mfma_f32_16x16x128_f8f6f4) on the MLP projections")
+                         "(v_mfma_f32_16x16x128_f8f6f4) on all four projections of a block")
     ap.add_argument("--model", default="125m", choices=sorted(MODELS), help="SGPT size (default: the BASELINE metric's 125M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the queries/sec @ 1M-doc scoring leg")

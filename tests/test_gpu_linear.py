@@ -164,5 +164,5 @@ def _k_group_checks(ctx, dt, M, N, K, a, w, bias, resid, acc, tol32, off):
         ctx.lib.sgpt_set_gemm_variant(old)
         assert float((x - ref).abs().max()) < 2e-5 * float(ref.abs().max())
         assert torch.equal(off, ref), "with the mode off every kernel produces the k-ascending sum, bit for bit"
-        if M <= 1024:
+        if M <= 1024 and (K // 64) % 2 == 0:      # (K = 2112: 33 k-steps do not split evenly -> one group, the control)
             assert not torch.equal(x, ref), "the k-group path did not run (the test would be vacuous)"
