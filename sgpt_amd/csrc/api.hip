@@ -799,8 +799,10 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // the (rare) fallback recomputes with fewer, larger launches: its score tile may leave the Infinity Cache
     long fchunk = chunk;
     if (filt) {
+        // (its launches are enqueued on every call and exit at once when the flag is clear: ~3 us each, so few of them)
         fchunk = (long)(((size_t)1 << 30) / ((size_t)nq * 4)) / 256 * 256;
-        if (fchunk > 131072) fchunk = 131072;
+        if (fchunk > (1L << 20)) fchunk = 1L << 20;
+        if (fchunk > N) fchunk = (long)align_up((size_t)N, 256);
         if (fchunk < chunk) fchunk = chunk;
     }
     const size_t sc_bytes = align_up((size_t)nq * fchunk * 4, 256);
@@ -841,8 +843,16 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             g.A = q; g.lda = d; g.M = nq; g.m_valid = nq; g.K = d; g.pred = pred;
             g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = d; g.N = (int)nc;
             g.out = sc; g.ldo = chunk;
-            if (fast && nc % 256 == 0) { g.A = qpad; g.M = nq_pad; }
-            gemm(c, dtype, EPI_SCORE, SGPT_F32, g, s);
+            const long na = fast ? nc / 256 * 256 : 0;      // documents the 256-document tile kernels take
+            if (na > 0) {
+                GemmArgs h = g;
+                h.A = qpad; h.M = nq_pad; h.N = (int)na;
+                gemm(c, dtype, EPI_SCORE, SGPT_F32, h, s);
+            }
+            if (na < nc) {                                  // fp32, or the ragged tail (< 256 documents): register-staged kernel
+                g.W = (const char*)corpus + (size_t)(c0 + na) * d * esz; g.N = (int)(nc - na); g.out = sc + na;
+                gemm(c, dtype, EPI_SCORE, SGPT_F32, g, s);
+            }
             const bool last = c0 + nc >= hi;
             if (last && pv == fin_v) {  // in/out alias on a single-chunk call: stage through the ping-pong buffer
                 launch_topk_select(sc, chunk, nc, idx_base + c0, pv, pi, have, k, nq, k, 0, nullptr, tv[cur], ti[cur], s, pred);
@@ -892,12 +902,19 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             g.cand_val = cand_v; g.cand_idx = cand_i; g.cand_cnt = cand_cnt; g.cand_cap = cap; g.idx_base = idx_base + seen;
             gemm(c, dtype, EPI_SCORE_FILTER, SGPT_F32, g, s);
             seen += len;
+            if (seen == n256 && seen < N) {
+                // ragged tail (< 256 documents): filtered against the same thresholds by the small-tile kernel, its
+                // survivors join this chunk's candidate lists -- one merge, no materialise + select round for 72 documents
+                g.W = (const char*)corpus + (size_t)seen * d * esz; g.N = (int)(N - seen); g.idx_base = idx_base + seen;
+                gemm(c, dtype, EPI_SCORE_FILTER, SGPT_F32, g, s);
+                seen = N;
+            }
             const bool fin = seen >= N;
             launch_cand_merge(tv[cur], ti[cur], cand_v, (const int64_t*)cand_i, cand_cnt, cap, nq, k,
                               fin ? run_val : tv[cur ^ 1], fin ? run_idx : ti[cur ^ 1], flag, s);
             cur ^= 1;
         }
-        if (seen < N) {   // ragged tail (< 256 documents): materialise + select
+        if (seen < N) {   // (only when no filtered chunk ran: N - first < 256) ragged tail: materialise + select
             st = classic(seen, N, tv[cur], ti[cur], k, run_val, run_idx, nullptr, chunk);
             if (st != SGPT_OK) return st;
         }

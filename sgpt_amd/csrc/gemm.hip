@@ -281,7 +281,31 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
     OutT* __restrict__ out = static_cast<OutT*>(p.out);
     const int mv = p.m_valid;
     typename OutRange<OutT>::type range;
-    if constexpr (SWAP) {
+    if constexpr (EPI == EPI_SCORE_FILTER) {
+        // the ragged tail (< 256 documents) of a threshold-filtered scorer pass: same rule as the 256x256 kernel's epilogue
+        // (only scores STRICTLY above the query's running k-th best are appended; NaN -> -1 first), columns >= N masked
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int m = m0 + wm * (16 * NI) + i * 16 + fr;
+            if (m >= mv) continue;
+            const float th = p.thr[(long)m * p.thr_ld];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * (16 * NI) + j * 16 + 4 * g + r;
+                    float v = acc[i][j][r];
+                    v = v != v ? -1.0f : v;
+                    if (n < N && v > th) {
+                        const int slot = atomicAdd(p.cand_cnt + m, 1);
+                        if (slot < p.cand_cap) {
+                            p.cand_val[(long)m * p.cand_cap + slot] = v;
+                            p.cand_idx[(long)m * p.cand_cap + slot] = p.idx_base + n;
+                        }
+                    }
+                }
+        }
+    } else if constexpr (SWAP) {
         // lane: m = .. + fr ; n = .. + 4g + r  -> 4 consecutive n, row-major vector store
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -814,7 +838,7 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
         if (epi == EPI_SCORE) return launch_score64<H, EPI_SCORE>(a, s);
         return launch_score64<H, EPI_SCORE_FILTER>(a, s);
     }
-    if (epi == EPI_SCORE_FILTER && !shape256) abort();   // caller guarantees padded queries, N % 256 == 0, d % 64 == 0, d >= 128
+    if (epi == EPI_SCORE_FILTER && !shape256) return launch<H, EPI_SCORE_FILTER, float, true>(a, s);   // ragged document tail
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
         // variant 1: the 32x32x16-MFMA re-tiling of the same kernel (gemm256w.hip); 0: the 16x16x32 one below

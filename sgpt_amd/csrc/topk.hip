@@ -170,7 +170,22 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
             const bool vec_ok = ((reinterpret_cast<size_t>(r.sc) & 15) == 0);
             const long nv = vec_ok ? (n / 4) : 0;
             const float4* sc4 = reinterpret_cast<const float4*>(r.sc);
-            for (long i0 = 0; i0 < nv; i0 += 2 * TK_THREADS) {
+            // eight 16-byte loads per thread in flight: with few query rows (nq = 16: 16 workgroups on the chip) the pass
+            // is bound by one workgroup's memory-level parallelism (two loads in flight: 3 GB/s per row, 168 us for 125 k
+            // scores), not by bandwidth
+            constexpr int UL = 8;
+            long i0 = 0;
+            for (; i0 + (long)UL * TK_THREADS <= nv; i0 += (long)UL * TK_THREADS) {
+                float4 v[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) v[u] = sc4[i0 + (long)u * TK_THREADS + t];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const long ia = i0 + (long)u * TK_THREADS + t;
+                    take(v[u].x, 4 * ia); take(v[u].y, 4 * ia + 1); take(v[u].z, 4 * ia + 2); take(v[u].w, 4 * ia + 3);
+                }
+            }
+            for (; i0 < nv; i0 += 2 * TK_THREADS) {
                 const long ia = i0 + t, ib = ia + TK_THREADS;
                 float4 a = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), b = a;
                 if (ia < nv) a = sc4[ia];
