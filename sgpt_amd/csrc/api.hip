@@ -794,6 +794,9 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // (the threshold is the k-th best of `seen` documents); the merge sorts the candidates in 2048 LDS slots.
     const int cap = k <= 64 ? 256 : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
     const bool half_growth = 2 * cap < 5 * k;          // k > ~340: cap < 2.5 k -> grow by half, expect ~k/2 per chunk
+    // small k: the lists have room for several times k, so a chunk may be up to 4x everything seen before it (expected
+    // survivors k * growth <= cap / 4): a 1 M-document pass is 1 + 4 launches instead of 1 + 6, a 125 k shard 1 + 2
+    const int growth = cap / (4 * k) >= 4 ? 4 : (cap / (4 * k) >= 2 ? 2 : 1);
     const bool filt = fast && !classic_only && k <= 1024 && chunk % 256 == 0 && N >= 2 * chunk;
 
     // the (rare) fallback recomputes with fewer, larger launches: its score tile may leave the Infinity Cache
@@ -888,10 +891,11 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         int cur = 0;
         long seen = first;
         const long n256 = N / 256 * 256;
-        // doubling schedule: a filtered chunk is as long as everything seen before it, so a query expects ~k
-        // survivors per chunk (k * len / seen) whatever N is; 1 M documents = 1 + 5 launches instead of 31
+        // geometric schedule: a filtered chunk is `growth` times as long as everything seen before it (1, 2 or 4 by the
+        // room in the candidate lists), so a query expects ~k * growth survivors per chunk (k * len / seen) whatever N
+        // is; 1 M documents = 1 + 4 launches (k = 11) instead of 31
         while (n256 - seen >= 256) {
-            long len = half_growth ? (seen / 2 / 256 * 256 > 256 ? seen / 2 / 256 * 256 : 256) : seen;
+            long len = half_growth ? (seen / 2 / 256 * 256 > 256 ? seen / 2 / 256 * 256 : 256) : seen * growth;
             if (len > n256 - seen) len = n256 - seen;
             if (len > (1L << 19)) len = 1L << 19;
             if (len >= unit) len = len / unit * unit;
