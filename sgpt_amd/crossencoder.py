@@ -9,7 +9,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 import torch
 
-from .model import SGPTModel
+from .model import ALIGN, SGPTModel
 
 
 def encode(requests: Sequence[Tuple[str, str]], tokenizer):
@@ -48,8 +48,8 @@ def loglikelihood_tokens(requests, model: SGPTModel, max_length: int, instructio
     start = 0
     while start < len(order):
         tok, end = 0, start
-        while end < len(order) and (end == start or tok + (len(inps[order[end]]) + 15) // 16 * 16 <= max_tokens_per_call):
-            tok += (len(inps[order[end]]) + 15) // 16 * 16
+        while end < len(order) and (end == start or tok + (len(inps[order[end]]) + ALIGN - 1) // ALIGN * ALIGN <= max_tokens_per_call):
+            tok += (len(inps[order[end]]) + ALIGN - 1) // ALIGN * ALIGN
             end += 1
         sel = order[start:end]
         pb = model.pack([inps[i] for i in sel])

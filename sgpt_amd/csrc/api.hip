@@ -396,8 +396,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
                                float* out, float* hidden_out, float* layer_out, float* layer_mean, void* stream) {
     if (!m) return SGPT_ERR_INVALID;
     sgpt_ctx* c = m->ctx;
-    if (!ids || !pos || !seq_off || !seq_len || B <= 0 || T <= 0 || T % 128 || max_alloc <= 0 || max_alloc % 16)
-        return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad token layout (T_pad % 128, max_alloc_len % 16)");
+    if (!ids || !pos || !seq_off || !seq_len || B <= 0 || T <= 0 || T % 128 || max_alloc <= 0 || max_alloc % 8)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad token layout (T_pad % 128, max_alloc_len % 8)");
     if (n_layers_run < 0 || n_layers_run > m->d.n_layers) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: n_layers_run out of range");
     if (pool_mode < 0 || pool_mode > 3) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad pool_mode");
     if (pool_mode == SGPT_POOL_LEARNTMEAN && (out || layer_out || layer_mean)) {
@@ -794,9 +794,12 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // (the threshold is the k-th best of `seen` documents); the merge sorts the candidates in 2048 LDS slots.
     const int cap = k <= 64 ? 256 : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
     const bool half_growth = 2 * cap < 5 * k;          // k > ~340: cap < 2.5 k -> grow by half, expect ~k/2 per chunk
-    // small k: the lists have room for several times k, so a chunk may be up to 4x everything seen before it (expected
-    // survivors k * growth <= cap / 4): a 1 M-document pass is 1 + 4 launches instead of 1 + 6, a 125 k shard 1 + 2
-    const int growth = cap / (4 * k) >= 4 ? 4 : (cap / (4 * k) >= 2 ? 2 : 1);
+    // Chunks grow by doubling even where the lists would hold more (k = 11: cap = 23 k): growing 4x per chunk was measured
+    // (-10 % at nq = 128) and rejected -- the expected count k * len / seen assumes exchangeable document order, and a corpus
+    // whose score distribution drifts along the index (the reference sorts documents by length, exact_search.py:66-71;
+    // bench.py's 1 M shard starts with its variable-length documents) then overflows the lists and pays the 12x slower
+    // materialised recomputation.  Doubling keeps 23x head-room over the expectation.
+    const int growth = 1;
     const bool filt = fast && !classic_only && k <= 1024 && chunk % 256 == 0 && N >= 2 * chunk;
 
     // the (rare) fallback recomputes with fewer, larger launches: its score tile may leave the Infinity Cache
@@ -891,9 +894,8 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         int cur = 0;
         long seen = first;
         const long n256 = N / 256 * 256;
-        // geometric schedule: a filtered chunk is `growth` times as long as everything seen before it (1, 2 or 4 by the
-        // room in the candidate lists), so a query expects ~k * growth survivors per chunk (k * len / seen) whatever N
-        // is; 1 M documents = 1 + 4 launches (k = 11) instead of 31
+        // doubling schedule: a filtered chunk is as long as everything seen before it, so a query expects ~k
+        // survivors per chunk (k * len / seen) whatever N is; 1 M documents = 1 + 5 launches instead of 31
         while (n256 - seen >= 256) {
             long len = half_growth ? (seen / 2 / 256 * 256 > 256 ? seen / 2 / 256 * 256 : 256) : seen * growth;
             if (len > n256 - seen) len = n256 - seen;

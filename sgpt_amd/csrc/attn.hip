@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
         for (int h = 0; h < 16 / RPI8; ++h) {
             const int row = h * RPI8 + lane / CPR8, ch = lane % CPR8;
             const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS8 + ch * 16);
-            gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 16, v);
+            if (q0 + row < alloc) gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 16, v);   // rows past the allocation are the next sequence's
         }
     } else {
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
         for (int h = 0; h < 16 / RPI; ++h) {
             const int row = h * RPI + lane / CPR, ch = lane % CPR;
             const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
-            gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);
+            if (q0 + row < alloc) gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);   // (allocations are multiples of 8 rows)
         }
     }
 }

@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F16, SGPT_F32, SGPT_FP8M, SGPT_FP8W, SgptRangeError
 from .runtime import Context, get_context, _p, _stream_ptr
 
-ALIGN = 16         # sequence starts on the packed token axis (MFMA 16-row tiles; V^T 8-byte loads)
+ALIGN = 8          # sequence starts on the packed token axis: multiples of 8 rows (16-byte V^T tile loads in attention)
 TOKEN_TILE = 256   # GEMM M tile (256x256 LDS-DMA kernel)
 
 
