@@ -9,7 +9,11 @@ nq, N, d, k = int(os.environ.get("NQ", 1000)), int(os.environ.get("N", 1000000))
 DT = torch.bfloat16 if os.environ.get("DT", "f16") == "bf16" else torch.float16
 g = torch.Generator(device="cuda").manual_seed(0)
 base = torch.randn(1, d, device="cuda", generator=g) * 3          # anisotropic: shared dominant direction
-c = torch.nn.functional.normalize(base + torch.randn(N, d, device="cuda", generator=g), dim=1).to(DT)
+cf = base + torch.randn(N, d, device="cuda", generator=g)
+if os.environ.get("DRIFT"):      # score distribution jumps at this fraction of the corpus (documents behind it score higher)
+    cf[int(float(os.environ["DRIFT"]) * N):] += 2.0 * base
+c = torch.nn.functional.normalize(cf, dim=1).to(DT)
+del cf
 q = torch.nn.functional.normalize(base + torch.randn(nq, d, device="cuda", generator=g), dim=1).to(DT)
 for _ in range(2):
     ctx.score_topk(q, c, k, dtype=DT)

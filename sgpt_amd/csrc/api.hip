@@ -802,20 +802,16 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     const int growth = 1;
     const bool filt = fast && !classic_only && k <= 1024 && chunk % 256 == 0 && N >= 2 * chunk;
 
-    // the (rare) fallback recomputes with fewer, larger launches: its score tile may leave the Infinity Cache
-    long fchunk = chunk;
-    if (filt) {
-        // (its launches are enqueued on every call and exit at once when the flag is clear: ~3 us each, so few of them)
-        fchunk = (long)(((size_t)1 << 30) / ((size_t)nq * 4)) / 256 * 256;
-        if (fchunk > (1L << 20)) fchunk = 1L << 20;
-        if (fchunk > N) fchunk = (long)align_up((size_t)N, 256);
-        if (fchunk < chunk) fchunk = chunk;
-    }
+    // A filtered chunk whose candidate lists overflow is recomputed by materialise + select, in pieces of `chunk`
+    // documents like the un-filtered loop: the score tile stays in the Infinity Cache (measured: 1 GiB tiles made the
+    // recomputation 6x slower than the plain materialised loop).  Its launches are predicated and exit at once otherwise.
+    const long fchunk = chunk;
+    const long n_flags = 64 + N / (1L << 19) + 1;      // one overflow flag per filtered chunk (doubling, then 2^19 each)
     const size_t sc_bytes = align_up((size_t)nq * fchunk * 4, 256);
     const size_t tv_bytes = align_up((size_t)nq * k * 4, 256), ti_bytes = align_up((size_t)nq * k * 8, 256);
     const size_t qp_bytes = fast ? align_up((size_t)nq_pad * d * 2, 256) : 0;
     const size_t cv_bytes = filt ? align_up((size_t)nq * cap * 4, 256) : 0, ci_bytes = filt ? align_up((size_t)nq * cap * 8, 256) : 0;
-    const size_t cc_bytes = filt ? align_up((size_t)(nq_pad + 1) * 4, 256) : 0;        // counters + overflow flag
+    const size_t cc_bytes = filt ? align_up((size_t)(nq_pad + n_flags) * 4, 256) : 0;  // counters + per-chunk overflow flags
     st = ensure(c, &c->ws2, &c->ws2_bytes,
                 sc_bytes + 3 * (tv_bytes + ti_bytes) + qp_bytes + cv_bytes + ci_bytes + cc_bytes);
     if (st != SGPT_OK) return st;
@@ -826,7 +822,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     float* tv[2]; int64_t* ti[2];
     tv[0] = (float*)take(tv_bytes); tv[1] = (float*)take(tv_bytes);
     ti[0] = (int64_t*)take(ti_bytes); ti[1] = (int64_t*)take(ti_bytes);
-    float* sav_v = (float*)take(tv_bytes); int64_t* sav_i = (int64_t*)take(ti_bytes);   // incoming running best (fallback)
+    float* sav_v = (float*)take(tv_bytes); int64_t* sav_i = (int64_t*)take(ti_bytes);   // third list: ping-pong partner of a recomputation
     void* qpad = fast ? take(qp_bytes) : nullptr;
     float* cand_v = filt ? (float*)take(cv_bytes) : nullptr;
     long long* cand_i = filt ? (long long*)take(ci_bytes) : nullptr;
@@ -838,6 +834,23 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     }
     const size_t esz = dtype == SGPT_F32 ? 4 : 2;
 
+    // fp32 scores of documents [c0, c0 + nc) for every query -> sc[nq][ld]
+    auto score_tile = [&](long c0, long nc, long ld, const int* pred) {
+        GemmArgs g{};
+        g.A = q; g.lda = d; g.M = nq; g.m_valid = nq; g.K = d; g.pred = pred;
+        g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = d; g.N = (int)nc;
+        g.out = sc; g.ldo = ld;
+        const long na = fast ? nc / 256 * 256 : 0;      // documents the 256-document tile kernels take
+        if (na > 0) {
+            GemmArgs h = g;
+            h.A = qpad; h.M = nq_pad; h.N = (int)na;
+            gemm(c, dtype, EPI_SCORE, SGPT_F32, h, s);
+        }
+        if (na < nc) {                                  // fp32, or the ragged tail (< 256 documents): register-staged kernel
+            g.W = (const char*)corpus + (size_t)(c0 + na) * d * esz; g.N = (int)(nc - na); g.out = sc + na;
+            gemm(c, dtype, EPI_SCORE, SGPT_F32, g, s);
+        }
+    };
     // Materialise-and-select over documents [lo, hi): the reference's chunk loop (exact_search.py:96-132).
     // (pv, pi, have) = running best going in; the last chunk writes (fin_v, fin_i), earlier ones ping-pong.
     auto classic = [&](long lo, long hi, const float* pv, const int64_t* pi, int have, float* fin_v, int64_t* fin_i,
@@ -845,20 +858,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         int cur = (pv == tv[0]) ? 1 : 0;
         for (long c0 = lo; c0 < hi; c0 += chunk) {
             const long nc = (hi - c0) < chunk ? (hi - c0) : chunk;
-            GemmArgs g{};
-            g.A = q; g.lda = d; g.M = nq; g.m_valid = nq; g.K = d; g.pred = pred;
-            g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = d; g.N = (int)nc;
-            g.out = sc; g.ldo = chunk;
-            const long na = fast ? nc / 256 * 256 : 0;      // documents the 256-document tile kernels take
-            if (na > 0) {
-                GemmArgs h = g;
-                h.A = qpad; h.M = nq_pad; h.N = (int)na;
-                gemm(c, dtype, EPI_SCORE, SGPT_F32, h, s);
-            }
-            if (na < nc) {                                  // fp32, or the ragged tail (< 256 documents): register-staged kernel
-                g.W = (const char*)corpus + (size_t)(c0 + na) * d * esz; g.N = (int)(nc - na); g.out = sc + na;
-                gemm(c, dtype, EPI_SCORE, SGPT_F32, g, s);
-            }
+            score_tile(c0, nc, chunk, pred);
             const bool last = c0 + nc >= hi;
             if (last && pv == fin_v) {  // in/out alias on a single-chunk call: stage through the ping-pong buffer
                 launch_topk_select(sc, chunk, nc, idx_base + c0, pv, pi, have, k, nq, k, 0, nullptr, tv[cur], ti[cur], s, pred);
@@ -875,23 +875,36 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         return SGPT_OK;
     };
 
+    // The same over [lo, hi) with every launch predicated on *pred (a filtered chunk's overflow flag): (pv, pi) = the
+    // k-slot running best before the chunk, result in (fin_v, fin_i); pieces of fchunk documents ping-pong through the
+    // third list so that nothing is copied (a copy could not be predicated).
+    auto recompute = [&](long lo, long hi, const float* pv, const int64_t* pi, float* fin_v, int64_t* fin_i, const int* pred) {
+        const long P = (hi - lo + fchunk - 1) / fchunk;
+        for (long pc = 0; pc < P; ++pc) {
+            const long c0 = lo + pc * fchunk, nc = (hi - c0) < fchunk ? (hi - c0) : fchunk;
+            const bool to_fin = (P - 1 - pc) % 2 == 0;
+            float* dv = to_fin ? fin_v : sav_v;
+            int64_t* di = to_fin ? fin_i : sav_i;
+            score_tile(c0, nc, fchunk, pred);
+            launch_topk_select(sc, fchunk, nc, idx_base + c0, pv, pi, k, k, nq, k, 0, nullptr, dv, di, s, pred);
+            pv = dv; pi = di;
+        }
+    };
+
     const float* pv0 = n_run > 0 ? run_val : nullptr;
     const int64_t* pi0 = n_run > 0 ? run_idx : nullptr;
     if (!filt) {
         st = classic(0, N, pv0, pi0, n_run, run_val, run_idx, nullptr, chunk);
         if (st != SGPT_OK) return st;
     } else {
-        HIPC(c, hipMemsetAsync(cand_cnt, 0, (size_t)(nq_pad + 1) * 4, s));
-        if (n_run > 0) {
-            HIPC(c, hipMemcpyAsync(sav_v, run_val, (size_t)nq * k * 4, hipMemcpyDeviceToDevice, s));
-            HIPC(c, hipMemcpyAsync(sav_i, run_idx, (size_t)nq * k * 8, hipMemcpyDeviceToDevice, s));
-        }
+        HIPC(c, hipMemsetAsync(cand_cnt, 0, (size_t)(nq_pad + n_flags) * 4, s));
+        static const bool no_fallback = getenv("SGPT_SCORE_NOFALLBACK") != nullptr;   // timing experiments ONLY: unsafe
         // first chunk: materialise + select -> the initial thresholds.  One whole wave of tiles is enough (the
         // doubling schedule takes over from there): 16 384 documents for nq = 1000 instead of 32 768
         const long first = unit < chunk ? unit : chunk;
         st = classic(0, first, pv0, pi0, n_run, tv[0], ti[0], nullptr, chunk);
         if (st != SGPT_OK) return st;
-        int cur = 0;
+        int cur = 0, chunk_i = 0;
         long seen = first;
         const long n256 = N / 256 * 256;
         // doubling schedule: a filtered chunk is as long as everything seen before it, so a query expects ~k
@@ -907,6 +920,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             g.thr = tv[cur] + (k - 1); g.thr_ld = k;
             g.cand_val = cand_v; g.cand_idx = cand_i; g.cand_cnt = cand_cnt; g.cand_cap = cap; g.idx_base = idx_base + seen;
             gemm(c, dtype, EPI_SCORE_FILTER, SGPT_F32, g, s);
+            const long c_lo = seen;
             seen += len;
             if (seen == n256 && seen < N) {
                 // ragged tail (< 256 documents): filtered against the same thresholds by the small-tile kernel, its
@@ -916,20 +930,22 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
                 seen = N;
             }
             const bool fin = seen >= N;
-            launch_cand_merge(tv[cur], ti[cur], cand_v, (const int64_t*)cand_i, cand_cnt, cap, nq, k,
-                              fin ? run_val : tv[cur ^ 1], fin ? run_idx : ti[cur ^ 1], flag, s);
+            int* cflag = flag + (chunk_i < n_flags ? chunk_i : n_flags - 1);
+            float* ov = fin ? run_val : tv[cur ^ 1];
+            int64_t* oi = fin ? run_idx : ti[cur ^ 1];
+            launch_cand_merge(tv[cur], ti[cur], cand_v, (const int64_t*)cand_i, cand_cnt, cap, nq, k, ov, oi, cflag, s);
+            // A candidate list of this chunk overflowed (document order with a drifting score distribution, a mass of
+            // equal scores): the merge result is incomplete -- redo THIS chunk from the pre-chunk best by materialise +
+            // select.  Sync-free: predicated on the chunk's device flag.  The thresholds of the next chunk come from the
+            // corrected list, so a drift costs one or two recomputed chunks, not the whole call.
+            if (!no_fallback) recompute(c_lo, seen, tv[cur], ti[cur], ov, oi, cflag);
             cur ^= 1;
+            ++chunk_i;
         }
         if (seen < N) {   // (only when no filtered chunk ran: N - first < 256) ragged tail: materialise + select
             st = classic(seen, N, tv[cur], ti[cur], k, run_val, run_idx, nullptr, chunk);
             if (st != SGPT_OK) return st;
         }
-        // A candidate list overflowed (adversarial document order / mass of equal scores): recompute the whole call
-        // the classic way.  Sync-free: the launches are predicated on the device flag and exit at once when it is 0.
-        static const bool no_fallback = getenv("SGPT_SCORE_NOFALLBACK") != nullptr;   // timing experiments ONLY: unsafe
-        if (!no_fallback)
-            st = classic(0, N, n_run > 0 ? sav_v : nullptr, n_run > 0 ? sav_i : nullptr, n_run, run_val, run_idx, flag, fchunk);
-        if (st != SGPT_OK) return st;
     }
     if (n_out) { const int64_t tot = (int64_t)n_run + N; *n_out = (int32_t)(tot < k ? tot : k); }
     HIPC(c, hipGetLastError());

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
             const int m = m0 + wm * (16 * NI) + i * 16 + fr;
             if (m >= mv) continue;
             const float th = p.thr[(long)m * p.thr_ld];
+            if (__builtin_nontemporal_load(p.cand_cnt + m) > p.cand_cap) continue;           // (over capacity: recomputed anyway)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
                         acc[i][j][r] = v;
                         mx = fmaxf(mx, v);
                     }
-                if (mx > th) {
+                if (mx > th && __builtin_nontemporal_load(p.cand_cnt + m) <= p.cand_cap) {   // (over capacity: recomputed anyway)
                     int c = 0;
 #pragma unroll
                     for (int j = 0; j < 2; ++j)

@@ -280,7 +280,7 @@ def test_score_topk_ring_depths(ctx, d):
 
 
 @pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("case", ["random", "ascending", "ties", "running"])
+@pytest.mark.parametrize("case", ["random", "ascending", "ties", "running", "drift"])
 def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case, dt16):
     """Long corpora take the threshold-filtered path (EPI_SCORE_FILTER: chunks after the first only append scores
     above the running k-th best; doubling chunk schedule; predicated classic fallback on candidate overflow).
@@ -302,6 +302,15 @@ def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case, dt16):
     elif case == "ties":
         N = 81_920
         c = torch.randn(1024, d, generator=g).repeat(N // 1024, 1)    # every score occurs 80 times
+    elif case == "drift":
+        # the score distribution jumps inside the corpus (a corpus sorted by length, SURVEY A.1 / exact_search.py:66-71):
+        # the chunk that contains the jump overflows its candidate lists and is recomputed on its own; the chunks behind
+        # it are filtered against the corrected thresholds again
+        N = 200_037
+        u = torch.randn(d, generator=g)
+        q = q.abs() * u.sign()
+        c = torch.randn(N, d, generator=g)
+        c[40_000:] += 0.5 * u[None, :]           # documents from 40 000 on score ~0.5 |u|^2-ish higher for every query
     else:
         N = 70_000
         c = torch.randn(N, d, generator=g)
