@@ -458,13 +458,15 @@ class SGPTModel:
         lens = np.fromiter(map(len, seqs), dtype=np.int64, count=n)
         if (lens <= 0).any():
             raise ValueError("Empty items should be cleaned prior to running")
-        plan = self.plan_batches(lens)
-        if len(plan) == 1 and np.array_equal(plan[0], np.arange(n)):     # already in order: no un-sort pass
-            sel = plan[0]
+        # everything fits one call: the packed layout has no padding to the longest sequence, so the length sort of the
+        # reference (SentenceTransformer.py:148-149) buys nothing -- pack in input order, no un-sort pass
+        alloc_total = int(((lens + ALIGN - 1) // ALIGN * ALIGN).sum())
+        if alloc_total <= self.max_tokens_per_call:
             res = torch.empty((n, d), dtype=torch.float32, device=self.device)
             run(self.pack(seqs, pad_left), res)
             self._check_range()
             return res
+        plan = self.plan_batches(lens)
         sorted_rows = torch.empty((n, d), dtype=torch.float32, device=self.device)
         o = 0
         for sel in plan:
