@@ -97,15 +97,15 @@ struct Prof {  // brackets one GEMM launch with events when profiling is on
         if (!on) return;
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;
-            hipEventCreate(&a); hipEventCreate(&b);
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
             c->ev_pool.emplace_back(a, b);
             c->ev_flops.push_back(0);
         }
         slot = c->ev_used++;
         c->ev_flops[slot] = flops;
-        hipEventRecord(c->ev_pool[slot].first, s);
+        (void)hipEventRecord(c->ev_pool[slot].first, s);
     }
-    ~Prof() { if (on) hipEventRecord(c->ev_pool[slot].second, s); }
+    ~Prof() { if (on) (void)hipEventRecord(c->ev_pool[slot].second, s); }
 };
 
 void gemm(sgpt_ctx* c, int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
@@ -137,12 +137,12 @@ sgpt_status sgpt_ctx_create(int hip_device, sgpt_ctx** out) {
 
 void sgpt_ctx_destroy(sgpt_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
-    if (c->ws) hipFree(c->ws);
-    if (c->ws2) hipFree(c->ws2);
-    if (c->range_flag) hipFree(c->range_flag);
-    for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->ws2) (void)hipFree(c->ws2);
+    if (c->range_flag) (void)hipFree(c->range_flag);
+    for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c;
 }
 
@@ -232,7 +232,7 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     unsigned* stats = nullptr;
     if (f16) {
         if (hipMalloc((void**)&stats, 16) != hipSuccess) { delete m; return fail(c, SGPT_ERR_OOM, "hipMalloc failed"); }
-        hipMemsetAsync(stats, 0, 16, 0);
+        (void)hipMemsetAsync(stats, 0, 16, 0);
     }
 
     auto find = [&](const std::string& name, int64_t numel) -> const float* {
@@ -366,7 +366,7 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         // range-checked on the device at run time (RangeTrack in the store epilogues -> sgpt_range_check).
         unsigned h[4] = {0, 0, 0, 0};
         if (st == SGPT_OK && hipMemcpy(h, stats, 12, hipMemcpyDeviceToHost) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "range audit");
-        hipFree(stats);
+        (void)hipFree(stats);
         float wmax, gmax, bmax;
         memcpy(&wmax, &h[0], 4); memcpy(&gmax, &h[1], 4); memcpy(&bmax, &h[2], 4);
         if (st == SGPT_OK && (!(wmax < 65504.f) || !(gmax * sqrtf((float)dm) + bmax < 32768.f)))
@@ -379,9 +379,9 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
 
 void sgpt_model_free(sgpt_model* m) {
     if (!m) return;
-    hipSetDevice(m->ctx->device);
-    hipDeviceSynchronize();
-    for (void* p : m->allocs) hipFree(p);
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : m->allocs) (void)hipFree(p);
     delete m;
 }
 
@@ -1064,8 +1064,8 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
         float ms = 0;
         HIPC(c, hipEventElapsedTime(&ms, e0, e1));
         *ms_out = ms / iters;
-        hipEventDestroy(e0); hipEventDestroy(e1);
-        hipFree(Af); hipFree(Wf); hipFree(A8); hipFree(W8); hipFree(sa); hipFree(sw); hipFree(bias); hipFree(O);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(Af); (void)hipFree(Wf); (void)hipFree(A8); (void)hipFree(W8); (void)hipFree(sa); (void)hipFree(sw); (void)hipFree(bias); (void)hipFree(O);
         HIPC(c, hipGetLastError());
         return SGPT_OK;
     }
@@ -1105,10 +1105,10 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
             fprintf(stderr, " | kloop_end %lld  dma_wait +%lld  barrier +%lld  epilogue +%lld | next tile step0 at %lld\n",
                     r[0] - ks[0], r[1] - r[0], r[2] - r[1], r[3] - r[2], h[64 + (tl + 1) * 16] - ks[0]);
         }
-        hipFree(dbg);
+        (void)hipFree(dbg);
     }
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(A); hipFree(W); hipFree(O); hipFree(bias);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(O); (void)hipFree(bias);
     HIPC(c, hipGetLastError());
     return SGPT_OK;
 }

@@ -35,10 +35,6 @@ constexpr bool RESID_NT = SGPT_RESID_NT != 0;
 #define SGPT_RESID_LD_NT 0
 #endif
 constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
-#ifndef SGPT_RESID_PF
-#define SGPT_RESID_PF 0      // residual-epilogue prefetch distance in rounds (16 VGPRs each); 0, 1, 2 measured equal, 3 spills
-#endif
-constexpr int RESID_PF = SGPT_RESID_PF;
 #ifndef SGPT_SMALL_PF
 #define SGPT_SMALL_PF 2
 #endif
@@ -597,11 +593,10 @@ template <typename T, int EPI, typename OutT, bool SWAP>
 void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
     const int MT = a.M / 256, NT = a.N / 256;
     const int AT = MT >= NT ? MT : NT, BT = MT >= NT ? NT : MT;
-    const int tiles_total = ((AT + 7) / 8 + 3) / 4 * 4 * 8 * BT;
     static const int ncu = [] {
         int dev = 0, n = 256;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n / 8 * 8;
     }();
     GemmArgs b = a;

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
             __syncthreads();
         }
         const uint32_t thr = prefix;  // exact key of the k-th largest; krem = how many == thr to keep
-        const unsigned n_gt = (unsigned)k - krem;
+        // (k - krem elements are strictly above the threshold key)
         // ---- gather everything above the threshold ----
         if (t == 0) sh_cnt = 0;
         __syncthreads();
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
         for (long i = t; i < total; i += TK_THREADS) {
             const float v = r.val(i);
             if (f2key(v) == thr && (unsigned long long)r.idx(i) <= cutoff) {
-                const unsigned slot = atomicAdd(&sh_cnt, 1u);       // continues behind the n_gt gathered elements
+                const unsigned slot = atomicAdd(&sh_cnt, 1u);       // continues behind the k - krem gathered elements
                 if (slot < (unsigned)k) {
                     if (in_lds) { s_val[slot] = v; s_idx[slot] = r.idx(i); } else { ov[slot] = v; oi[slot] = r.idx(i); }
                 }
