@@ -327,11 +327,15 @@ def test_encode_graph_capture_and_replay():
     with pytest.raises(ValueError):
         g.replay(a[:-1])
     # capacity bucket: any batch that fits (fewer / shorter / differently shaped sequences) replays the same graph
+    # (equal to the eager call of the un-padded batch because every batch size produces the same bits -- the default;
+    # the opt-in low-latency k-groups give that up, so the comparison pins the mode)
+    old_kg = m.ctx.lib.sgpt_set_gemm_kgroups(1)
     gb = EncodeGraph(m, a, normalize=True, bucket=(64, 2048, 64))
     for n, hi in ((32, 33), (5, 60), (64, 17), (1, 2)):
         q = [rng.integers(0, 50256, size=int(k)).tolist() for k in rng.integers(1, hi, size=n)]
         got = gb.replay(q)[:n].cpu().numpy()
         assert gb.pb.n_real == n and np.abs(got - m.encode_ids(q, normalize=True).cpu().numpy()).max() < 1e-6
+    m.ctx.lib.sgpt_set_gemm_kgroups(old_kg)
     with pytest.raises(ValueError):
         gb.replay([rng.integers(0, 50256, size=70).tolist()])       # longer than the bucket's A_cap
     with pytest.raises(ValueError):

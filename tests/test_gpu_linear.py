@@ -130,9 +130,10 @@ def test_k_group_launches_are_deterministic_and_match_the_unsplit_kernel(ctx, dt
     acc = a.float() @ w.float().T
     scale = float(acc.abs().max())
     tol32 = 1e-3 * math.sqrt(K / 64) * scale
-    off = ctx.linear(a, w, bias, epi="resid", resid=resid)          # mode off (default): one group
-    old_kg = ctx.lib.sgpt_set_gemm_kgroups(2)
+    old_kg = ctx.lib.sgpt_set_gemm_kgroups(1)                       # mode off (the default): one group
     try:
+        off = ctx.linear(a, w, bias, epi="resid", resid=resid)
+        ctx.lib.sgpt_set_gemm_kgroups(2)
         _k_group_checks(ctx, dt, M, N, K, a, w, bias, resid, acc, tol32, off)
     finally:
         ctx.lib.sgpt_set_gemm_kgroups(old_kg)
