@@ -507,11 +507,18 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
         if (bf) {
             // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]
-            g.W = l.w_qkv; g.N = 2 * dm; g.out = qkv; g.ldo = 2 * dm; g.bias = l.b_qkv;            // bias: BLOOM only
-            gemm(c, dt, EPI_STORE, dt, g, s);
-            g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; g.N = dm; g.out = vt; g.ldo = T;
-            g.bias = l.b_qkv ? l.b_qkv + 2 * dm : nullptr;
-            gemm(c, dt, EPI_VT, dt, g, s);
+            g.W = l.w_qkv; g.out = qkv; g.ldo = 2 * dm; g.bias = l.b_qkv;                           // bias: BLOOM only
+            if (gemm_qkv_one_launch(T, 2 * dm)) {        // query-sized batch: one launch (a launch costs ~8 us there)
+                g.N = 3 * dm; g.n_split = 2 * dm; g.out2 = vt; g.ldo2 = T;
+                gemm(c, dt, EPI_QKV, dt, g, s);
+                g.out2 = nullptr; g.n_split = 0;
+            } else {
+                g.N = 2 * dm;
+                gemm(c, dt, EPI_STORE, dt, g, s);
+                g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; g.N = dm; g.out = vt; g.ldo = T;
+                g.bias = l.b_qkv ? l.b_qkv + 2 * dm : nullptr;
+                gemm(c, dt, EPI_VT, dt, g, s);
+            }
             if (gptj) launch_rope(qkv, dt, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
             at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
             launch_attn_bf16(at, s);

@@ -174,6 +174,8 @@ enum GemmEpi {
     EPI_NONE = 5,         // micro-benchmark only: no stores (accumulators kept live)
     EPI_SCORE_FILTER = 6, // scorer, chunks after the first: append (score, index) of every score > thr[m] to a
                           // per-query candidate list instead of materialising the score tile
+    EPI_QKV = 7,          // fused QKV projection: columns < n_split -> out[m][n] (q | k, row-major), the rest -> out2[n - n_split][m]
+                          // (V^T); one launch for query-sized batches, split into EPI_STORE + EPI_VT launches otherwise
 };
 
 struct GemmArgs {
@@ -198,6 +200,10 @@ struct GemmArgs {
     long idx_base;      // global index of W row 0
     long long* dbg;     // optional s_memtime stamps of workgroup 0 / wave 0 (micro-benchmark diagnostics)
     int* range_flag;    // f16 outputs: device flag raised when a stored magnitude reaches RANGE_LIMIT (or null)
+    // EPI_QKV
+    void* out2;         // V^T [N - n_split][ldo2]
+    long ldo2;
+    int n_split;        // multiple of 128
     // fp8 operands (gemm256q.hip): C = (A8 . W8^T) * a_scale[m] * a_scalar * w_scale[n]
     const float* a_scale;   // [M] per-row scale of the A codes, or null (1)
     const float* w_scale;   // [N] per-output-channel scale of the W codes
@@ -208,6 +214,7 @@ struct GemmArgs {
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
 int set_gemm_skew(int cycles);  // start-up stagger of the persistent 256^2 kernel (shader cycles per phase); returns the previous value
 int set_gemm_kgroups(int g);    // 1: off; 2: k-groups for under-filled small-tile launches (gemm.hip); returns the previous value
+bool gemm_qkv_one_launch(int M, int n_split);   // 16-bit operands: does EPI_QKV apply (query-sized batch)?
 int set_gemm_variant(int v);   // 0: 16x16x32-MFMA 256^2 kernel, 1: 32x32x16-MFMA one; returns the previous value
 // gemm256q.hip: fp8 (e4m3fn) x fp8 on v_mfma_f32_16x16x128_f8f6f4; epi = EPI_BIAS_GELU (fp8 out) | EPI_BIAS_RESID (fp32) |
 // EPI_STORE / EPI_VT (16-bit out) | EPI_NONE

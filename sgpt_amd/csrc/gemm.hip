@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                     const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
                     v[0] += bb.x + rr.x; v[1] += bb.y + rr.y; v[2] += bb.z + rr.z; v[3] += bb.w + rr.w;
-                } else if (EPI == EPI_BIAS_GELU || (EPI == EPI_STORE && p.bias != nullptr)) {
+                } else if (EPI == EPI_BIAS_GELU || ((EPI == EPI_STORE || EPI == EPI_QKV) && p.bias != nullptr)) {
                     if (full) {
                         const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -337,6 +337,14 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
                     for (int r = 0; r < 4; ++r) v[r] = (v[r] != v[r]) ? -1.0f : v[r];  // exact_search.py:99
                 }
                 range.note(v[0], v[1]); range.note(v[2], v[3]);
+                if constexpr (EPI == EPI_QKV) {
+                    if (n >= p.n_split) {        // V columns: transposed (scattered 2-byte stores; query-sized batches only)
+                        OutT* vt = static_cast<OutT*>(p.out2) + (long)(n - p.n_split) * p.ldo2 + m;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) store1<OutT>(vt + (long)r * p.ldo2, v[r]);
+                        continue;
+                    }
+                }
                 OutT* dst = out + (long)m * p.ldo + n;
                 if (full) {
                     store4<OutT>(dst, v[0], v[1], v[2], v[3]);
@@ -835,6 +843,7 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
         return launch_score64<H, EPI_SCORE_FILTER>(a, s);
     }
     if (epi == EPI_SCORE_FILTER && !shape256) return launch<H, EPI_SCORE_FILTER, float, true>(a, s);   // ragged document tail
+    if (epi == EPI_QKV) return launch<H, EPI_QKV, H, true>(a, s);   // caller checked gemm_qkv_one_launch()
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
         // variant 1: the 32x32x16-MFMA re-tiling of the same kernel (gemm256w.hip); 0: the 16x16x32 one below
@@ -860,6 +869,13 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int set_gemm_variant(int v) { const int old = gemm_variant(); g_variant = v; return old; }
+// The fused QKV projection as ONE launch (EPI_QKV: q | k row-major, V^T scattered) when the q | k part alone would take
+// the small-tile kernel -- query-sized batches, where a launch costs ~8 us and the scatter stores are few; larger batches
+// keep the two launches with their own store epilogues.  Same sums either way: identical bits.
+bool gemm_qkv_one_launch(int M, int n_split) {
+    static const bool small_tiles = getenv("SGPT_NO_SMALL_TILE") == nullptr && getenv("SGPT_QKV_TWO") == nullptr;
+    return small_tiles && !(gemm_variant() & 2) && n_split % 128 == 0 && (long)(M / 256) * (n_split / 256) * 2 <= 256;
+}
 int set_gemm_kgroups(int g) { const int old = gemm_kgroups(); g_kgroups = g < 1 ? 1 : g; return old; }
 int set_gemm_skew(int cycles) { const int old = g_skew; g_skew = cycles; return old; }
 

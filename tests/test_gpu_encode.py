@@ -308,6 +308,29 @@ def test_encode_fp8_weights(tag):
     assert maxabs(got, fx["emb_weightedmean"]) > maxabs(got, want)
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_query_sized_and_bulk_batches_give_identical_bits(dtype):
+    """SGPT-125M shape: the same sentences encoded alone (512 token rows: 64x64 register-staged tiles, fused one-launch QKV
+    projection with scattered V^T stores) and inside a 131 072-token call (256x256 LDS-DMA tiles, separate QK / V^T
+    launches with their own store epilogues) must agree bit for bit -- every kernel accumulates k ascending and rounds
+    once.  (The opt-in k-group mode gives this up; pinned off here.)"""
+    fx, cfg_kw, *_ = load_case("cfg1_125m_32x64")
+    m = build_model(cfg_kw, int(fx["seed"]), float(fx["std"]), dtype)
+    old_kg, old_budget = m.ctx.lib.sgpt_set_gemm_kgroups(1), m.max_tokens_per_call      # (the model is shared by the session)
+    try:
+        rng = np.random.default_rng(21)
+        few = [rng.integers(0, 50256, size=int(k)).tolist() for k in rng.integers(3, 40, size=12)]
+        bulk = few + [rng.integers(0, 50256, size=128).tolist() for _ in range(1020)]
+        m.max_tokens_per_call = 1 << 18
+        alone = m.encode_ids(few, normalize=True).cpu().numpy()
+        inside = m.encode_ids(bulk, normalize=True)[: len(few)].cpu().numpy()
+        mid = m.encode_ids(bulk[:100], normalize=True)[: len(few)].cpu().numpy()      # ~11 k rows: 128x128 tiles
+        assert np.array_equal(alone, inside) and np.array_equal(alone, mid)
+    finally:
+        m.ctx.lib.sgpt_set_gemm_kgroups(old_kg)
+        m.max_tokens_per_call = old_budget
+
+
 def test_encode_graph_capture_and_replay():
     """sgpt_encode is stream-pure (no hidden sync / allocation once the workspace is sized), so one call captures
     into a hipGraph; replay on new ids of the same layout bucket equals the eager call bit for bit."""
