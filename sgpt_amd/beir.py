@@ -11,6 +11,7 @@ import logging
 import os
 import pathlib
 import pickle
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Tuple, Union
 
 import numpy as np
@@ -54,12 +55,24 @@ class CustomEmbedder:
             pathlib.Path(self.base_path).parent.mkdir(parents=True, exist_ok=True)
 
     # -- device leg --------------------------------------------------------------------------
-    def embed_device(self, sentences: List[str], is_query: bool, normalize: bool = False) -> torch.Tensor:
+    def tokenize(self, sentences: List[str], is_query: bool) -> List[List[int]]:
+        """Host leg only (text -> truncated, bracketed id lists).  Separate from the device leg so that a caller can run
+        it for the NEXT corpus chunk on a worker thread while the GPU encodes the current one (HF fast tokenizers
+        release the GIL; DenseRetrievalExactSearch.search does exactly that)."""
         before = (self.pipe.docs_truncated, self.pipe.toks_truncated)
         seqs = self.pipe.batch(sentences, is_query)
         if self.pipe.docs_truncated > before[0]:
             logging.warning(f"Truncated {self.pipe.docs_truncated - before[0]} out of {len(sentences)} documents "
                             f"by {self.pipe.toks_truncated - before[1]} tokens.")                # :216-219
+        return seqs
+
+    def tokenize_corpus(self, corpus) -> List[List[int]]:
+        return self.tokenize([t for (_, t) in self._corpus_texts(corpus)], False)
+
+    def embed_device(self, sentences: List[str], is_query: bool, normalize: bool = False) -> torch.Tensor:
+        return self.embed_ids_device(self.tokenize(sentences, is_query), normalize=normalize)
+
+    def embed_ids_device(self, seqs: List[List[int]], normalize: bool = False) -> torch.Tensor:
         L = self.model.cfg.num_layers
         if abs(self.layeridx) > L + 1:
             raise ValueError(f"Layer Idx {self.layeridx} is larger than the {L + 1} hidden states")   # :234-235
@@ -114,11 +127,17 @@ class CustomEmbedder:
             return get_context(self.model.device).l2_normalize(emb) if normalize else emb
         return self.embed_device([q for (_, q) in queries], True, normalize=normalize)
 
-    def encode_corpus_device(self, corpus, batch_num="", normalize=False):
-        if os.path.exists(f"{self.base_path}_corpus{batch_num}.pickle") or self.save_emb:
+    def uses_embedding_cache(self, batch_num="") -> bool:
+        return os.path.exists(f"{self.base_path}_corpus{batch_num}.pickle") or self.save_emb
+
+    def encode_corpus_device(self, corpus, batch_num="", normalize=False, seqs=None):
+        """seqs: the chunk's id lists when the caller tokenised it ahead of time (tokenize_corpus)."""
+        if self.uses_embedding_cache(batch_num):
             emb = torch.from_numpy(self.encode_corpus(corpus, batch_num=batch_num)).to(self.model.device)
             return get_context(self.model.device).l2_normalize(emb) if normalize else emb
-        return self.embed_device([t for (_, t) in self._corpus_texts(corpus)], False, normalize=normalize)
+        if seqs is None:
+            seqs = self.tokenize_corpus(corpus)
+        return self.embed_ids_device(seqs, normalize=normalize)
 
 
 class DenseRetrievalExactSearch:
@@ -128,8 +147,9 @@ class DenseRetrievalExactSearch:
     query, the (k+1) best of {per-chunk top-(k+1) minus corpus_id == query_id} (:102-132)."""
 
     def __init__(self, model, batch_size: int = 128, corpus_chunk_size: int = 50000, score_dtype=torch.float32,
-                 **kwargs):
+                 prefetch_tokenize: bool = True, **kwargs):
         self.model = model
+        self.prefetch_tokenize = prefetch_tokenize
         self.batch_size = batch_size
         self.score_function_desc = {"cos_sim": "Cosine Similarity", "dot": "Dot Product"}
         self.corpus_chunk_size = corpus_chunk_size
@@ -175,10 +195,25 @@ class DenseRetrievalExactSearch:
         nq = len(query_ids)
         run_val = run_idx = None
         itr = range(0, len(clist), self.corpus_chunk_size)
+        # The host leg (tokenise + truncate + brackets) of chunk i+1 runs on a worker thread while the GPU encodes and
+        # scores chunk i (the reference does both serially, exact_search.py:80-93).  Embedding caches bypass it.
+        ahead = self.prefetch_tokenize and hasattr(self.model, "tokenize_corpus")
+        pool = ThreadPoolExecutor(max_workers=1) if ahead else None
+        fut = None
+
+        def tokens_for(batch_num, start):
+            if not ahead or self.model.uses_embedding_cache(batch_num) or start >= len(clist):
+                return None
+            return pool.submit(self.model.tokenize_corpus, clist[start: start + self.corpus_chunk_size])
+        fut = tokens_for(0, 0)
         for batch_num, start in enumerate(itr):
             logger.info("Encoding Batch {}/{}...".format(batch_num + 1, len(itr)))
             end = min(start + self.corpus_chunk_size, len(clist))
-            if hasattr(self.model, "encode_corpus_device"):
+            if ahead:
+                seqs = fut.result() if fut is not None else None
+                fut = tokens_for(batch_num + 1, end)
+                sub = self.model.encode_corpus_device(clist[start:end], batch_num=batch_num, seqs=seqs)
+            elif hasattr(self.model, "encode_corpus_device"):
                 sub = self.model.encode_corpus_device(clist[start:end], batch_num=batch_num)
             else:
                 sub = self.model.encode_corpus(clist[start:end], batch_size=self.batch_size,
@@ -196,6 +231,8 @@ class DenseRetrievalExactSearch:
             keep = min(top_k + 1, cand_v.shape[1])                                # :126
             run_val, run_idx = ctx.topk_merge(cand_v, cand_i, keep, exclude_idx=self_idx)          # :118,121-132
 
+        if pool is not None:
+            pool.shutdown(wait=True)
         if run_val is not None:
             vals, idxs = run_val.cpu().numpy(), run_idx.cpu().numpy()
             for qi, qid in enumerate(query_ids):

@@ -120,6 +120,40 @@ def test_custom_embedder_and_search_end_to_end_vs_oracle(tmp_path, monkeypatch):
         assert maxabs(got, O.encode(w, cfg, seqs, mode=method)) < 1e-3, method
 
 
+def test_search_tokenises_the_next_chunk_during_gpu_work(tmp_path, monkeypatch):
+    """DenseRetrievalExactSearch.search hands the host leg (HF fast tokenizer, truncation, brackets) of corpus chunk i+1 to
+    a worker thread while the GPU encodes and scores chunk i.  Same results as the serial loop; the wall time of a
+    multi-chunk search (SGPT-125M shape, word-level fast tokenizer, ~100-token documents) is reported for both."""
+    import time
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    from sgpt_amd.beir import CustomEmbedder, DenseRetrievalExactSearch
+    monkeypatch.chdir(tmp_path)
+    words = [f"w{i}" for i in range(5000)] + ["[", "]", "{", "}", "[UNK]"]
+    tk = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok = PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="[UNK]", eos_token="[UNK]")
+    tok.pad_token = tok.eos_token
+    fx, cfg_kw, *_ = load_case("cfg1_125m_32x64")
+    m = build_model(cfg_kw, int(fx["seed"]), float(fx["std"]), "f16")
+    emb = CustomEmbedder(model_name="synthetic/125m", model=m, tokenizer=tok, method="weightedmean", specb=True,
+                         maxseqlen=128, dataset="unit")
+    rng = np.random.default_rng(4)
+    mk = lambda n, lo, hi: [" ".join(f"w{j}" for j in rng.integers(0, 5000, size=int(rng.integers(lo, hi)))) for _ in range(n)]  # noqa: E731
+    corpus = {f"d{i}": {"title": "", "text": t} for i, t in enumerate(mk(12000, 60, 140))}
+    queries = {f"q{i}": t for i, t in enumerate(mk(50, 4, 20))}
+    out, secs = {}, {}
+    for ahead in (True, False, True, False):
+        dres = DenseRetrievalExactSearch(emb, corpus_chunk_size=3000, score_dtype=torch.float16, prefetch_tokenize=ahead)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out[ahead] = dres.search(corpus, queries, 10, "cos_sim")
+        secs[ahead] = time.perf_counter() - t
+    assert out[True] == out[False]
+    print(f"12 000 documents in 4 chunks: {secs[False]:.3f} s serial host leg, {secs[True]:.3f} s with the next chunk "
+          f"tokenised during GPU work")
+
+
 def test_embedding_pickle_cache_roundtrip(tmp_path, monkeypatch):
     """--saveemb cache format {id: ndarray} (beir_dense_retriever.py:311-312,319-323)."""
     import pickle
