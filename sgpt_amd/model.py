@@ -211,7 +211,7 @@ class SGPTModel:
     """GPT-Neo weights resident on one GPU behind an `sgpt_model*` handle."""
 
     def __init__(self, cfg: SGPTConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device=None,
-                 dtype: str = "f16", ctx: Optional[Context] = None, max_tokens_per_call: int = 32768,
+                 dtype: str = "f16", ctx: Optional[Context] = None, max_tokens_per_call: int = 131072,
                  calibrate: bool = True):
         if dtype in ("fp16", "float16", "half"):
             dtype = "f16"
@@ -223,6 +223,9 @@ class SGPTModel:
         self.ctx = ctx or get_context(device)
         self.device = self.ctx.device
         self.dtype = dtype
+        # token rows per sgpt_encode call: 131 072 = 6 / 12 / 24 full rounds of 256x256 tiles on 256 CUs for the 125M
+        # projections (measured: 1000 TFLOP/s there, 864-890 at 49 k rows, 754 at 25 k); activations ~2.5 GB (125M) to
+        # ~13 GB (bloom-7b1) of the 288 GB
         self.max_tokens_per_call = max_tokens_per_call
         lib = self.ctx.lib
         local = (C.c_uint8 * cfg.num_layers)(*[1 if a == "local" else 0 for a in cfg.attention_layers])
