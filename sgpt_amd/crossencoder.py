@@ -12,14 +12,18 @@ import torch
 from .model import ALIGN, SGPTModel
 
 
+def _ids(tokenizer, text: str) -> List[int]:
+    return list(tokenizer.encode(text, add_special_tokens=False))
+
+
 def encode(requests: Sequence[Tuple[str, str]], tokenizer):
-    """sgptce.py:77-91: requests are (continuation = query, context = prompted document)."""
-    new_reqs = []
-    for continuation, context in requests:
-        context_enc = [tokenizer.eos_token_id] if context == "" else tokenizer.encode(context, add_special_tokens=False)
-        continuation_enc = tokenizer.encode(continuation, add_special_tokens=False)
-        new_reqs.append(((context, continuation), list(context_enc), list(continuation_enc)))
-    return new_reqs
+    """(query, prompted document) pairs -> ((document, query), document ids, query ids): the request triples
+    `loglikelihood_tokens` scores.  An empty document stands for the end-of-text id alone (sgptce.py:77-91)."""
+    out = []
+    for query, doc in requests:
+        doc_ids = _ids(tokenizer, doc) if doc != "" else [tokenizer.eos_token_id]
+        out.append(((doc, query), doc_ids, _ids(tokenizer, query)))
+    return out
 
 
 def model_input(context_enc: List[int], continuation_enc: List[int], max_length: int, instruction_len: int = 0) -> List[int]:
@@ -71,21 +75,25 @@ def loglikelihood_tokens(requests, model: SGPTModel, max_length: int, instructio
 
 
 class GPTRanker:
-    """sgptce.py:265-331 (`Rerank(GPTRanker(...))` in BEIR): predict([(query, doc), ...]) -> log-probabilities."""
+    """sgptce.py:265-331 (`Rerank(GPTRanker(...))` in BEIR): predict([(query, doc), ...]) -> log-probabilities.
+    The text in front of the document slot of `prompt_doc` (and the few-shot block, if any) is the instruction: it is never
+    truncated away, and its token count is fixed at construction."""
 
     def __init__(self, model: SGPTModel, tokenizer, max_length: int = None, use_prompt: bool = True,
                  prompt_doc: str = "{}\n", prompt_doc_start: str = "{}\n{}\n", fewshots=""):
         self.model, self.tokenizer = model, tokenizer
-        self.max_length = max_length or model.cfg.max_position_embeddings
-        self.prompt_doc, self.use_prompt = prompt_doc, use_prompt
-        self.instruction_len = len(tokenizer.tokenize(prompt_doc[:prompt_doc.index("{")]))
-        self.fewshots = fewshots
-        if self.fewshots:
-            self.fewshots = prompt_doc_start.format(self.fewshots[0], self.fewshots[1])
-            self.instruction_len += len(tokenizer.tokenize(self.fewshots))
+        self.max_length = max_length if max_length else model.cfg.max_position_embeddings
+        self.use_prompt, self.prompt_doc = use_prompt, prompt_doc
+        n_tok = lambda text: len(tokenizer.tokenize(text))  # noqa: E731
+        self.fewshots = prompt_doc_start.format(fewshots[0], fewshots[1]) if fewshots else ""   # one formatted block
+        head = prompt_doc.split("{", 1)[0]
+        if "{" not in prompt_doc:
+            raise ValueError("prompt_doc needs a {} slot for the document")
+        self.instruction_len = n_tok(head) + (n_tok(self.fewshots) if self.fewshots else 0)
 
     def predict(self, sentences: List[Tuple[str, str]], batch_size: int = 0, **kwargs) -> List[float]:
+        pairs = list(sentences)
         if self.use_prompt:
-            sentences = [(query, self.fewshots + self.prompt_doc.format(doc)) for (query, doc) in sentences]
-        return loglikelihood_tokens(encode(sentences, self.tokenizer), self.model, self.max_length,
+            pairs = [(query, self.fewshots + self.prompt_doc.format(doc)) for query, doc in pairs]
+        return loglikelihood_tokens(encode(pairs, self.tokenizer), self.model, self.max_length,
                                     instruction_len=self.instruction_len)
