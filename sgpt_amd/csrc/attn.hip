@@ -24,6 +24,10 @@
 #define SGPT_ATTN_NT_LOAD 1   // K / V^T tiles are read once per (sequence, head): non-temporal loads (+0.2 % end to end)
 #endif
 constexpr bool ATTN_NT_LOAD = SGPT_ATTN_NT_LOAD != 0;
+#ifndef SGPT_ATTN_WAVES_PER_SIMD
+#define SGPT_ATTN_WAVES_PER_SIMD 4   // register budget of attn16_lds_kernel: 4 waves per SIMD = two 512-thread workgroups per CU
+#endif
+constexpr int ATTN_WAVES_PER_SIMD = SGPT_ATTN_WAVES_PER_SIMD;
 
 namespace {
 
@@ -43,7 +47,7 @@ constexpr bool ATTN_NT = SGPT_ATTN_NT != 0;
 // H = bf16_t | f16_t: the 16-bit format of q / k / V^T, of the probabilities fed to the P.V MFMA and of the context
 // OUT8: the context leaves as e4m3 codes of ctx / out_scale (fp8 out-projection operand) instead of the 16-bit format
 template <typename H, int DH, bool OUT8>
-__global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(const AttnArgs p) {
     constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
     constexpr int NT = 512, QB = 128;                          // 8 waves x 16 queries per block
     constexpr int ORS = DH * 2 + 16;                           // output-transpose row stride (bytes)
@@ -80,10 +84,12 @@ __global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
     if (p.window > 0) { j_lo = qb0 - p.window + 1; j_lo = j_lo < 0 ? 0 : (j_lo & ~63); }
     int j_hi = qb0 + QB - 1;                         // last key any query of the block may see
     if (j_hi > alloc - 1) j_hi = alloc - 1;
-    for (int j0 = j_lo; j0 <= j_hi; j0 += 64) {
-        // ---- cooperative tile load (row-contiguous 16-B pieces) ----
-        constexpr int KU = (64 * CPR + NT - 1) / NT, VU = (DH * 8 + NT - 1) / NT;
-        uint4 kreg[KU], vreg[VU];
+    // ---- cooperative tile load (row-contiguous 16-B pieces), one tile ahead: the global loads of key tile j+1 are
+    // issued before tile j is consumed from LDS, so a sequence of several key tiles (S >= 128) does not pay one
+    // un-hidden global-load round trip per tile ----
+    constexpr int KU = (64 * CPR + NT - 1) / NT, VU = (DH * 8 + NT - 1) / NT;
+    uint4 kreg[KU], vreg[VU];
+    auto tile_load = [&](int j0) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int c = t + NT * u, row = c / CPR, ch = c % CPR;
@@ -94,6 +100,9 @@ __global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
             const int c = t + NT * u, row = c >> 3, ch = c & 7;
             if (c < DH * 8) vreg[u] = ldg16u<ATTN_NT_LOAD>(vt + (long)row * p.ldvt + s0 + j0 + ch * 8);
         }
+    };
+    if (j_lo <= j_hi) tile_load(j_lo);
+    for (int j0 = j_lo; j0 <= j_hi; j0 += 64) {
         __syncthreads();                             // previous tile fully consumed
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
@@ -106,6 +115,7 @@ __global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
             if (c < DH * 8) Vs[row * 8 + (ch ^ (row & 7))] = vreg[u];
         }
         __syncthreads();
+        if (j0 + 64 <= j_hi) tile_load(j0 + 64);     // next tile's loads fly under this tile's MFMAs and softmax
         if (!wave_on || j0 > q0 + 15) continue;      // nothing visible for this wave in this tile
         // ---- S^T = K.Q^T : 4 tiles of [16 keys][16 queries] ----
         f32x4 s[4];
@@ -119,6 +129,10 @@ __global__ __launch_bounds__(512) void attn16_lds_kernel(const AttnArgs p) {
                 s[nt] = Half<H>::mfma16(kv, qf[ks], s[nt]);
             }
         }
+        // (Measured at S = 512, where this kernel is 19 % of a step and neither HBM- nor MFMA-bound -- 657 us per 131 072
+        // tokens against 60 us of MFMA issue: skipping the mask on fully visible tiles and a log2-domain softmax (one
+        // multiply less per score) changed nothing; asking for 6 or 8 waves per SIMD instead of 4 spills and costs 30-40 %.
+        // What is left is the two barriers per 64-key tile with two workgroups per CU.)
         float mx = -INFINITY;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
