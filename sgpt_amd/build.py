@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsgpt_hip.so")
-SOURCES = ["gemm.hip", "gemm256w.hip", "gemm256q.hip", "gemm256h.hip", "attn.hip", "elementwise.hip", "topk.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm256w.hip", "gemm256q.hip", "attn.hip", "elementwise.hip", "topk.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result"] + os.environ.get("SGPT_EXTRA_FLAGS", "").split()
 

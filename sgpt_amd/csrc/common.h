@@ -222,8 +222,6 @@ bool gemm_fp8_shape_ok(int M, int N, int K);
 void launch_gemm_fp8(int epi, int out_dtype, const GemmArgs& a, hipStream_t s);   // out_dtype: EPI_STORE / EPI_VT only
 // gemm256w.hip: the 256x256 LDS-DMA kernel on v_mfma_f32_32x32x16 (16-bit operands and outputs as gemm256d_kernel)
 void launch_gemm256w(int dtype, int epi, const GemmArgs& a, hipStream_t s, bool deep_a);
-// gemm256h.hip: probe of a half-tile (128x256 per pass) k-loop, EPI_NONE only (variant bit 3)
-void launch_gemm256h_probe(int dtype, const GemmArgs& a, hipStream_t s);
 
 struct AttnArgs {
     const void* q;       // [T][ldq]  (bf16 path: qk buffer; fp32 path: qkv buffer)

@@ -855,8 +855,6 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
         if (epi == EPI_VT) return launch256d<H, EPI_VT, H, false>(a, s, deep_a);
         if (epi == EPI_BIAS_GELU) return launch256d<H, EPI_BIAS_GELU, H, true>(a, s, deep_a);
         if (epi == EPI_BIAS_RESID) return launch256d<H, EPI_BIAS_RESID, float, true>(a, s, deep_a);
-        if (epi == EPI_NONE && (gemm_variant() & 8) && a.M >= a.N)      // probe: half-tile k-loop (gemm256h.hip)
-            return launch_gemm256h_probe(Half<H>::is_f16 ? DT_F16 : DT_BF16, a, s);
         if (epi == EPI_NONE) return launch256d<H, EPI_NONE, H, true>(a, s, deep_a);
     }
     if (epi == EPI_STORE && o16) return launch<H, EPI_STORE, H, true>(a, s);
