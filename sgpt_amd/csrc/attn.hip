@@ -42,7 +42,7 @@ constexpr bool ATTN_NT = SGPT_ATTN_NT != 0;
 // A 512-thread block (128 queries of one (sequence, head)) loads
 // each 64-key tile ONCE with row-contiguous 16-byte loads into LDS
 //     Ks[64 keys][DH]   (16-B chunk index XOR (key & 7): conflict-free ds_read_b128 fragments)
-//     Vs[DH][64 keys]   (same swizzle; ds_read_b64 pairs for the permuted k-slots)
+//     Vs[DH][64 keys]   (same swizzle; keys k-slot-permuted inside each 32-key block: one ds_read_b128 per P.V fragment)
 // and every wave takes its MFMA operands from there.  Same math / lane maps as above.
 // H = bf16_t | f16_t: the 16-bit format of q / k / V^T, of the probabilities fed to the P.V MFMA and of the context
 // OUT8: the context leaves as e4m3 codes of ctx / out_scale (fp8 out-projection operand) instead of the 16-bit format
@@ -112,7 +112,16 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
 #pragma unroll
         for (int u = 0; u < VU; ++u) {
             const int c = t + NT * u, row = c >> 3, ch = c & 7;
-            if (c < DH * 8) Vs[row * 8 + (ch ^ (row & 7))] = vreg[u];
+            if (c < DH * 8) {
+                // keys are stored k-slot-permuted inside each 32-key block: the 16-byte chunk 4*step + g of a row holds keys
+                // 32*step + 4g..4g+3 and 32*step + 16 + 4g..4g+3 -- exactly the eight k-slots lane group g feeds to the P.V
+                // MFMA, so a fragment is ONE ds_read_b128 (it was two ds_read_b64 from chunks two apart, and with them most
+                // of this kernel's time at S >= 256).  The 16 loaded bytes (keys 8ch..8ch+7) go to two chunks, 8 bytes each.
+                const int blk = ch >> 2, w = ch & 3, hf = w >> 1, g0 = 2 * (w & 1);
+                char* vrow = reinterpret_cast<char*>(&Vs[row * 8]);
+                *reinterpret_cast<uint2*>(vrow + ((4 * blk + g0) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vreg[u].x, vreg[u].y);
+                *reinterpret_cast<uint2*>(vrow + ((4 * blk + g0 + 1) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vreg[u].z, vreg[u].w);
+            }
         }
         __syncthreads();
         if (j0 + 64 <= j_hi) tile_load(j0 + 64);     // next tile's loads fly under this tile's MFMAs and softmax
@@ -172,12 +181,8 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int row = dt * 16 + fr;
-                // keys 32*step + 4g .. +3 live in 16-B chunk (4*step + g/2), 8-B half (g&1); +16 keys = +2 chunks
-                const char* vrow = reinterpret_cast<const char*>(&Vs[row * 8]);
-                const int c0 = (4 * step + (g >> 1)) ^ (row & 7), c1 = (4 * step + 2 + (g >> 1)) ^ (row & 7);
-                const uint2 v0 = *reinterpret_cast<const uint2*>(vrow + c0 * 16 + (g & 1) * 8);
-                const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + c1 * 16 + (g & 1) * 8);
-                uint4 vu; vu.x = v0.x; vu.y = v0.y; vu.z = v1.x; vu.w = v1.y;
+                // chunk 4*step + g of the k-slot-permuted row = this lane group's eight k-slots (see the staging store)
+                const uint4 vu = Vs[row * 8 + ((4 * step + g) ^ (row & 7))];
                 o[dt] = Half<H>::mfma16(vu, pu, o[dt]);
             }
         }
