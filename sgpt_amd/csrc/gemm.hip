@@ -791,9 +791,12 @@ int gemm_kgroups() {
 template <typename T, int EPI, typename OutT, bool SWAP>
 void launch(const GemmArgs& a, hipStream_t s) {
     // 64x64 tiles when 128x128 ones would leave most of the 256 CUs idle (short query batches, USEB's 21-32 sentence
-    // calls: M = 1024 x N = 768 is 48 tiles of 128^2 but 192 of 64^2)
+    // calls: M = 1024 x N = 768 is 48 tiles of 128^2 but 192 of 64^2).  Switch point measured on whole encodes
+    // (SGPT_T128_MIN sweep): 1536 token rows prefer 64^2 tiles up to fc1's 288 tiles of 128^2 (1.26 -> 1.15 ms), 6912 rows
+    // prefer 128^2 tiles from the N = 768 launches' 324 on.
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const bool small = t128 < 192;
+    static const long t128_min = getenv("SGPT_T128_MIN") ? atol(getenv("SGPT_T128_MIN")) : 300;   // measured switch point (A/B knob)
+    const bool small = t128 < t128_min;
     const int B = small ? 64 : 128;
     const int MT = (a.M + B - 1) / B, NT = (a.N + B - 1) / B;
     const int mt_per_xcd = (MT + 7) / 8;
