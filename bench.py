@@ -292,50 +292,9 @@ def main():
         assert int(flag.item()) == 1, "sharded search != single-rank search on the same documents"
         shard_check = {"docs": world * m, "nq": args.nq, "identical_to_single_rank": True}
 
-    # ---- the same step on documents of lengths ~U{16..128} (SURVEY 8d cfg2 asks for both) ----
-    varlen = None
-    if not args.no_varlen:
-        vrng = np.random.default_rng(2000 + rank)
-        v_steps = max(1, min(max(4, args.steps // 3), n_steps - 1))
-        vpacked, v_tokens, v_flops = [], 0, 0.0
-        for _ in range(v_steps + 1):
-            lens = vrng.integers(16, S + 1, size=args.chunk)
-            docs = [vrng.integers(0, min(50256, cfg.vocab_size), size=int(n)) for n in lens]
-            plan = model.plan_batches(lens.astype(np.int64))
-            vpacked.append([model.pack([docs[i] for i in sel]) for sel in plan])
-            v_tokens += int(lens.sum())
-            v_flops += float(sum(flops_per_sentence(int(n), cfg.num_layers, cfg.hidden_size) for n in lens))
-        per_step_tokens, per_step_flops = v_tokens / (v_steps + 1), v_flops / (v_steps + 1)
-
-        def vstep(i, run):
-            o = 0
-            for pb in vpacked[i]:
-                model.encode_packed(pb, mode="weightedmean", normalize=True, out=emb32[o: o + pb.B])
-                o += pb.B
-            rows = corpus[i * args.chunk: (i + 1) * args.chunk]
-            if score_dt != torch.float32:
-                ctx.to_16(emb32, score_dt, out=rows)
-            else:
-                rows.copy_(emb32)
-            return ctx.score_topk(q, rows, k1, idx_base=i * args.chunk, run=run, dtype=score_dt)
-        vrun = vstep(0, None)
-        sync()
-        t = time.perf_counter()
-        for i in range(1, v_steps + 1):
-            vrun = vstep(i, vrun)
-        sync()
-        vdt = time.perf_counter() - t
-        if dist_on:
-            tv = torch.tensor([vdt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
-            vdt = float(tv.item())
-        varlen = {"lengths": f"U{{16..{S}}}", "steps": v_steps, "sentences_per_s": round(world * v_steps * args.chunk / vdt, 1),
-                  "tokens_per_s": round(world * v_steps * per_step_tokens / vdt, 1),
-                  "mean_len": round(per_step_tokens / args.chunk, 2),
-                  "end_to_end_frac_of_mfma_roofline": round(v_steps * per_step_flops / vdt / (PEAK_BF16_TFLOPS * 1e12), 4)}
-        del vpacked
-
-    # ---- queries/sec: scoring + top-k only, against this job's encoded corpus and a 1M-doc synthetic shard ----
+    # ---- queries/sec: scoring + top-k only, against this job's encoded corpus and a 1M-doc synthetic shard (before the
+    # variable-length leg below re-uses the corpus rows: a shard that starts with differently distributed documents measures
+    # the overflow-recomputation path instead, see scripts/score_bench.py DRIFT=) ----
     def search_once(cmat):
         v, i, _ = ctx.score_topk(q, cmat, k1, idx_base=rank * cmat.shape[0], dtype=score_dt)
         if dist_on:
@@ -403,6 +362,49 @@ def main():
             qps_enc_ll = {k_: float(tq[1 + len(keys) + j].item()) for j, k_ in enumerate(keys_ll)}
             qps_1m_enc = qps_enc_by_nq[args.nq]
         del big
+
+    # ---- the same step on documents of lengths ~U{16..128} (SURVEY 8d cfg2 asks for both) ----
+    varlen = None
+    if not args.no_varlen:
+        vrng = np.random.default_rng(2000 + rank)
+        v_steps = max(1, min(max(4, args.steps // 3), n_steps - 1))
+        vpacked, v_tokens, v_flops = [], 0, 0.0
+        for _ in range(v_steps + 1):
+            lens = vrng.integers(16, S + 1, size=args.chunk)
+            docs = [vrng.integers(0, min(50256, cfg.vocab_size), size=int(n)) for n in lens]
+            plan = model.plan_batches(lens.astype(np.int64))
+            vpacked.append([model.pack([docs[i] for i in sel]) for sel in plan])
+            v_tokens += int(lens.sum())
+            v_flops += float(sum(flops_per_sentence(int(n), cfg.num_layers, cfg.hidden_size) for n in lens))
+        per_step_tokens, per_step_flops = v_tokens / (v_steps + 1), v_flops / (v_steps + 1)
+
+        def vstep(i, run):
+            o = 0
+            for pb in vpacked[i]:
+                model.encode_packed(pb, mode="weightedmean", normalize=True, out=emb32[o: o + pb.B])
+                o += pb.B
+            rows = corpus[i * args.chunk: (i + 1) * args.chunk]
+            if score_dt != torch.float32:
+                ctx.to_16(emb32, score_dt, out=rows)
+            else:
+                rows.copy_(emb32)
+            return ctx.score_topk(q, rows, k1, idx_base=i * args.chunk, run=run, dtype=score_dt)
+        vrun = vstep(0, None)
+        sync()
+        t = time.perf_counter()
+        for i in range(1, v_steps + 1):
+            vrun = vstep(i, vrun)
+        sync()
+        vdt = time.perf_counter() - t
+        if dist_on:
+            tv = torch.tensor([vdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+            vdt = float(tv.item())
+        varlen = {"lengths": f"U{{16..{S}}}", "steps": v_steps, "sentences_per_s": round(world * v_steps * args.chunk / vdt, 1),
+                  "tokens_per_s": round(world * v_steps * per_step_tokens / vdt, 1),
+                  "mean_len": round(per_step_tokens / args.chunk, 2),
+                  "end_to_end_frac_of_mfma_roofline": round(v_steps * per_step_flops / vdt / (PEAK_BF16_TFLOPS * 1e12), 4)}
+        del vpacked
 
     if rank != 0:
         if dist_on:

@@ -164,6 +164,15 @@ __device__ __forceinline__ float gelu_new_fast(float u) {
     return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 
+// Filtered scorer epilogues: is there still room in query row's candidate list?  Called only AFTER a lane has found a
+// survivor (rare).  An ATOMIC relaxed load on purpose: a plain load is hoisted by the compiler in front of the
+// `max > threshold` test, which put a global load (and its wait) on every row of every tile -- measured 0.27 -> 0.37 ms on
+// a 90 k-document pass.  A list already over capacity is recomputed anyway (cand_merge flags raw > cap), so its atomics are
+// skipped: a chunk in which every document beats the threshold otherwise spends milliseconds in them.
+__device__ __forceinline__ bool cand_room(const int* cnt, int cap) {
+    return __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= cap;
+}
+
 // ---- launch descriptors shared between the .hip translation units and api.cpp ----
 enum GemmEpi {
     EPI_STORE = 0,        // out[m][n] = acc                          (row-major, OutT)

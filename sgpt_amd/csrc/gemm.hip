@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
             const int m = m0 + wm * (16 * NI) + i * 16 + fr;
             if (m >= mv) continue;
             const float th = p.thr[(long)m * p.thr_ld];
-            if (__builtin_nontemporal_load(p.cand_cnt + m) > p.cand_cap) continue;           // (over capacity: recomputed anyway)
+            // (capacity is checked per survivor below: a check up here would put a global load on every row's path)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
                     const int n = n0 + wn * (16 * NI) + j * 16 + 4 * g + r;
                     float v = acc[i][j][r];
                     v = v != v ? -1.0f : v;
-                    if (n < N && v > th) {
+                    if (n < N && v > th && cand_room(p.cand_cnt + m, p.cand_cap)) {
                         const int slot = atomicAdd(p.cand_cnt + m, 1);
                         if (slot < p.cand_cap) {
                             p.cand_val[(long)m * p.cand_cap + slot] = v;
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
                         acc[i][j][r] = v;
                         mx = fmaxf(mx, v);
                     }
-                if (mx > th && __builtin_nontemporal_load(p.cand_cnt + m) <= p.cand_cap) {   // (over capacity: recomputed anyway)
+                if (mx > th && cand_room(p.cand_cnt + m, p.cand_cap)) {   // (over capacity: recomputed anyway)
                     int c = 0;
 #pragma unroll
                     for (int j = 0; j < 2; ++j)

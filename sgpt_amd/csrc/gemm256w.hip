@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void gemm256w_kernel(const GemmArgs p) {
                             acc[i][j][e] = v;
                             mx = fmaxf(mx, v);
                         }
-                    if (mx > th && __builtin_nontemporal_load(p.cand_cnt + m) <= p.cand_cap) {   // (over capacity: recomputed anyway)
+                    if (mx > th && cand_room(p.cand_cnt + m, p.cand_cap)) {   // (over capacity: recomputed anyway)
                         int c = 0;
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
