@@ -361,6 +361,79 @@ def synth_weights_bloom(cfg: BloomConfig, seed: int = 0, std: float = 0.02, bf16
     return w
 
 
+def synth_weights_streams(cfg, seed: int = 0, std: float = 0.02, threads: Optional[int] = None) -> Dict[str, np.ndarray]:
+    """Seeded random-init weights for the FULL-SIZE shapes (SGPT-1.3B / 5.8B / bloom-7b1: 1.3-6 G parameters), any of the
+    three families, under the same HF state-dict names and scales as synth_weights / synth_weights_gptj /
+    synth_weights_bloom -- but every tensor draws from its OWN generator stream ``default_rng([seed, tensor_index])``
+    (numpy SeedSequence: stable across platforms), so the tensors are independent of generation order and can be
+    produced by a thread pool (Generator.standard_normal releases the GIL): 6 G parameters take ~20 s on 8 cores
+    instead of minutes on one stream.  Used by tests/golden/make_golden_large.py and tests/test_gpu_parity_large.py,
+    which must read identical bytes."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    d, ffn, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_layers
+    spec: List[Tuple[str, tuple, float, float]] = []          # (name, shape, scale, offset)
+
+    def add(name, shape, s, off=0.0):
+        spec.append((name, tuple(shape), float(s), float(off)))
+
+    def add_ln(base):
+        add(base + ".weight", (d,), 0.1, 1.0)
+        add(base + ".bias", (d,), 0.05)
+    if isinstance(cfg, BloomConfig):
+        add("word_embeddings.weight", (cfg.vocab_size, d), std * 2)
+        add_ln("word_embeddings_layernorm")
+        for i in range(L):
+            p = f"h.{i}."
+            add_ln(p + "input_layernorm")
+            add_ln(p + "post_attention_layernorm")
+            add(p + "self_attention.query_key_value.weight", (3 * d, d), std)
+            add(p + "self_attention.query_key_value.bias", (3 * d,), 0.02)
+            add(p + "self_attention.dense.weight", (d, d), std)
+            add(p + "self_attention.dense.bias", (d,), 0.02)
+            add(p + "mlp.dense_h_to_4h.weight", (ffn, d), std)
+            add(p + "mlp.dense_h_to_4h.bias", (ffn,), 0.02)
+            add(p + "mlp.dense_4h_to_h.weight", (d, ffn), std)
+            add(p + "mlp.dense_4h_to_h.bias", (d,), 0.02)
+    elif isinstance(cfg, GPTJConfig):
+        add("wte.weight", (cfg.vocab_size, d), std * 2)
+        for i in range(L):
+            p = f"h.{i}."
+            add_ln(p + "ln_1")
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                add(p + f"attn.{n}.weight", (d, d), std)
+            add(p + "mlp.fc_in.weight", (ffn, d), std)
+            add(p + "mlp.fc_in.bias", (ffn,), 0.02)
+            add(p + "mlp.fc_out.weight", (d, ffn), std)
+            add(p + "mlp.fc_out.bias", (d,), 0.02)
+    else:
+        add("wte.weight", (cfg.vocab_size, d), std)
+        add("wpe.weight", (cfg.max_position_embeddings, d), std / 2)
+        for i in range(L):
+            p = f"h.{i}."
+            add_ln(p + "ln_1")
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                add(p + f"attn.attention.{n}.weight", (d, d), std)
+            add(p + "attn.attention.out_proj.bias", (d,), 0.02)
+            add_ln(p + "ln_2")
+            add(p + "mlp.c_fc.weight", (ffn, d), std)
+            add(p + "mlp.c_fc.bias", (ffn,), 0.02)
+            add(p + "mlp.c_proj.weight", (d, ffn), std)
+            add(p + "mlp.c_proj.bias", (d,), 0.02)
+    add_ln("ln_f")
+
+    def gen(item):
+        i, (name, shape, s, off) = item
+        a = np.random.default_rng([seed, i]).standard_normal(shape, dtype=np.float32)
+        a *= F32(s)
+        if off:
+            a += F32(off)
+        return name, a
+    n_thr = threads or min(32, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=n_thr) as ex:
+        return dict(ex.map(gen, enumerate(spec)))
+
+
 def alibi_slopes(n_head: int) -> np.ndarray:
     """build_alibi_tensor slopes (HF:bloom:62-79), float32."""
     import math
@@ -627,13 +700,17 @@ def topk_rows(scores, k):
 
 def exact_search(query_emb, query_ids: List[str], corpus_emb_chunks, corpus_ids: List[str],
                  top_k: int, score_function: str = "cos_sim",
-                 chunk_size: int = 50000) -> Dict[str, Dict[str, float]]:
+                 chunk_size: int = 50000, backend: str = "numpy") -> Dict[str, Dict[str, float]]:
     """DenseRetrievalExactSearch.search after the encode calls
     (biencoder/beir/custommodels/exact_search.py:80-132): per corpus chunk score
     (:96-98), NaN -> -1 (:99), topk(min(k+1,n)) (:102-108), drop corpus_id == query_id
     (:118), after the first chunk keep heapq.nlargest(min(k+1,len)) (:121-132).
 
     ``corpus_emb_chunks`` is a callable chunk_index -> fp32[n_chunk,d] or a full array.
+    backend "torch": the score / NaN / top-k lines run on the torch CPU primitives the reference itself calls
+    (F.normalize + torch.mm, util.py:41-43; torch.topk, exact_search.py:102-108) -- the timing stand-in for the
+    reference's CPU search leg in bench.py (scripts/cpu_search_ref_vs_port.py: within a few % of the reference's own
+    file on the same inputs; the numpy lines are ~6x slower, an argsort instead of a partial selection).
     """
     if score_function not in ("cos_sim", "dot"):
         raise ValueError(
@@ -642,12 +719,25 @@ def exact_search(query_emb, query_ids: List[str], corpus_emb_chunks, corpus_ids:
     fn = cos_sim if score_function == "cos_sim" else dot_score
     results: Dict[str, Dict[str, float]] = {qid: {} for qid in query_ids}
     n = len(corpus_ids)
+    if backend == "torch":
+        import torch
+        tq = torch.from_numpy(np.ascontiguousarray(query_emb, dtype=np.float32))
     for batch_num, start in enumerate(range(0, n, chunk_size)):
         end = min(start + chunk_size, n)
         sub = corpus_emb_chunks(batch_num) if callable(corpus_emb_chunks) else corpus_emb_chunks[start:end]
-        sc = fn(query_emb, sub)
-        sc[np.isnan(sc)] = -1
-        vals, idx = topk_rows(sc, min(top_k + 1, sc.shape[1]))
+        if backend == "torch":
+            ts = torch.from_numpy(np.ascontiguousarray(sub, dtype=np.float32))
+            if score_function == "cos_sim":
+                tsc = torch.mm(torch.nn.functional.normalize(tq, p=2, dim=1), torch.nn.functional.normalize(ts, p=2, dim=1).transpose(0, 1))
+            else:
+                tsc = torch.mm(tq, ts.transpose(0, 1))
+            tsc[torch.isnan(tsc)] = -1
+            tv, ti = torch.topk(tsc, min(top_k + 1, tsc.shape[1]), dim=1, largest=True, sorted=False)
+            vals, idx = tv.numpy(), ti.numpy()
+        else:
+            sc = fn(query_emb, sub)
+            sc[np.isnan(sc)] = -1
+            vals, idx = topk_rows(sc, min(top_k + 1, sc.shape[1]))
         for qi, qid in enumerate(query_ids):
             for sub_id, score in zip(idx[qi].tolist(), vals[qi].tolist()):
                 cid = corpus_ids[start + sub_id]

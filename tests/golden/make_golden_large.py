@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Full-SHAPE golden fixtures for BASELINE configs[2], [3], [4]: what the REFERENCE stack computes
+at SGPT-1.3B (24 layers, d 2048), SGPT-5.8B = GPT-J-6B (28 layers, d 4096, head_dim 256, rotary 64) and
+sgpt-bloom-7b1 (30 layers, d 4096, 32 heads) shape -- depth and width untouched; only the GPT-J / BLOOM vocabularies are
+shrunk to 2048 rows (the embedding table is a gather, not arithmetic; 250 880 x 4096 fp32 would be 4 GB of nothing).
+
+Runs only in the build container (needs /root/reference and HF transformers; ~25 GB of host RAM for the 6-7 G-parameter
+models, a few minutes of 8-core fp32 each):
+    HF GPTNeoModel / GPTJModel / BloomModel (eager attention, fp32, eval)    beir_dense_retriever.py:204-205, Transformer.py:72
+ -> the reference's Pooling.py (weightedmean)                               sentence_transformers/models/Pooling.py:99-125
+ -> the reference's util.cos_sim                                            sentence_transformers/util.py:24-43
+ -> the reference's DenseRetrievalExactSearch.search (top-10)               custommodels/exact_search.py:34-134
+Queries / documents carry the specb brackets of sentence_bert_asym.py:37-79 ([ ] / { }) in the GPT-Neo case.
+
+Weights are NOT stored: oracle.sgpt_oracle.synth_weights_streams(cfg, seed) regenerates them (one numpy stream per
+tensor, thread-parallel) on the GPU box.  Stored per case: token ids, pad_left, raw pooled embeddings, the cosine
+matrix, the reference's ranked top-10.  The numpy oracle is pinned against HF on a slice of every case (all layers).
+
+    python tests/golden/make_golden_large.py [neo13b] [gptj6b] [bloom7b1]
+"""
+import contextlib
+import gc
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from oracle import sgpt_oracle as O  # noqa: E402
+import make_golden as G  # noqa: E402
+
+
+@contextlib.contextmanager
+def no_init():
+    """Build an HF model without running any initialiser (6 G parameters of normal_() are minutes of nothing: every
+    tensor is replaced by load_state_dict(assign=True) right after)."""
+    import torch.nn.init as I
+    import transformers.initialization as TI
+    names = [n for n in dir(I) if n.endswith("_") and not n.startswith("_") and callable(getattr(I, n))]
+    saved = {n: getattr(I, n) for n in names}
+    for n in names:
+        setattr(I, n, lambda t, *a, **k: t)
+    try:
+        with TI.no_init_weights():
+            yield
+    finally:
+        for n, f in saved.items():
+            setattr(I, n, f)
+
+
+def hf_build(arch, cfg, w):
+    """HF model of the family holding the numpy weights (shared memory: no second copy of a 24 GB state dict)."""
+    if arch == "gpt_neo":
+        from transformers import GPTNeoConfig, GPTNeoModel
+        hc = GPTNeoConfig(vocab_size=cfg.vocab_size, max_position_embeddings=cfg.max_position_embeddings,
+                          hidden_size=cfg.hidden_size, num_layers=cfg.num_layers, num_heads=cfg.num_heads,
+                          intermediate_size=cfg.intermediate_size, window_size=cfg.window_size,
+                          attention_types=[[["global", "local"], cfg.num_layers // 2]],
+                          layer_norm_epsilon=cfg.layer_norm_epsilon, attention_dropout=0.0, resid_dropout=0.0,
+                          embed_dropout=0.0, bos_token_id=None, eos_token_id=None)
+        cls = GPTNeoModel
+    elif arch == "gptj":
+        from transformers import GPTJConfig, GPTJModel
+        hc = GPTJConfig(vocab_size=cfg.vocab_size, n_positions=cfg.max_position_embeddings, n_embd=cfg.hidden_size,
+                        n_layer=cfg.num_layers, n_head=cfg.num_heads, rotary_dim=cfg.rotary_dim,
+                        n_inner=cfg.intermediate_size, layer_norm_epsilon=cfg.layer_norm_epsilon, resid_pdrop=0.0,
+                        embd_pdrop=0.0, attn_pdrop=0.0, activation_function="gelu_new", bos_token_id=None, eos_token_id=None)
+        cls = GPTJModel
+    else:
+        from transformers import BloomConfig, BloomModel
+        hc = BloomConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, n_layer=cfg.num_layers,
+                         n_head=cfg.num_heads, layer_norm_epsilon=cfg.layer_norm_epsilon, hidden_dropout=0.0,
+                         attention_dropout=0.0, apply_residual_connection_post_layernorm=False, pretraining_tp=1,
+                         slow_but_exact=False, bos_token_id=None, eos_token_id=None, pad_token_id=None)
+        cls = BloomModel
+    hc._attn_implementation = "eager"
+    with no_init():
+        m = cls(hc).eval()
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False, assign=True)
+    assert not unexpected, unexpected
+    assert all(("bias" in k and "attn" in k) or "masked_bias" in k or "embed_positions" in k for k in missing), missing
+    return m
+
+
+def ref_encode(model, pm, seqs, pad_side, pad_id, batch):
+    """The reference's encode loop on id lists: batches of `batch` in the given order, tokenizer.pad to the batch
+    maximum (beir_dense_retriever.py:201), HF forward, Pooling.py weightedmean.  -> (embeddings, pad_left per sequence)"""
+    out, pad_left = [], []
+    for s0 in range(0, len(seqs), batch):
+        sub = seqs[s0:s0 + batch]
+        ids, mask = O.pad_batch(sub, pad_id=pad_id, side=pad_side)
+        with torch.no_grad():
+            h = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).last_hidden_state
+        out.append(pm.forward({"token_embeddings": h, "attention_mask": torch.from_numpy(mask)})["sentence_embedding"].numpy())
+        S = ids.shape[1]
+        pad_left += [S - len(s) if pad_side == "left" else 0 for s in sub]
+    return np.concatenate(out), np.asarray(pad_left, dtype=np.int32)
+
+
+def ref_search(ES, q_emb, d_emb, topk):
+    """The reference's DenseRetrievalExactSearch over the reference embeddings (fake encoder that looks them up)."""
+    nd, nq = len(d_emb), len(q_emb)
+    corpus = {f"d{i}": {"title": "", "text": "x" * (1 + i % 7)} for i in range(nd)}
+    queries = {f"q{i}": "q" for i in range(nq)}
+
+    class Fake:
+        def encode_queries(self, qq, batch_size, **kw):
+            return torch.from_numpy(np.stack([q_emb[int(qid[1:])] for qid, _ in qq]))
+
+        def encode_corpus(self, cs, batch_size, **kw):
+            return torch.from_numpy(np.stack([d_emb[int(cid[1:])] for cid, _ in cs]))
+    res = ES.DenseRetrievalExactSearch(Fake(), batch_size=8, corpus_chunk_size=max(8, nd // 3 + 1)).search(corpus, queries, topk, "cos_sim")
+    return np.array([[int(c[1:]) for c in sorted(res[f"q{i}"], key=lambda c: (-res[f"q{i}"][c], int(c[1:])))[:topk]]
+                     for i in range(nq)], dtype=np.int64)
+
+
+def flat(seqs):
+    return np.concatenate([np.asarray(s, dtype=np.int32) for s in seqs]), np.asarray([len(s) for s in seqs], dtype=np.int32)
+
+
+def case(tag, arch, cfg_kw, seed, std, groups, Pooling, U, ES, topk=10):
+    """groups: list of (name, seqs, pad_side, batch, is_query).  Every group is encoded by the reference loop in its own
+    batches; all document groups form the corpus, all query groups the queries."""
+    t0 = time.time()
+    cfg = {"gpt_neo": O.NeoConfig, "gptj": O.GPTJConfig, "bloom": O.BloomConfig}[arch](**cfg_kw)
+    w = O.synth_weights_streams(cfg, seed=seed, std=std)
+    print(f"[{tag}] weights: {sum(v.size for v in w.values()) / 1e9:.2f} G parameters in {time.time() - t0:.0f} s", flush=True)
+    model = hf_build(arch, cfg, w)
+    pm = Pooling.Pooling(cfg.hidden_size, pooling_mode_weightedmean_tokens=True, pooling_mode_mean_tokens=False)
+    pad_id = min(O.GPT2_PAD, cfg.vocab_size - 1)
+    seqs_all, pl_all, emb_all, isq_all, grp_all = [], [], [], [], []
+    for gi, (name, seqs, side, batch, is_query) in enumerate(groups):
+        t = time.time()
+        emb, pl = ref_encode(model, pm, seqs, side, pad_id, batch)
+        print(f"[{tag}] group {name}: {len(seqs)} sequences, {sum(map(len, seqs))} tokens, {side}-padded batches of {batch}: "
+              f"{time.time() - t:.0f} s", flush=True)
+        seqs_all += list(seqs)
+        pl_all.append(pl)
+        emb_all.append(emb)
+        isq_all += [1 if is_query else 0] * len(seqs)
+        grp_all += [gi] * len(seqs)
+    emb = np.concatenate(emb_all)
+    pad_left = np.concatenate(pl_all)
+    isq = np.asarray(isq_all, dtype=np.int8)
+    q_emb, d_emb = emb[isq == 1], emb[isq == 0]
+    cos = U.cos_sim(torch.from_numpy(q_emb), torch.from_numpy(d_emb)).numpy()
+    ranked = ref_search(ES, q_emb, d_emb, topk)
+    brute = np.argsort(-cos, axis=1, kind="stable")[:, :topk]
+    assert np.array_equal(ranked, brute), "reference exact_search top-k != brute force on the reference cosine matrix"
+    # ---- pin the numpy oracle at this depth / width: the two shortest sequences of every group, all layers ----
+    t = time.time()
+    worst = 0.0
+    for gi, (name, seqs, side, batch, is_query) in enumerate(groups):
+        idx = [i for i, g in enumerate(grp_all) if g == gi]
+        pick = sorted(idx, key=lambda i: len(seqs_all[i]))[:2]
+        for i in pick:
+            # the oracle sees the sequence with the same left padding the reference batch gave it
+            ids = np.full((1, pad_left[i] + len(seqs_all[i])), pad_id, dtype=np.int64)
+            mask = np.zeros_like(ids)
+            ids[0, pad_left[i]:] = seqs_all[i]
+            mask[0, pad_left[i]:] = 1
+            last, _ = O.forward_any(w, cfg, ids, mask, output_hidden_states=True)
+            got = O.pool(last, mask, "weightedmean")
+            worst = max(worst, float(np.abs(got[0] - emb[i]).max() / np.linalg.norm(emb[i])))
+    print(f"[{tag}] oracle vs HF (2 sequences per group, all {cfg.num_layers} layers): max|d emb|/||emb|| = {worst:.2e} "
+          f"({time.time() - t:.0f} s)", flush=True)
+    assert worst < 2e-5, worst
+    ids_flat, lens = flat(seqs_all)
+    srt = -np.sort(-cos, axis=1)
+    meta = dict(tag=tag, arch=arch, cfg=cfg_kw, seed=seed, std=std, topk=topk, n_docs=int((isq == 0).sum()), n_queries=int(isq.sum()),
+                groups=[dict(name=g[0], pad_side=g[2], batch=g[3], is_query=bool(g[4]), n=len(g[1])) for g in groups],
+                oracle_vs_hf_rel=worst, emb_norm_range=[float(np.linalg.norm(emb, axis=1).min()), float(np.linalg.norm(emb, axis=1).max())],
+                cos_range=[float(cos.min()), float(cos.max())], min_gap_rank10_11=float((srt[:, topk - 1] - srt[:, topk]).min()))
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), ids=ids_flat, lens=lens, pad_left=pad_left, is_query=isq,
+                        group=np.asarray(grp_all, dtype=np.int8), emb=emb.astype(np.float32), cos=cos.astype(np.float32),
+                        top10=ranked, meta=np.array(json.dumps(meta)))
+    print(f"[{tag}] wrote {tag}.npz in {time.time() - t0:.0f} s: {json.dumps(meta)}", flush=True)
+    del model, w
+    gc.collect()
+
+
+def main():
+    which = set(sys.argv[1:]) or {"neo13b", "gptj6b", "bloom7b1"}
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(os.cpu_count() or 1)
+    Pooling = G.load_file_module("ref_pooling", f"{G.ST}/models/Pooling.py")
+    U = G.load_ref_util()
+    ES = G.load_ref_exact_search(U)
+
+    if "neo13b" in which:
+        # configs[2]: SGPT-1.3B, asymmetric MSMARCO-style search with the specb brackets; documents up to the reference's
+        # max_seq_length 300 (sentence_bert_asym.py: 298 content tokens + 2 brackets) -> the 256-token local window is live
+        rng = np.random.default_rng(31)
+        docs = [O.specb_wrap(rng.integers(0, 50256, size=int(n)).tolist(), is_query=False)
+                for n in np.concatenate([[298, 297], rng.integers(150, 297, size=94)])]
+        docs.sort(key=len, reverse=True)                                  # the reference sorts by length (exact_search.py:66-71)
+        qs = [O.specb_wrap(rng.integers(0, 50256, size=int(n)).tolist(), is_query=True) for n in rng.integers(4, 31, size=32)]
+        case("cfg3_neo13b_specb", "gpt_neo", dict(O.SGPT_1_3B), seed=3, std=0.02,
+             groups=[("docs", docs, "right", 8, False), ("queries", qs, "right", 16, True)], Pooling=Pooling, U=U, ES=ES)
+    if "gptj6b" in which:
+        # configs[3]: SGPT-5.8B = GPT-J-6B shape (vocabulary shrunk), 96 documents x 128 tokens + 32 queries
+        rng = np.random.default_rng(41)
+        V = 2048
+        docs = [rng.integers(0, V - 1, size=128).tolist() for _ in range(96)]
+        qs = [rng.integers(0, V - 1, size=int(n)).tolist() for n in rng.integers(4, 33, size=32)]
+        case("cfg4_gptj6b", "gptj", dict(O.SGPT_5_8B, vocab_size=V), seed=4, std=0.02,
+             groups=[("docs", docs, "right", 8, False), ("queries", qs, "right", 16, True)], Pooling=Pooling, U=U, ES=ES)
+    if "bloom7b1" in which:
+        # configs[4]: sgpt-bloom-7b1 shape (vocabulary shrunk).  BLOOM tokenizers pad LEFT and the pooling weights follow the
+        # padded index (Pooling.py:104-112): one document group left-padded (as the real tokenizer does), one right-padded
+        rng = np.random.default_rng(51)
+        V = 2048
+        lens = rng.integers(64, 129, size=48)
+        dl = [rng.integers(0, V - 1, size=int(n)).tolist() for n in lens]
+        dr = [rng.integers(0, V - 1, size=int(n)).tolist() for n in lens]
+        qs = [rng.integers(0, V - 1, size=int(n)).tolist() for n in rng.integers(4, 33, size=32)]
+        case("cfg5_bloom7b1", "bloom", dict(O.SGPT_BLOOM_7B1, vocab_size=V), seed=5, std=0.02,
+             groups=[("docs_left", dl, "left", 8, False), ("docs_right", dr, "right", 8, False),
+                     ("queries_left", qs, "left", 16, True)], Pooling=Pooling, U=U, ES=ES)
+
+
+if __name__ == "__main__":
+    main()

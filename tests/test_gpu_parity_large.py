@@ -1,0 +1,126 @@
+"""-m gpu: parity at the FULL shape of BASELINE configs[2], [3], [4] against the REFERENCE stack.
+
+tests/golden/cfg3_neo13b_specb.npz, cfg4_gptj6b.npz, cfg5_bloom7b1.npz hold what the reference computes at SGPT-1.3B
+(24 layers, d 2048, specb brackets, documents up to 300 tokens), GPT-J-6B (28 layers, d 4096, head_dim 256, rotary 64) and
+bloom-7b1 (30 layers, d 4096, 32 heads; left- and right-padded batches) shape: HF model fp32 eager -> the reference's
+Pooling.py (weightedmean) -> the reference's util.cos_sim -> the reference's DenseRetrievalExactSearch top-10
+(tests/golden/make_golden_large.py; the weights are regenerated here from the seed, one numpy stream per tensor).
+
+Every case goes through the HIP path in ONE sgpt_encode call whose projections all run on the 256x256-tile throughput
+kernels (the launch shapes are checked), then through the 16-bit scorer.
+
+north_star bar: embeddings and ranked cosine scores within 1e-3 of the reference CPU path.
+  f16 operands (the default and benchmarked mode): held to the bar.
+  bf16 / fp8 storage / fp8 MFMA: reported, asserted at ~1.5 x the measured deviation (SURVEY 7 allows report-only for fp8)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, maxabs
+from oracle import sgpt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BAR = 1e-3
+TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16, "fp8": torch.bfloat16, "fp8mfma": torch.bfloat16}
+# max |cos - cos_ref| allowed per case and operand format; f16 is the north_star bar, the others ~1.5 x measured (r03)
+BUDGET = {
+    "cfg3_neo13b_specb": {"f16": BAR, "bf16": 6e-3},
+    "cfg4_gptj6b": {"f16": BAR, "bf16": 6e-3, "fp8mfma": 8e-2},
+    "cfg5_bloom7b1": {"f16": BAR, "bf16": 6e-3, "fp8": 8e-2, "fp8mfma": 8e-2},
+}
+CASES = [(tag, dt) for tag, per in BUDGET.items() for dt in per]
+
+_weights = {}
+
+
+def case_weights(tag, meta):
+    """Seed-regenerated weights of a case, kept for the dtypes of that case only (6 G parameters = 24 GB of host RAM)."""
+    if tag not in _weights:
+        _weights.clear()
+        arch = meta["arch"]
+        cfg = {"gpt_neo": O.NeoConfig, "gptj": O.GPTJConfig, "bloom": O.BloomConfig}[arch](**meta["cfg"])
+        t = time.time()
+        _weights[tag] = O.synth_weights_streams(cfg, seed=meta["seed"], std=meta["std"])
+        print(f"{tag}: {sum(v.size for v in _weights[tag].values()) / 1e9:.2f} G parameters regenerated in {time.time() - t:.0f} s")
+    return _weights[tag]
+
+
+@pytest.mark.parametrize("tag,dtype", CASES, ids=[f"{t}-{d}" for t, d in CASES])
+def test_full_shape_cosine_and_ranked_top10_vs_reference(tag, dtype):
+    from sgpt_amd import SGPTConfig, SGPTModel, get_context
+    fx = np.load(os.path.join(GOLDEN, f"{tag}.npz"))
+    meta = json.loads(str(fx["meta"]))
+    w = case_weights(tag, meta)
+    arch = meta["arch"]
+    scfg = SGPTConfig(**meta["cfg"]) if arch == "gpt_neo" else SGPTConfig.from_hf_dict(dict(meta["cfg"], model_type=arch))
+    ctx = get_context("cuda:0")
+    lens = fx["lens"].astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    seqs = [fx["ids"][off[i]: off[i + 1]].tolist() for i in range(len(lens))]
+    pad_left = fx["pad_left"].astype(np.int64).tolist()
+    isq = fx["is_query"].astype(bool)
+    m = SGPTModel(scfg, w, device="cuda:0", dtype=dtype, max_tokens_per_call=1 << 17)
+    try:
+        if dtype == "fp8mfma":
+            m.calibrate(seqs[:: max(1, len(seqs) // 16)])                # calibrated on a slice of the case's own inputs
+        # every projection of the call must take the 256x256 LDS-DMA kernel: more than half a wave of tiles for the
+        # narrowest launch (N = d_model), sgpt_amd/csrc/gemm.hip::launch_gemm16
+        alloc = int(((lens + 7) // 8 * 8).sum())
+        T_pad = (alloc + 255) // 256 * 256
+        assert alloc <= m.max_tokens_per_call and (T_pad // 256) * (scfg.hidden_size // 256) * 2 > 256, (alloc, T_pad)
+        t = time.time()
+        emb = m.encode_ids(seqs, pad_left=pad_left)                      # ONE sgpt_encode call
+        torch.cuda.synchronize()
+        t_enc = time.time() - t
+        shifts = m.range_shifts() if dtype == "f16" else None
+    finally:
+        m.close()
+        torch.cuda.empty_cache()
+    ref = fx["emb"]
+    emb_np = emb.cpu().numpy()
+    assert np.isfinite(emb_np).all()
+    rel = float((np.abs(emb_np - ref).max(1) / np.linalg.norm(ref, axis=1)).max())
+    sdt = TORCH_DT[dtype]
+    en = ctx.l2_normalize(emb)
+    e_dev = maxabs(en.cpu().numpy(), O.normalize(ref))
+    qi, di = np.nonzero(isq)[0], np.nonzero(~isq)[0]
+    qn = en[torch.from_numpy(qi).to(en.device)].contiguous()
+    dn = en[torch.from_numpy(di).to(en.device)].contiguous()
+    cos = ctx.scores(ctx._operand(qn, sdt), ctx._operand(dn, sdt), dtype=sdt).cpu().numpy()
+    c_dev = maxabs(cos, fx["cos"])
+    budget = BUDGET[tag][dtype]
+    k = meta["topk"]
+    val, idx, n = ctx.score_topk(ctx._operand(qn, sdt), ctx._operand(dn, sdt), k, dtype=sdt)
+    val, idx = val.cpu().numpy(), idx.cpu().numpy()
+    ref_cos, ref_top = fx["cos"], fx["top10"]
+    ref_sorted = np.take_along_axis(ref_cos, ref_top, 1)
+    overlap = [k - len(set(idx[q].tolist()) - set(ref_top[q].tolist())) for q in range(len(qi))]
+    same_rank = int(sum(np.array_equal(idx[q], ref_top[q]) for q in range(len(qi))))
+    line = (f"{tag} {dtype}: {len(seqs)} sequences / {alloc} token rows in one call ({t_enc * 1e3:.0f} ms incl. pack); "
+            f"max|emb-ref|/||ref|| = {rel:.2e}, normalised max|emb-ref| = {e_dev:.2e}, max|cos-ref| = {c_dev:.2e} over {cos.size} pairs "
+            f"(budget {budget:g}); top-{k} id overlap mean {np.mean(overlap):.2f} min {min(overlap)}, identical ranking "
+            f"{same_rank}/{len(qi)}" + (f"; range shifts max {int(shifts.max())}" if shifts is not None else ""))
+    print(line)
+    out_dir = os.environ.get("SGPT_PARITY_LOG")
+    if out_dir:
+        with open(out_dir, "a") as f:
+            f.write(json.dumps(dict(case=tag, dtype=dtype, rows=alloc, rel_emb=rel, max_abs_norm_emb=e_dev, max_abs_cos=c_dev,
+                                    budget=budget, top10_overlap_mean=float(np.mean(overlap)), identical_rank=same_rank,
+                                    n_queries=int(len(qi)), n_docs=int(len(di)))) + "\n")
+    assert np.isfinite(cos).all() and n == k
+    assert c_dev < budget and e_dev < budget, line
+    # ranked top-k through the fused scorer: every returned score within the budget of the reference score of its pair,
+    # rank-for-rank scores within the budget of the reference's ranked scores; a document outside the reference top-k may
+    # appear only where the reference itself separates it from its k-th hit by less than 2 x budget
+    assert maxabs(val, np.take_along_axis(ref_cos, idx, 1)) < budget
+    assert maxabs(val, ref_sorted) < budget
+    for q in range(len(qi)):
+        for doc in set(idx[q].tolist()) - set(ref_top[q].tolist()):
+            assert ref_sorted[q, k - 1] - ref_cos[q, doc] < 2 * budget, (q, doc)
+    if dtype == "f16":
+        assert shifts is not None and int(shifts.max()) == 0        # std-0.02 random-init weights stay inside the half range

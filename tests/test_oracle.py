@@ -179,3 +179,20 @@ def test_crossencoder_loglikelihood_golden():
     # truncation rule: instruction kept, rest cut from the left, last token dropped
     inp = O.ce_model_input(list(range(100, 170)), list(range(12)), 48, 3)
     assert inp[:3] == [100, 101, 102] and len(inp) == 48 and inp[-1] == 10 and inp[3] == 100 + 70 - (46 - 12)
+
+
+def test_exact_search_torch_backend_equals_numpy_lines():
+    """oracle.exact_search(backend="torch") -- bench.py's CPU search baseline -- returns the hit sets and scores of the
+    numpy lines (which the golden fixtures pin against the reference's exact_search.py)."""
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((9, 32)).astype(np.float32)
+    c = rng.standard_normal((257, 32)).astype(np.float32)
+    c[5] = 0.0                                             # zero row: cosine 0 through the eps clamp, not NaN
+    qids, cids = [f"q{i}" for i in range(9)], [f"d{i}" for i in range(257)]
+    qids[2] = "d7"                                         # the corpus_id != query_id rule
+    for fn in ("cos_sim", "dot"):
+        a = O.exact_search(q, qids, c, cids, 5, fn, chunk_size=100)
+        b = O.exact_search(q, qids, c, cids, 5, fn, chunk_size=100, backend="torch")
+        for qid in qids:
+            assert set(a[qid]) == set(b[qid]) and "d7" not in b["d7"]
+            assert max(abs(a[qid][k] - b[qid][k]) for k in a[qid]) < 1e-5
