@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPT_ABI_VERSION 4
+#define SGPT_ABI_VERSION 5
 
 typedef int sgpt_status;
 #define SGPT_OK 0
@@ -42,7 +42,8 @@ typedef int sgpt_status;
 #define SGPT_ERR_HIP (-2)         /* a HIP runtime call failed */
 #define SGPT_ERR_MISSING (-3)     /* a required weight tensor was not supplied */
 #define SGPT_ERR_OOM (-4)
-#define SGPT_ERR_RANGE (-5)       /* SGPT_F16: a weight / LayerNorm parameter does not fit the f16 range */
+#define SGPT_ERR_COMM (-6)        /* an RCCL call failed */
+#define SGPT_ERR_RANGE (-5)       /* SGPT_F16: a matmul weight does not fit the f16 range, or an activation class is beyond every range shift */
 
 typedef struct sgpt_ctx sgpt_ctx;
 typedef struct sgpt_model sgpt_model;
@@ -68,10 +69,14 @@ typedef struct {
     int32_t compute_dtype;   /* SGPT_F16 : IEEE half MFMA operands (weights, LN output, q/k/v, probabilities, context, GELU
                                            output), fp32 accumulate/residual/LN/softmax -- the same MFMA rate as bf16 with 3
                                            more mantissa bits: the mode that meets the 1e-3 cosine bar against the fp32
-                                           reference.  Range-guarded: sgpt_model_load refuses weights /
-                                           LayerNorm parameters outside the f16 range (SGPT_ERR_RANGE) and every kernel that
-                                           rounds an activation to f16 raises a device flag at |v| >= 32768, read with
-                                           sgpt_range_check;
+                                           reference.  Range-managed: every operand class of a block (LayerNorm
+                                           outputs, q | k | v + attention context, GELU output) is stored under a power-of-two
+                                           down-shift (0 by default) that the consuming GEMM undoes on its fp32 accumulators
+                                           -- exact, the f16 analogue of the e4m3 scales of SGPT_FP8M.  sgpt_model_load
+                                           derives the LayerNorm shifts from the parameters and refuses only weights outside
+                                           the format (SGPT_ERR_RANGE); every kernel that rounds an activation to f16 records
+                                           |v| >= 32768 in a per-model device word (sgpt_model_range_check), from which
+                                           sgpt_model_range_adapt raises the shifts of exactly the classes that overflowed;
                                 SGPT_BF16: bf16 MFMA operands, fp32 accumulate/residual/LN/softmax;
                                 SGPT_F32 : exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the parity gate;
                                 SGPT_FP8W: the six matmul weights per block are STORED as OCP e4m3fn with one
@@ -208,10 +213,25 @@ sgpt_status sgpt_l2_normalize(sgpt_ctx* ctx, const float* in, int64_t n, int32_t
 sgpt_status sgpt_f32_to_16(sgpt_ctx* ctx, const float* in, int64_t numel, void* out, int32_t out_dtype, void* stream);
 sgpt_status sgpt_f32_to_bf16(sgpt_ctx* ctx, const float* in, int64_t numel, void* out, void* stream);
 
-/* SGPT_F16 range guard: *flagged = 1 when, since the last reset, a kernel rounded an activation of magnitude >= 32768
- * (or a non-finite one) to f16 -- the results of the affected calls are not trustworthy and the model should be
- * re-loaded with SGPT_BF16 (bit 0 of *flagged) -- or an SGPT_FP8M GELU output saturated its e4m3 codes (bit 1: re-calibrate).  Synchronises `stream` (one 4-byte read-back); the Python host calls it once per
- * encode_ids() and raises.  The reference's fp32 CPU path has no such failure mode. */
+/* Range guards.  The reference's fp32 CPU path cannot overflow, so the 16-bit / 8-bit paths must never do so silently.
+ * sgpt_model_range_check: *flagged = the model's guard word since the last reset --
+ *     bit 0: an sgpt_encode* call on this SGPT_F16 model rounded an activation of magnitude >= 32768 (or +-inf) to f16: the
+ *            results of the affected calls are not trustworthy; call sgpt_model_range_adapt and re-run them;
+ *     bit 1: an SGPT_FP8M GELU output saturated its e4m3 codes;  bit 2: an SGPT_FP8M attention context did (re-calibrate).
+ *   Per model: a flag raised by one model is never attributed to another one sharing the ctx.  Synchronises `stream` (one
+ *   4-byte read-back); the Python host calls it once per encode_ids().
+ * sgpt_model_range_adapt (SGPT_F16): reads the magnitudes the flagged launches recorded per (block, operand class), raises
+ *   the power-of-two shift of each such class so that the recorded maximum lands at <= 16384, clears bit 0 and returns the
+ *   number of classes raised through *n_raised (0: nothing recorded).  Shifts never decrease; a class that would need more
+ *   than 2^40 returns SGPT_ERR_RANGE.  Bumps sgpt_ctx_generation (captured graphs carry the factors as kernel arguments).
+ * sgpt_model_get/set_range_shifts: the 4 * n_layers exponents (per block: LayerNorm-1 output, q | k | v, LayerNorm-2 output,
+ *   GELU output) -- to pin the shifts found on one run for reproducible embeddings on the next (a shift changes results only
+ *   through f16 subnormals: |v| * 2^-k < 6.1e-5).
+ * sgpt_range_check: the same bit 0 for the ctx-level stand-alone ops (sgpt_linear with f16 output). */
+sgpt_status sgpt_model_range_check(sgpt_model* model, int32_t* flagged, int32_t reset, void* stream);
+sgpt_status sgpt_model_range_adapt(sgpt_model* model, int32_t* n_raised, void* stream);
+sgpt_status sgpt_model_get_range_shifts(sgpt_model* model, int32_t* shifts, int32_t n);
+sgpt_status sgpt_model_set_range_shifts(sgpt_model* model, const int32_t* shifts, int32_t n);
 sgpt_status sgpt_range_check(sgpt_ctx* ctx, int32_t* flagged, int32_t reset, void* stream);
 
 /* hipGraph support.  sgpt_ctx_generation changes whenever a library-owned buffer that launched kernels point into is
@@ -270,6 +290,35 @@ sgpt_status sgpt_topk_merge(sgpt_ctx* ctx, const float* val, const int64_t* idx,
                             int32_t m, int32_t k, const int64_t* exclude_idx,
                             float* out_val, int64_t* out_idx, void* stream);
 
+/* -- a9 / 8e: multi-GPU exchange steps on RCCL (one process per GPU, xGMI) ---------------------------------------------- */
+/* One communicator per ctx.  Rank 0 creates the 128-byte id (ncclGetUniqueId), the host carries it to the other ranks by
+ * any means (sgpt_amd/dist.py: one torch.distributed broadcast, the only use of torch.distributed on this path), every rank
+ * calls sgpt_comm_init (collective, blocking: ncclCommInitRank).  sgpt_ctx_destroy tears the communicator down.
+ *
+ * sgpt_allgather_rows replaces the reference's two-step util.mismatched_sizes_all_gather
+ * (sentence_transformers/util.py:326-347: all-gather the sizes, pad to the maximum, all-gather the rows): rank r contributes
+ * counts[r] rows of row_bytes bytes (counts: host int64[world], known to every rank because shards are a pure function of the
+ * global length list -- SentenceTransformer.py:159-163, or the token-balanced cut of sgpt_amd/st.py); out device
+ * [sum(counts)][row_bytes] receives the blocks in rank order.  Equal counts: ONE ncclAllGather straight into `out`; ragged:
+ * padded to the largest block through the exchange workspace and compacted.  Asynchronous on `stream`.
+ *
+ * sgpt_exchange_topk is the last step of the corpus-sharded search: every rank holds the k best (score, global
+ * index) pairs per query of ITS corpus shard (sgpt_score_topk with idx_base = the shard's first global index); the lists are
+ * all-gathered (two ncclAllGathers in one group) and the k_out best of the world * k candidates per query are selected by
+ * the library's merge kernel on the same stream -- the heapq.nlargest merge of exact_search.py:121-132 including the
+ * `corpus_id != query_id` rule (:118) through exclude_idx (device int64[nq] or NULL).  Ties -> lowest index: every rank gets
+ * identical results.  val device fp32[nq,k], idx device int64[nq,k] -> out_val fp32[nq,k_out], out_idx int64[nq,k_out]. */
+#define SGPT_COMM_ID_BYTES 128
+sgpt_status sgpt_comm_unique_id(uint8_t* id /* [SGPT_COMM_ID_BYTES], host */);
+sgpt_status sgpt_comm_init(sgpt_ctx* ctx, const uint8_t* id, int32_t rank, int32_t world);
+sgpt_status sgpt_comm_destroy(sgpt_ctx* ctx);
+int32_t sgpt_comm_world(const sgpt_ctx* ctx);     /* 0 = no communicator */
+int32_t sgpt_comm_rank(const sgpt_ctx* ctx);
+sgpt_status sgpt_allgather_rows(sgpt_ctx* ctx, const void* local, const int64_t* counts, int64_t row_bytes, void* out,
+                                void* stream);
+sgpt_status sgpt_exchange_topk(sgpt_ctx* ctx, const float* val, const int64_t* idx, int32_t nq, int32_t k, int32_t k_out,
+                               const int64_t* exclude_idx, float* out_val, int64_t* out_idx, void* stream);
+
 /* Plain top-k over a materialised score matrix: torch.topk(scores, k, dim=1)
  * (exact_search.py:102-108; util.semantic_search util.py:241).  NaN -> -1 first (:99). */
 sgpt_status sgpt_topk(sgpt_ctx* ctx, const float* scores, int32_t nq, int64_t n, int64_t ld,
@@ -312,22 +361,18 @@ sgpt_status sgpt_linear_fp8(sgpt_ctx* ctx, int32_t epi, int32_t out_dtype, const
 sgpt_status sgpt_prof_enable(sgpt_ctx* ctx, int32_t on);
 sgpt_status sgpt_prof_read(sgpt_ctx* ctx, int64_t* launches, double* ms, double* flops, int32_t reset);
 
-/* Process-wide choice between the two 256x256-tile GEMM kernels (bit 0 -- 0: v_mfma_f32_16x16x32, 1: v_mfma_f32_32x32x16;
- * bit 1: use them even for problems of less than half a wave of tiles, which normally take the small-tile kernel; default
- * from env SGPT_GEMM_W, else the library's built-in default).  Both accumulate the same products in fp32 in ascending k;
- * the results agree to fp32 rounding (the two instructions group the products of a k-step differently), so this is a
- * speed knob for in-process A/B measurements.  Returns the previous value. */
-int32_t sgpt_set_gemm_variant(int32_t variant);
-/* Start-up stagger of the persistent 256x256 GEMM workgroups in shader cycles per phase (4 phases per XCD; 0 = off; default
- * from env SGPT_SKEW): de-synchronises the CUs' store epilogues.  A speed knob; results are unaffected. */
-int32_t sgpt_set_gemm_skew(int32_t cycles);
-/* Low-latency mode for query-sized launches (process-wide; default from env SGPT_KGROUPS, else 1 = off).  With 2, GEMM
- * launches that have fewer 64x64 tiles than workgroup slots split each tile's k range over two groups of waves that run
- * concurrently and add their fp32 accumulators in a fixed order: a 16-query SGPT-125M encode drops from 1.05 to 0.88 ms.
- * Deterministic, but the sum is no longer the k-ascending one every other kernel produces, so with this mode on an
- * embedding depends (at 16-bit operand-rounding level, <= 5e-4 on normalised bf16 embeddings) on whether its batch was
- * small enough to take this path.  Off, every batch size produces identical bits.  Returns the previous value. */
-int32_t sgpt_set_gemm_kgroups(int32_t groups);
+/* Per-ctx run-time policies (the library holds no process-global mutable state and reads no environment variable).
+ * sgpt_ctx_set_low_latency: on = 1 lets GEMM launches that have fewer 64x64 tiles than workgroup slots (query-sized batches)
+ *   split each tile's k range over two groups of waves that run concurrently and add their fp32 accumulators in a fixed
+ *   order: a 16-query SGPT-125M encode drops from 1.05 to 0.88 ms.  Deterministic, but the sum is no longer the k-ascending
+ *   one every other kernel produces, so with the mode on an embedding depends (at 16-bit operand-rounding level, <= 5e-4 on
+ *   normalised bf16 embeddings) on whether its batch was small enough to take this path.  Off (default), every batch size
+ *   produces identical bits.  Returns the previous setting.
+ * sgpt_ctx_set_tile_policy: 0 (default) = problems with less than half a wave of 256x256 tiles take the 128x128 / 64x64
+ *   register-staged kernel; 1 = keep the 256x256 LDS-DMA kernel wherever the shape allows (kernel-level tests of
+ *   single-tile shapes; identical bits either way).  Returns the previous policy. */
+int32_t sgpt_ctx_set_low_latency(sgpt_ctx* ctx, int32_t on);
+int32_t sgpt_ctx_set_tile_policy(sgpt_ctx* ctx, int32_t policy);
 
 /* Micro-benchmark of one GEMM launch configuration (library-owned pseudo-random operands, never
  * zeros): average milliseconds per launch over `iters` launches.  epi: 0 store, 1 bias+gelu,

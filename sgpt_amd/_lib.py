@@ -8,8 +8,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGPT_HIP_LIB") or os.path.join(HERE, "lib", "libsgpt_hip.so")   # env: A/B builds of the same ABI
 
 SGPT_F32, SGPT_BF16, SGPT_FP8W, SGPT_F16, SGPT_FP8M = 0, 1, 2, 3, 4
-SGPT_ABI_VERSION = 4
+SGPT_ABI_VERSION = 5
 SGPT_ERR_RANGE = -5
+SGPT_ERR_COMM = -6
+SGPT_COMM_ID_BYTES = 128
 SGPT_ARCH_GPTNEO, SGPT_ARCH_GPTJ, SGPT_ARCH_BLOOM = 0, 1, 2
 POOL_MODES = {"weightedmean": 0, "mean": 1, "lasttoken": 2, "learntmean": 3}
 
@@ -75,9 +77,20 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "sgpt_linear_fp8": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
-    "sgpt_set_gemm_variant": (C.c_int32, [C.c_int32]),
-    "sgpt_set_gemm_skew": (C.c_int32, [C.c_int32]),
-    "sgpt_set_gemm_kgroups": (C.c_int32, [C.c_int32]),
+    "sgpt_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "sgpt_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "sgpt_comm_destroy": (C.c_int, [C.c_void_p]),
+    "sgpt_comm_world": (C.c_int32, [C.c_void_p]),
+    "sgpt_comm_rank": (C.c_int32, [C.c_void_p]),
+    "sgpt_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sgpt_exchange_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgpt_ctx_set_low_latency": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "sgpt_ctx_set_tile_policy": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "sgpt_model_range_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]),
+    "sgpt_model_range_adapt": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "sgpt_model_get_range_shifts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "sgpt_model_set_range_shifts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "sgpt_bench_gemm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.POINTER(C.c_float)]),
     "sgpt_prof_enable": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -93,7 +106,15 @@ class SgptHipError(RuntimeError):
 
 
 class SgptRangeError(SgptHipError):
-    """dtype='f16': a weight or an activation left the IEEE-half range (|v| >= 32768); use dtype='bf16'."""
+    """dtype='f16': a weight is outside the IEEE-half range, or an activation class is beyond every power-of-two range
+    shift (use dtype='bf16'); dtype='fp8mfma': an e4m3 code saturated (re-calibrate)."""
+
+# symbols that exist only in the experiment build (SGPT_EXPERIMENTS=1 python -m sgpt_amd.build -> libsgpt_hip_exp.so,
+# selected with SGPT_HIP_LIB): A/B knobs of scripts/, never part of the product ABI
+EXPERIMENT_SIGNATURES = {
+    "sgpt_exp_set_gemm_skew": (C.c_int32, [C.c_int32]),
+    "sgpt_exp_set_gemm_w": (C.c_int32, [C.c_int32]),
+}
 
 
 def load():
@@ -109,6 +130,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENT_SIGNATURES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     if lib.sgpt_abi_version() != SGPT_ABI_VERSION:
         raise SgptHipError("libsgpt_hip.so ABI version mismatch: rebuild with `python -m sgpt_amd.build --force`")
     _lib = lib

@@ -8,10 +8,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libsgpt_hip.so")
-SOURCES = ["gemm.hip", "gemm256w.hip", "gemm256q.hip", "attn.hip", "elementwise.hip", "topk.hip", "api.hip"]
+# SGPT_EXPERIMENTS=1: the measurement scripts' build (libsgpt_hip_exp.so): environment A/B switches, the s_memtime stamps and
+# the slower 32x32x16-MFMA re-tiling (gemm256w.hip) compiled in.  The product library has none of them.
+EXPERIMENTS = os.environ.get("SGPT_EXPERIMENTS") == "1"
+LIB = os.path.join(LIBDIR, "libsgpt_hip_exp.so" if EXPERIMENTS else "libsgpt_hip.so")
+SOURCES = ["gemm.hip", "gemm256q.hip", "attn.hip", "elementwise.hip", "topk.hip", "comm.hip", "api.hip"] + (["gemm256w.hip"] if EXPERIMENTS else [])
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wno-unused-result"] + os.environ.get("SGPT_EXTRA_FLAGS", "").split()
+         "-Wno-unused-result"] + (["-DSGPT_EXPERIMENTS"] if EXPERIMENTS else []) + os.environ.get("SGPT_EXTRA_FLAGS", "").split()
+OBJ_SUFFIX = ".exp.o" if EXPERIMENTS else ".o"
 
 
 def _hipcc():
@@ -36,7 +40,7 @@ def build(force=False, verbose=False):
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        op = os.path.join(LIBDIR, src.replace(".hip", OBJ_SUFFIX))
         objs.append(op)
         if force or _stale(op, [sp] + headers):
             jobs.append([hipcc] + FLAGS + ["-c", sp, "-o", op])
@@ -52,7 +56,10 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        # librccl: the exchange steps of the multi-GPU search (comm.hip).  torch ships its own copy under the same soname
+        # (librccl.so.1): in a process that imported torch first, the loader resolves to that one -- a single RCCL per process.
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
+            ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 
 

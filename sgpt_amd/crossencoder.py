@@ -47,8 +47,14 @@ def loglikelihood_tokens(requests, model: SGPTModel, max_length: int, instructio
             raise ValueError("continuation longer than the model input left after truncation")
         inps.append(inp)
         spans.append((len(inp) - len(cont_enc), len(inp), list(cont_enc)))
-    res = [0.0] * len(inps)
     order = np.argsort([-len(x) for x in inps], kind="stable")        # longest first, as the reference's Reorderer
+    # under the model's range guard: an f16 activation class that overflows gets its power-of-two shift raised and the
+    # requests are scored again (otherwise inf / NaN log-probabilities would come back silently)
+    return model.guarded(lambda: _score_batches(inps, spans, order, model, max_tokens_per_call))
+
+
+def _score_batches(inps, spans, order, model: SGPTModel, max_tokens_per_call: int) -> List[float]:
+    res = [0.0] * len(inps)
     start = 0
     while start < len(order):
         tok, end = 0, start

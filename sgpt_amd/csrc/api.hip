@@ -12,24 +12,8 @@
 
 #include "../../include/sgpt_hip.h"
 #include "common.h"
+#include "ctx.h"
 
-struct sgpt_ctx {
-    int device = 0;
-    std::string err;
-    // grow-only workspaces
-    void* ws = nullptr; size_t ws_bytes = 0;        // encoder activations
-    void* ws2 = nullptr; size_t ws2_bytes = 0;      // scorer: score chunk + ping-pong top-k
-    // bumped whenever a library-owned buffer that launched kernels point into is re-allocated (workspace growth,
-    // learnt pooling weights): a hipGraph captured earlier holds stale pointers once this moves (sgpt_ctx_generation)
-    uint64_t generation = 0;
-    int* range_flag = nullptr;                      // device int: an f16 activation left the representable range
-    // GEMM profiling (bench.py roofline)
-    bool prof = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    size_t ev_used = 0;
-    std::vector<double> ev_flops;
-    int64_t prof_launches = 0; double prof_ms = 0, prof_flops = 0;
-};
 
 struct LayerW {
     void* w_qkv = nullptr;   // [3d, d]  (q rows, k rows, v rows)
@@ -59,8 +43,20 @@ struct sgpt_model {
     std::vector<float> act_scale;      // [2 * n_layers]: GELU-output scales, then attention-context scales
     unsigned* h_amax = nullptr;        // device float bits [2 * n_layers], same order
     bool calibrating = false;
+    // SGPT_F16 range shifts: operand class c of block l is STORED as value * 2^-shift[l * RS_N + c] (classes: RS_*), the
+    // consuming launches multiply their fp32 accumulators back (exact).  All 0 until a load-time bound or a run-time
+    // magnitude asks for more (sgpt_model_range_adapt).  range_dev: device words [0] = flag (bit 0: an f16 store reached
+    // RANGE_LIMIT, bit 1: an e4m3 code saturated), [1 + l * RS_N + c] = fp32 bits of the largest offending magnitude.
+    std::vector<int> shift;
+    unsigned* range_dev = nullptr;
     std::vector<void*> allocs;
 };
+
+// operand classes of a block: LayerNorm-1 output, q | k | v (and the attention context, a convex combination of v rows),
+// LayerNorm-2 output, GELU output
+enum { RS_LN1 = 0, RS_QKV = 1, RS_LN2 = 2, RS_H = 3, RS_N = 4 };
+constexpr int RS_MAX_SHIFT = 40;
+static inline float pow2f(int k) { return std::ldexp(1.0f, k); }
 
 namespace {
 
@@ -79,6 +75,13 @@ sgpt_status fail(sgpt_ctx* c, sgpt_status st, const std::string& m) {
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// environment switches of the measurement scripts: compiled in only with -DSGPT_EXPERIMENTS (libsgpt_hip_exp.so)
+#ifdef SGPT_EXPERIMENTS
+const char* exp_env(const char* name) { return getenv(name); }
+#else
+const char* exp_env(const char*) { return nullptr; }
+#endif
 
 sgpt_status ensure(sgpt_ctx* c, void** p, size_t* have, size_t need) {
     if (*have >= need) return SGPT_OK;
@@ -108,8 +111,10 @@ struct Prof {  // brackets one GEMM launch with events when profiling is on
     ~Prof() { if (on) (void)hipEventRecord(c->ev_pool[slot].second, s); }
 };
 
-void gemm(sgpt_ctx* c, int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
-    Prof p(c, s, 2.0 * (double)a.m_valid * a.N * a.K);
+void gemm(sgpt_ctx* c, int dtype, int epi, int out_dtype, const GemmArgs& a0, hipStream_t s) {
+    Prof p(c, s, 2.0 * (double)a0.m_valid * a0.N * a0.K);
+    GemmArgs a = a0;
+    a.kgroups = c->kgroups; a.force256 = c->force256;     // per-ctx policies (no process-global state)
     launch_gemm(dtype, epi, out_dtype, a, s);
 }
 
@@ -141,6 +146,8 @@ void sgpt_ctx_destroy(sgpt_ctx* c) {
     (void)hipDeviceSynchronize();
     if (c->ws) (void)hipFree(c->ws);
     if (c->ws2) (void)hipFree(c->ws2);
+    (void)sgpt_comm_destroy(c);
+    if (c->ws3) (void)hipFree(c->ws3);
     if (c->range_flag) (void)hipFree(c->range_flag);
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c;
@@ -359,18 +366,32 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         m->h_amax = (unsigned*)dalloc((size_t)d->n_layers * 8);
         if (m->h_amax && hipMemsetAsync(m->h_amax, 0, (size_t)d->n_layers * 8, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memset");
     }
+    m->shift.assign((size_t)d->n_layers * RS_N, 0);
+    if (st == SGPT_OK) {
+        m->range_dev = (unsigned*)dalloc((size_t)(1 + d->n_layers * RS_N) * 4);
+        if (m->range_dev && hipMemsetAsync(m->range_dev, 0, (size_t)(1 + d->n_layers * RS_N) * 4, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memset");
+    }
     if (st == SGPT_OK && hipDeviceSynchronize() != hipSuccess) st = fail(c, SGPT_ERR_HIP, "sync after weight pack");
     if (f16) {
-        // f16 has 5 exponent bits: refuse a checkpoint whose weights, or whose LayerNorm output bound
-        // max|gamma| * sqrt(d) + max|beta| (|x_hat| <= sqrt(d-1)), can leave the format.  Activations behind the GEMMs are
-        // range-checked on the device at run time (RangeTrack in the store epilogues -> sgpt_range_check).
+        // f16 has 5 exponent bits.  A LayerNorm output is bounded by max|gamma| * sqrt(d) + max|beta| (|x_hat| <= sqrt(d-1)):
+        // when that bound can leave the format the LayerNorm outputs are stored under a power-of-two down-shift that the
+        // consuming GEMMs undo on their fp32 accumulators (exact; shift[] above).  Activations behind the GEMMs are
+        // range-checked on the device at run time (RangeTrack in the store epilogues -> sgpt_model_range_check /
+        // sgpt_model_range_adapt).  Only a weight outside the format is refused.
         unsigned h[4] = {0, 0, 0, 0};
         if (st == SGPT_OK && hipMemcpy(h, stats, 12, hipMemcpyDeviceToHost) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "range audit");
         (void)hipFree(stats);
         float wmax, gmax, bmax;
         memcpy(&wmax, &h[0], 4); memcpy(&gmax, &h[1], 4); memcpy(&bmax, &h[2], 4);
-        if (st == SGPT_OK && (!(wmax < 65504.f) || !(gmax * sqrtf((float)dm) + bmax < 32768.f)))
-            st = fail(c, SGPT_ERR_RANGE, "SGPT_F16: weights or LayerNorm parameters exceed the f16 range; load with SGPT_BF16");
+        const float bound = gmax * sqrtf((float)dm) + bmax;
+        if (st == SGPT_OK && (!(wmax < 65504.f) || !std::isfinite(bound)))
+            st = fail(c, SGPT_ERR_RANGE, "SGPT_F16: a matmul weight exceeds the f16 range (or a LayerNorm parameter is not finite); load with SGPT_BF16");
+        if (st == SGPT_OK && !(bound < 32768.f)) {
+            int k = (int)std::ceil(std::log2(bound / 16384.f));
+            k = k < 1 ? 1 : k;
+            if (k > RS_MAX_SHIFT) st = fail(c, SGPT_ERR_RANGE, "SGPT_F16: LayerNorm parameters beyond any usable range shift; load with SGPT_BF16");
+            for (int i = 0; i < d->n_layers && st == SGPT_OK; ++i) m->shift[(size_t)i * RS_N + RS_LN1] = m->shift[(size_t)i * RS_N + RS_LN2] = k;
+        }
     }
     if (st != SGPT_OK) { sgpt_model_free(m); return st; }
     *out = m;
@@ -404,7 +425,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         if (!m->pool_w) return fail(c, SGPT_ERR_MISSING, "sgpt_encode: learntmean needs sgpt_model_set_pool_weights first");
         // with pad_left on the device the longest padded position is not known here: the kernel clamps the table index,
         // and the Python host checks max(pad_left + len) before the call (model.py::_check_learnt)
-        if (!pad_left && max_alloc - 15 > m->pool_w_n)
+        // (allocations are 8-row aligned: the longest sequence has at least max_alloc - 7 tokens)
+        if (!pad_left && max_alloc - 7 > m->pool_w_n)
             return fail(c, SGPT_ERR_INVALID, "sgpt_encode: fewer learnt position weights than the longest sequence");
     }
     if (max_alloc > 2048) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: sequence longer than 2048 tokens");
@@ -477,15 +499,22 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             launch_fp8_dequant_rows(l.w_proj, l.s_proj, dm, ffn, m->dq[3], SGPT_BF16, s);
             l.w_qkv = m->dq[0]; l.w_o = m->dq[1]; l.w_fc = m->dq[2]; l.w_proj = m->dq[3];
         }
+        // SGPT_F16 range shifts of this block (all 0 unless the checkpoint needed them): class stored as value * 2^-k
+        const bool f16m = dt == SGPT_F16;
+        const int* sh = &m->shift[(size_t)li * RS_N];
+        const int k_ln1 = f16m ? sh[RS_LN1] : 0, k_qkv = f16m ? sh[RS_QKV] : 0, k_h = f16m ? sh[RS_H] : 0;
+        const int k_ln2 = f16m ? (gptj ? sh[RS_LN1] : sh[RS_LN2]) : 0;     // GPT-J: ln_1's output feeds the MLP too
+        unsigned* slots = m->range_dev + 1 + (size_t)li * RS_N;
         GemmArgs g{};
         g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
-        g.range_flag = dt == SGPT_F16 ? c->range_flag : nullptr;
+        g.range_flag = f16m ? (int*)m->range_dev : nullptr;
         AttnArgs at{};
         at.dtype = dt;
         at.seq_off = seq_off; at.B = B; at.H = H; at.dh = dh; at.window = l.is_local ? m->d.window : 0;
-        at.scale = m->d.attn_scale; at.max_alloc_len = max_alloc; at.ctx = ctx; at.ldo = dm; at.alibi = m->alibi;
+        at.scale = m->d.attn_scale * pow2f(2 * k_qkv);      // q and k are both stored down-shifted
+        at.max_alloc_len = max_alloc; at.ctx = ctx; at.ldo = dm; at.alibi = m->alibi;
         GemmArgs q{};      // fp8 projections
-        q.M = T; q.m_valid = T; q.range_flag = c->range_flag;
+        q.M = T; q.m_valid = T; q.range_flag = (int*)m->range_dev;
         if (mlp8) {
             // ---- attention projections on the fp8 MFMA: a8 = e4m3(LN1(x) / sa[row]) feeds Q, K (row-major bf16) and V^T ----
             launch_layernorm_q8(x, l.ln1_g, l.ln1_b, base + o_a8, (float*)(base + o_sa), nullptr, dt, T, dm, m->d.ln_eps, s);
@@ -497,18 +526,19 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             { Prof pr(c, s, 2.0 * T * (double)dm * dm); launch_gemm_fp8(EPI_VT, dt, q, s); }
             if (gptj) launch_rope(qkv, dt, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
             at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
-            at.out_fp8 = 1; at.out_scale = m->act_scale[m->d.n_layers + li]; at.range_flag = c->range_flag;
+            at.out_fp8 = 1; at.out_scale = m->act_scale[m->d.n_layers + li]; at.range_flag = (int*)m->range_dev;
             launch_attn_bf16(at, s);                         // context as e4m3 codes of ctx / s_c, [T][dm] bytes
             q.A = ctx; q.lda = dm; q.a_scale = nullptr; q.a_scalar = m->act_scale[m->d.n_layers + li];
             q.W = w_o8; q.w_scale = l.s_o; q.N = dm; q.K = dm; q.ldw = dm; q.bias = l.b_o; q.resid = x; q.out = x; q.ldo = dm;
             { Prof pr(c, s, 2.0 * T * (double)dm * dm); launch_gemm_fp8(EPI_BIAS_RESID, 0, q, s); }
             q.resid = nullptr;
         } else {
-        launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s);
+        launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln1));
         if (bf) {
             // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]
             g.W = l.w_qkv; g.out = qkv; g.ldo = 2 * dm; g.bias = l.b_qkv;                           // bias: BLOOM only
-            if (gemm_qkv_one_launch(T, 2 * dm)) {        // query-sized batch: one launch (a launch costs ~8 us there)
+            g.in_mul = pow2f(k_ln1); g.out_mul = g.out_mul2 = pow2f(-k_qkv); g.range_amax = f16m ? slots + RS_QKV : nullptr;
+            if (gemm_qkv_one_launch(T, 2 * dm, c->force256 != 0)) {        // query-sized batch: one launch (a launch costs ~8 us there)
                 g.N = 3 * dm; g.n_split = 2 * dm; g.out2 = vt; g.ldo2 = T;
                 gemm(c, dt, EPI_QKV, dt, g, s);
                 g.out2 = nullptr; g.n_split = 0;
@@ -531,8 +561,9 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             at.q = qkv; at.k = (float*)qkv + dm; at.v = (float*)qkv + 2 * dm; at.ldq = 3 * dm;
             launch_attn_f32(at, s);
         }
-        // x += ctx . Wo^T (+ bo)
+        // x += ctx . Wo^T (+ bo)      (the context carries v's shift)
         g.A = ctx; g.W = l.w_o; g.N = dm; g.K = dm; g.ldw = dm; g.out = x; g.ldo = dm; g.bias = l.b_o; g.resid = x;
+        g.in_mul = pow2f(k_qkv); g.out_mul = g.out_mul2 = 1.0f; g.range_amax = nullptr;
         gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
         }
         // GPT-Neo: x += MLP(LN2(x));  GPT-J (parallel block, HF:gptj:400-411): x += MLP(LN1(x_old)), `a` still holds it
@@ -548,12 +579,14 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             q.resid = x; q.out = x; q.ldo = dm;
             { Prof pr(c, s, 2.0 * T * (double)ffn * dm); launch_gemm_fp8(EPI_BIAS_RESID, 0, q, s); }
         } else {
-            if (!gptj) launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s);
+            if (!gptj) launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln2));
             g.A = a; g.lda = dm; g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
+            g.in_mul = pow2f(k_ln2); g.out_mul = pow2f(-k_h); g.range_amax = f16m ? slots + RS_H : nullptr;
             gemm(c, dt, EPI_BIAS_GELU, dt, g, s);
             if (m->calibrating) launch_absmax16(h, (long)T * ffn, dt, m->h_amax + li, s);   // FP8M calibration: range of this block's GELU output
             g.A = h; g.lda = ffn; g.W = l.w_proj; g.N = dm; g.K = ffn; g.ldw = ffn; g.out = x; g.ldo = dm;
             g.bias = l.b_proj; g.resid = x;
+            g.in_mul = pow2f(k_h); g.out_mul = 1.0f; g.range_amax = nullptr;
             gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
         }
     }
@@ -792,11 +825,11 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // fp32 go through the 128^2 kernel.
     const bool fast = dtype != SGPT_F32 && d % 64 == 0 && d >= 128;
     // nq <= 64: the 64-query-row scorer tile (score64_kernel) instead of 256 padded rows -- the pass is HBM-bound there
-    static const bool no_small_q = getenv("SGPT_SCORE_NO64") != nullptr;      // A/B switch
+    static const bool no_small_q = exp_env("SGPT_SCORE_NO64") != nullptr;      // A/B switch (experiment build only)
     const int nq_pad = (fast && nq <= 64 && !no_small_q) ? 64 : (nq + 255) / 256 * 256;
     // Threshold-filtered chunks (after the first): see EPI_SCORE_FILTER.  Candidate capacity per query and chunk;
     // the doubling schedule below keeps the expected count at ~k.
-    static const bool classic_only = getenv("SGPT_SCORE_CLASSIC") != nullptr;
+    static const bool classic_only = exp_env("SGPT_SCORE_CLASSIC") != nullptr;
     // Capacity and growth: a filtered chunk of len = growth * seen documents expects ~k * growth survivors per query
     // (the threshold is the k-th best of `seen` documents); the merge sorts the candidates in 2048 LDS slots.
     const int cap = k <= 64 ? 256 : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
@@ -905,7 +938,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         if (st != SGPT_OK) return st;
     } else {
         HIPC(c, hipMemsetAsync(cand_cnt, 0, (size_t)(nq_pad + n_flags) * 4, s));
-        static const bool no_fallback = getenv("SGPT_SCORE_NOFALLBACK") != nullptr;   // timing experiments ONLY: unsafe
+        static const bool no_fallback = exp_env("SGPT_SCORE_NOFALLBACK") != nullptr;   // timing experiments ONLY: unsafe
         // first chunk: materialise + select -> the initial thresholds.  One whole wave of tiles is enough (the
         // doubling schedule takes over from there): 16 384 documents for nq = 1000 instead of 32 768
         const long first = unit < chunk ? unit : chunk;
@@ -1015,9 +1048,90 @@ sgpt_status sgpt_linear_fp8(sgpt_ctx* c, int32_t epi, int32_t out_dtype, const u
     return SGPT_OK;
 }
 
-int32_t sgpt_set_gemm_variant(int32_t v) { return set_gemm_variant(v); }
-int32_t sgpt_set_gemm_skew(int32_t cycles) { return set_gemm_skew(cycles); }
-int32_t sgpt_set_gemm_kgroups(int32_t groups) { return set_gemm_kgroups(groups); }
+int32_t sgpt_ctx_set_low_latency(sgpt_ctx* c, int32_t on) {
+    if (!c) return 0;
+    const int old = c->kgroups > 1 ? 1 : 0;
+    c->kgroups = on ? 2 : 1;
+    return old;
+}
+int32_t sgpt_ctx_set_tile_policy(sgpt_ctx* c, int32_t policy) {
+    if (!c) return 0;
+    const int old = c->force256;
+    c->force256 = policy == 1 ? 1 : 0;
+    return old;
+}
+#ifdef SGPT_EXPERIMENTS
+int32_t sgpt_exp_set_gemm_skew(int32_t cycles) { return set_gemm_skew(cycles); }
+int32_t sgpt_exp_set_gemm_w(int32_t on) { return set_gemm_use_w(on); }
+#endif
+
+// ---- SGPT_F16 range guard, per model --------------------------------------------------------------------------------
+sgpt_status sgpt_model_range_check(sgpt_model* m, int32_t* flagged, int32_t reset, void* stream) {
+    if (!m || !flagged) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned h = 0;
+    HIPC(c, hipMemcpyAsync(&h, m->range_dev, 4, hipMemcpyDeviceToHost, s));
+    HIPC(c, hipStreamSynchronize(s));
+    if (reset && h) HIPC(c, hipMemsetAsync(m->range_dev, 0, (size_t)(1 + m->d.n_layers * RS_N) * 4, s));
+    *flagged = (int32_t)h;
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_model_range_adapt(sgpt_model* m, int32_t* n_raised, void* stream) {
+    if (!m || !n_raised) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    *n_raised = 0;
+    if (m->d.compute_dtype != SGPT_F16) return fail(c, SGPT_ERR_INVALID, "sgpt_model_range_adapt applies to SGPT_F16 models");
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int n = m->d.n_layers * RS_N;
+    std::vector<unsigned> h((size_t)n + 1);
+    HIPC(c, hipMemcpyAsync(h.data(), m->range_dev, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPC(c, hipStreamSynchronize(s));
+    int raised = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!h[i + 1]) continue;
+        float amax;
+        memcpy(&amax, &h[i + 1], 4);
+        // the stored magnitude was amax >= RANGE_LIMIT: bring it to <= 16384 (a factor of two of head-room for later
+        // batches); infinite (the fp32 value itself overflowed f16 by an unknown factor): 8 binary orders per attempt
+        int need = std::isfinite(amax) ? (int)std::ceil(std::log2(amax / 16384.f)) : 8;
+        need = need < 1 ? 1 : need;
+        if (m->shift[i] + need > RS_MAX_SHIFT)
+            return fail(c, SGPT_ERR_RANGE, "SGPT_F16: an activation class needs a range shift beyond 2^40; load with SGPT_BF16");
+        m->shift[i] += need;
+        ++raised;
+    }
+    if (raised) {
+        HIPC(c, hipMemsetAsync(m->range_dev + 1, 0, (size_t)n * 4, s));
+        const unsigned keep = h[0] & ~1u;                 // bit 0 handled; fp8 saturation bits stay
+        HIPC(c, hipMemcpyAsync(m->range_dev, &keep, 4, hipMemcpyHostToDevice, s));
+        HIPC(c, hipStreamSynchronize(s));
+        c->generation++;                                  // captured graphs carry the old factors as kernel arguments
+    }
+    *n_raised = raised;
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_model_get_range_shifts(sgpt_model* m, int32_t* shifts, int32_t n) {
+    if (!m || !shifts || n != m->d.n_layers * RS_N) return m ? fail(m->ctx, SGPT_ERR_INVALID, "sgpt_model_get_range_shifts: n must be 4 * n_layers") : SGPT_ERR_INVALID;
+    for (int i = 0; i < n; ++i) shifts[i] = m->shift[i];
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_model_set_range_shifts(sgpt_model* m, const int32_t* shifts, int32_t n) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (m->d.compute_dtype != SGPT_F16 || !shifts || n != m->d.n_layers * RS_N)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_range_shifts: SGPT_F16 models, n = 4 * n_layers");
+    for (int i = 0; i < n; ++i)
+        if (shifts[i] < 0 || shifts[i] > RS_MAX_SHIFT) return fail(c, SGPT_ERR_INVALID, "range shifts must lie in [0, 40]");
+    for (int i = 0; i < n; ++i) m->shift[i] = shifts[i];
+    c->generation++;
+    return SGPT_OK;
+}
 
 sgpt_status sgpt_linear(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out_dtype, const void* A, const void* W,
                         const float* bias, const float* resid, void* out, int32_t M, int32_t N, int32_t K, void* stream) {
@@ -1092,7 +1206,7 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
     hipEvent_t e0, e1;
     HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
     long long* dbg = nullptr;
-    if (getenv("SGPT_GEMM_DBG")) { HIPC(c, hipMalloc((void**)&dbg, 128 * 8)); HIPC(c, hipMemset(dbg, 0, 128 * 8)); g.dbg = dbg; }
+    if (exp_env("SGPT_GEMM_DBG")) { HIPC(c, hipMalloc((void**)&dbg, 128 * 8)); HIPC(c, hipMemset(dbg, 0, 128 * 8)); g.dbg = dbg; }
     for (int i = 0; i < 3; ++i) launch_gemm(dtype, epi, out_dtype, g, 0);
     HIPC(c, hipEventRecord(e0, 0));
     for (int i = 0; i < iters; ++i) launch_gemm(dtype, epi, out_dtype, g, 0);

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
             amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
             *reinterpret_cast<uint32_t*>(os + fr * ORS8 + dt * 16 + 4 * g) = pack_fp8x4(v0, v1, v2, v3);
         }
-        if (p.range_flag != nullptr && !(amax <= 448.f)) atomicOr(p.range_flag, 2);
+        if (p.range_flag != nullptr && !(amax <= 448.f)) atomicOr(p.range_flag, 4);   // bit 2: attention context (bit 1: GELU output)
         uint8_t* obase = static_cast<uint8_t*>(p.ctx) + (long)(s0 + q0) * p.ldo + (long)head * DH;
 #pragma unroll
         for (int h = 0; h < 16 / RPI8; ++h) {

@@ -94,9 +94,15 @@ template <typename H> struct RangeTrack {
     __device__ __forceinline__ void note(float a, float b) {
         if constexpr (Half<H>::is_f16) amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));   // v_max3_f32 with |.| modifiers
     }
-    __device__ __forceinline__ void finish(int* flag) const {
+    // amax_slot (optional): the offending magnitude (fp32 bits of a non-negative float: unsigned order == float order) is
+    // folded into the slot of this launch's (block, operand class) so that the host can raise that class's power-of-two
+    // down-shift by the right amount and re-run (sgpt_model_range_adapt) instead of giving up on the checkpoint
+    __device__ __forceinline__ void finish(int* flag, unsigned* amax_slot = nullptr) const {
         if constexpr (Half<H>::is_f16) {
-            if (flag != nullptr && !(amax < RANGE_LIMIT)) atomicOr(flag, 1);            // also catches NaN
+            if (flag != nullptr && !(amax < RANGE_LIMIT)) {                             // also catches +-inf
+                atomicOr(flag, 1);
+                if (amax_slot != nullptr) atomicMax(amax_slot, __float_as_uint(amax));
+            }
         }
     }
 };
@@ -164,6 +170,16 @@ __device__ __forceinline__ float gelu_new_fast(float u) {
     return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 
+// the same with the f16 range shift folded in: returns gelu_new(u) * m for m = 1 / inv (a power of two).  (1 + e) * inv is
+// one fma (inv = 1: e + 1 exactly as above, so the default path keeps its bits), and the reciprocal of a power-of-two
+// multiple is the power-of-two multiple of the reciprocal.
+__device__ __forceinline__ float gelu_new_fast_scaled(float u, float inv) {
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const float k1 = k0 * 0.044715f;
+    const float z = u * __builtin_fmaf(u * u, k1, k0);
+    return u * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(z), inv, inv));
+}
+
 // Filtered scorer epilogues: is there still room in query row's candidate list?  Called only AFTER a lane has found a
 // survivor (rare).  An ATOMIC relaxed load on purpose: a plain load is hoisted by the compiler in front of the
 // `max > threshold` test, which put a global load (and its wait) on every row of every tile -- measured 0.27 -> 0.37 ms on
@@ -209,6 +225,14 @@ struct GemmArgs {
     long idx_base;      // global index of W row 0
     long long* dbg;     // optional s_memtime stamps of workgroup 0 / wave 0 (micro-benchmark diagnostics)
     int* range_flag;    // f16 outputs: device flag raised when a stored magnitude reaches RANGE_LIMIT (or null)
+    unsigned* range_amax;   // with range_flag: slot that collects the offending magnitude (fp32 bits, atomicMax) or null
+    // Power-of-two range shifts of the f16 path (exact in fp32; 0 is read as 1 by the launchers, so a zero-initialised
+    // GemmArgs means "no scaling"):  out = epilogue(acc * in_mul) * out_mul
+    //   in_mul  = product of the operands' up-shifts (an operand stored as v * 2^-k contributes 2^k),
+    //   out_mul = 2^-k of the tensor this launch writes (EPI_QKV: out_mul for q | k, out_mul2 for V^T).
+    float in_mul, out_mul, out_mul2;
+    int kgroups;        // per-ctx low-latency mode: 2 = k-groups for under-filled small-tile launches (0 / 1 = off)
+    int force256;       // per-ctx tile policy: 1 = keep 256x256 tiles even where the small-tile rule would apply (kernel tests)
     // EPI_QKV
     void* out2;         // V^T [N - n_split][ldo2]
     long ldo2;
@@ -221,10 +245,11 @@ struct GemmArgs {
 };
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
+bool gemm_qkv_one_launch(int M, int n_split, bool force256);   // 16-bit operands: does EPI_QKV apply (query-sized batch)?
+#ifdef SGPT_EXPERIMENTS        // A/B knobs of the measurement scripts (libsgpt_hip_exp.so only)
 int set_gemm_skew(int cycles);  // start-up stagger of the persistent 256^2 kernel (shader cycles per phase); returns the previous value
-int set_gemm_kgroups(int g);    // 1: off; 2: k-groups for under-filled small-tile launches (gemm.hip); returns the previous value
-bool gemm_qkv_one_launch(int M, int n_split);   // 16-bit operands: does EPI_QKV apply (query-sized batch)?
-int set_gemm_variant(int v);   // 0: 16x16x32-MFMA 256^2 kernel, 1: 32x32x16-MFMA one; returns the previous value
+int set_gemm_use_w(int on);     // 1: the 32x32x16-MFMA re-tiling of the 256^2 kernel (gemm256w.hip); returns the previous value
+#endif
 // gemm256q.hip: fp8 (e4m3fn) x fp8 on v_mfma_f32_16x16x128_f8f6f4; epi = EPI_BIAS_GELU (fp8 out) | EPI_BIAS_RESID (fp32) |
 // EPI_STORE / EPI_VT (16-bit out) | EPI_NONE
 bool gemm_fp8_shape_ok(int M, int N, int K);
@@ -257,7 +282,7 @@ void launch_attn_f32(const AttnArgs& a, hipStream_t s);
 void launch_embed(const int* ids, const int* pos, const float* wte, const float* wpe, float* x, int T, int d, int vocab,
                   int max_pos, hipStream_t s);
 void launch_layernorm(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
-                      float eps, hipStream_t s);
+                      float eps, hipStream_t s, float out_mul = 1.0f);   // out_mul: f16 range shift (power of two)
 // LayerNorm -> e4m3fn codes q[T,d] + one power-of-two scale per row (+ optionally the same rows in a 16-bit format)
 void launch_layernorm_q8(const float* x, const float* g, const float* b, void* q, float* scale, void* out16, int out16_dtype,
                          int T, int d, float eps, hipStream_t s);

@@ -82,10 +82,12 @@ struct RowLN {
     }
 };
 
+// out_mul: power-of-two range shift of an f16 output (the consuming GEMMs multiply their accumulators by 1 / out_mul);
+// 1 for every other format and for models without shifts (v * 1 == v: the default path keeps its bits)
 template <typename OutT, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, OutT* __restrict__ out, int T,
-                                                        int d, float eps) {
+                                                        int d, float eps, float out_mul) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
     const int lane = threadIdx.x & 63;
@@ -100,7 +102,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (long)row * d + c) = r.v[i];
             } else {
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (long)row * d + c) =
-                    make_uint2(Half<OutT>::pack2(r.v[i].x, r.v[i].y), Half<OutT>::pack2(r.v[i].z, r.v[i].w));
+                    make_uint2(Half<OutT>::pack2(r.v[i].x * out_mul, r.v[i].y * out_mul),
+                               Half<OutT>::pack2(r.v[i].z * out_mul, r.v[i].w * out_mul));
             }
         }
     }
@@ -501,17 +504,17 @@ void launch_embed(const int* ids, const int* pos, const float* wte, const float*
 }
 
 void launch_layernorm(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
-                      float eps, hipStream_t s) {
+                      float eps, hipStream_t s, float out_mul) {
 #define LN_CASE(NV)                                                                                              \
     if (out_dtype == DT_BF16)                                                                                    \
         hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,          \
-                           (bf16_t*)out, T, d, eps);                                                             \
+                           (bf16_t*)out, T, d, eps, 1.0f);                                                       \
     else if (out_dtype == DT_F16)                                                                                \
         hipLaunchKernelGGL((layernorm_kernel<f16_t, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,           \
-                           (f16_t*)out, T, d, eps);                                                              \
+                           (f16_t*)out, T, d, eps, out_mul);                                                     \
     else                                                                                                         \
         hipLaunchKernelGGL((layernorm_kernel<float, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,           \
-                           (float*)out, T, d, eps);
+                           (float*)out, T, d, eps, 1.0f);
     const int nv = (d + 255) / 256;
     if (nv <= 1) { LN_CASE(1) } else if (nv <= 2) { LN_CASE(2) } else if (nv <= 3) { LN_CASE(3) }
     else if (nv <= 4) { LN_CASE(4) } else if (nv <= 8) { LN_CASE(8) } else if (nv <= 10) { LN_CASE(10) }

@@ -39,9 +39,16 @@ constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 #define SGPT_SMALL_PF 2
 #endif
 constexpr int CH = 8;  // 16-byte chunks per row per k-step
+
+// A/B switches of the measurement scripts exist only in the experiment build (`SGPT_EXPERIMENTS=1 python -m sgpt_amd.build`
+// -> libsgpt_hip_exp.so, loaded through SGPT_HIP_LIB): the shipped library reads no environment variable and holds no
+// process-global mutable state -- the two run-time policies it has (tile policy, k-groups) are per-ctx and arrive in GemmArgs.
+#ifdef SGPT_EXPERIMENTS
+inline const char* exp_env(const char* name) { return getenv(name); }
 int g_skew = getenv("SGPT_SKEW") ? atoi(getenv("SGPT_SKEW")) : 0;     // start-up stagger of gemm256d_kernel, shader cycles per phase
-#ifndef SGPT_GEMM_W_DEFAULT
-#define SGPT_GEMM_W_DEFAULT false
+int g_use_w = getenv("SGPT_GEMM_W") ? (atoi(getenv("SGPT_GEMM_W")) & 1) : 0;   // 1: the 32x32x16-MFMA re-tiling (gemm256w.hip)
+#else
+inline const char* exp_env(const char*) { return nullptr; }
 #endif
 
 template <typename T> struct ElemTraits;
@@ -314,23 +321,35 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
                 if (n >= N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const bool full = n + 3 < N;
+                // f16 range shifts, the arithmetic of gemm256_epilogue.inc bit for bit (all factors 1 unless a model carries
+                // shifts): store (acc * in_mul + bias) * out_mul as one fma; gelu(fma(acc, in_mul, bias)) * out_mul
+                float om = p.out_mul;
+                if constexpr (EPI == EPI_QKV) om = n >= p.n_split ? p.out_mul2 : p.out_mul;
+                const float cs = (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) ? p.in_mul : p.in_mul * om;
+                const float bsc = EPI == EPI_BIAS_GELU ? 1.0f : om;
                 if constexpr (EPI == EPI_BIAS_RESID) {
-                    // acc + (bias + resid): the association of gemm256_kernel's epilogue, bit for bit
+                    // acc (* in_mul) + (bias + resid): the association of gemm256_kernel's epilogue, bit for bit
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                     const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
-                    v[0] += bb.x + rr.x; v[1] += bb.y + rr.y; v[2] += bb.z + rr.z; v[3] += bb.w + rr.w;
+                    v[0] = __builtin_fmaf(v[0], cs, bb.x + rr.x); v[1] = __builtin_fmaf(v[1], cs, bb.y + rr.y);
+                    v[2] = __builtin_fmaf(v[2], cs, bb.z + rr.z); v[3] = __builtin_fmaf(v[3], cs, bb.w + rr.w);
                 } else if (EPI == EPI_BIAS_GELU || ((EPI == EPI_STORE || EPI == EPI_QKV) && p.bias != nullptr)) {
                     if (full) {
                         const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                        v[0] = __builtin_fmaf(v[0], cs, bb.x * bsc); v[1] = __builtin_fmaf(v[1], cs, bb.y * bsc);
+                        v[2] = __builtin_fmaf(v[2], cs, bb.z * bsc); v[3] = __builtin_fmaf(v[3], cs, bb.w * bsc);
                     } else {       // ragged last column group (LM head: vocab % 4 != 0): no read past the bias array
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (n + r < N) ? p.bias[n + r] : 0.f;
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], cs, (n + r < N) ? p.bias[n + r] * bsc : 0.f);
                     }
+                } else if constexpr (sizeof(OutT) == 2) {       // 16-bit store without bias (GPT-Neo / GPT-J q | k | v)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], cs, 0.f);
                 }
                 if constexpr (EPI == EPI_BIAS_GELU) {
+                    const float ginv = 1.0f / om;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = sizeof(T) == 2 ? gelu_new_fast(v[r]) : gelu_new(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = sizeof(T) == 2 ? gelu_new_fast_scaled(v[r], ginv) : gelu_new(v[r]);
                 }
                 if constexpr (EPI == EPI_SCORE) {
 #pragma unroll
@@ -366,13 +385,16 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
             for (int i = 0; i < NI; ++i) {
                 const int m = m0 + wm * (16 * NI) + i * 16 + 4 * g;
                 if (m >= M) continue;  // M (token axis) is padded to a multiple of 128 by the caller
-                const float bn = p.bias ? p.bias[n] : 0.f;   // BLOOM: V projection has a bias
-                range.note(acc[i][j][0] + bn, acc[i][j][1] + bn); range.note(acc[i][j][2] + bn, acc[i][j][3] + bn);
-                store4<OutT>(out + (long)n * p.ldo + m, acc[i][j][0] + bn, acc[i][j][1] + bn, acc[i][j][2] + bn, acc[i][j][3] + bn);
+                const float csv = p.in_mul * p.out_mul;                   // f16 range shifts (1 by default)
+                const float bn = (p.bias ? p.bias[n] : 0.f) * p.out_mul;   // BLOOM: V projection has a bias
+                const float v0 = __builtin_fmaf(acc[i][j][0], csv, bn), v1 = __builtin_fmaf(acc[i][j][1], csv, bn);
+                const float v2 = __builtin_fmaf(acc[i][j][2], csv, bn), v3 = __builtin_fmaf(acc[i][j][3], csv, bn);
+                range.note(v0, v1); range.note(v2, v3);
+                store4<OutT>(out + (long)n * p.ldo + m, v0, v1, v2, v3);
             }
         }
     }
-    range.finish(p.range_flag);
+    range.finish(p.range_flag, p.range_amax);
 }
 
 
@@ -463,17 +485,23 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     int sd = 0, ss = 0;      // ring slots of the k-step about to be computed
     int dbg_tile = 0;
     typename OutRange<OutT>::type range;
+#ifdef SGPT_EXPERIMENTS
 #define STAMP(k)                                                                                   \
     if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 8) p.dbg[dbg_tile * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define STAMP(k) (void)0
+#endif
 
     // Start-up stagger (p.skew shader cycles per phase, 4 phases per XCD): every workgroup walks equally long tiles, so
     // without it all 256 CUs reach their store / read-modify-write epilogues at the same moment and the chip alternates
     // between an HBM-bound burst and an MFMA-bound phase.
+#ifdef SGPT_EXPERIMENTS
     if (p.skew > 0) {
         const int phase = (blockIdx.x >> 3) & 3;
         const long until = (long)__builtin_amdgcn_s_memtime() + (long)phase * p.skew;
         while (phase && (long)__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
     }
+#endif
     {   // prologue: deep(0), shallow(0), deep(1) -- in the order the waits assume
         const bf16_t* dsrc = DEEP_A ? asrc : wsrc;
         const bf16_t* ssrc = DEEP_A ? wsrc : asrc;
@@ -511,8 +539,10 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         const bf16_t* d_cur = DEEP_A ? asrc : wsrc, *d_nxt = DEEP_A ? nasrc : nwsrc;
         const bf16_t* s_cur = DEEP_A ? wsrc : asrc, *s_nxt = DEEP_A ? nwsrc : nasrc;
         for (int kt = 0; kt < nk; ++kt) {
+#ifdef SGPT_EXPERIMENTS
             if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 4 && kt < 12)
                 p.dbg[64 + dbg_tile * 16 + kt] = (long long)__builtin_amdgcn_s_memtime();
+#endif
             const bool s_in = kt + 1 < nk, d_in = kt + 2 < nk;
             const bf16_t* sp = s_in ? s_cur : s_nxt;  const int skt = s_in ? kt + 1 : 0;
             const bf16_t* dp = d_in ? d_cur : d_nxt;  const int dkt = d_in ? kt + 2 : kt + 2 - nk;
@@ -544,20 +574,6 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
                     for (int j = 0; j < 4; ++j) wf[0][j] = ld_w(nlw, 0, j);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#ifdef SGPT_PROBE_OVERLAP
-                // experiment (not in the product build): a store epilogue's worth of HBM writes (128 KiB per tile) issued
-                // from inside the k-loop of the no-store variant -- does the k-loop keep its rate with stores riding along?
-                if constexpr (EPI == EPI_NONE) {
-                    if (q == 3 || (q == 6 && kt % 3 == 0)) {
-                        char* dst = reinterpret_cast<char*>(p.out) + ((long)(m0 / 256) * (N / 256) + n0 / 256) * 131072;
-                        const int cnt = kt + (q == 6 ? nk + kt / 3 : 0);
-                        const long off = ((long)cnt * 8 + wave) * 1024 + lane * 16;
-                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 pv = {wf[0][0].x, wf[0][0].y, wf[0][0].z, wf[0][0].w};
-                        if (off < 131072) __builtin_nontemporal_store(pv, reinterpret_cast<u32x4*>(dst + off));
-                    }
-                }
-#endif
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int i = 2 * pr + h;
@@ -593,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         ntile = n2tile; nm0 = n2m0; nn0 = n2n0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead DMA before the LDS is released
-    range.finish(p.range_flag);
+    range.finish(p.range_flag, p.range_amax);
 #undef STAMP
 }
 
@@ -608,13 +624,19 @@ void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
         return n / 8 * 8;
     }();
     GemmArgs b = a;
+#ifdef SGPT_EXPERIMENTS
     static const int env_gm = getenv("SGPT_GM") ? atoi(getenv("SGPT_GM")) : 0, env_gn = getenv("SGPT_GN") ? atoi(getenv("SGPT_GN")) : 0;
     if (env_gm > 0) b.gm = env_gm;
     if (env_gn > 0) b.gn = env_gn;
+#endif
     const int gm = b.gm > 0 ? b.gm : 4;
     const int tiles_pad = ((AT + 7) / 8 + gm - 1) / gm * gm * 8 * BT;
     const int grid = tiles_pad < ncu ? tiles_pad : ncu;
+#ifdef SGPT_EXPERIMENTS
     b.skew = tiles_pad >= 4 * grid ? g_skew : 0;       // fewer than ~4 tiles per workgroup: the delay is not amortised
+#else
+    b.skew = 0;
+#endif
     if (deep_a) hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, true>), dim3(grid), dim3(512), 0, s, b);
     else hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, false>), dim3(grid), dim3(512), 0, s, b);
 }
@@ -781,13 +803,6 @@ void launch_score64(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((score64_kernel<T, EPI>), dim3(NT < ncu ? NT : ncu), dim3(512), 0, s, a);
 }
 
-// low-latency k-groups for under-filled small-tile launches: env SGPT_KGROUPS at first use, or sgpt_set_gemm_kgroups()
-int g_kgroups = -1;
-int gemm_kgroups() {
-    if (g_kgroups < 0) g_kgroups = getenv("SGPT_KGROUPS") ? atoi(getenv("SGPT_KGROUPS")) : 1;
-    return g_kgroups;
-}
-
 template <typename T, int EPI, typename OutT, bool SWAP>
 void launch(const GemmArgs& a, hipStream_t s) {
     // 64x64 tiles when 128x128 ones would leave most of the 256 CUs idle (short query batches, USEB's 21-32 sentence
@@ -795,7 +810,7 @@ void launch(const GemmArgs& a, hipStream_t s) {
     // (SGPT_T128_MIN sweep): 1536 token rows prefer 64^2 tiles up to fc1's 288 tiles of 128^2 (1.26 -> 1.15 ms), 6912 rows
     // prefer 128^2 tiles from the N = 768 launches' 324 on.
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    static const long t128_min = getenv("SGPT_T128_MIN") ? atol(getenv("SGPT_T128_MIN")) : 300;   // measured switch point (A/B knob)
+    static const long t128_min = exp_env("SGPT_T128_MIN") ? atol(exp_env("SGPT_T128_MIN")) : 300;   // measured switch point
     const bool small = t128 < t128_min;
     const int B = small ? 64 : 128;
     const int MT = (a.M + B - 1) / B, NT = (a.N + B - 1) / B;
@@ -805,8 +820,8 @@ void launch(const GemmArgs& a, hipStream_t s) {
     // two k-groups (split-K inside the workgroup, see gemm_kernel) when the 64x64 tiles leave workgroup slots empty (two
     // 512-thread workgroups fit a CU); each group keeps >= 3 k-steps.  Measured on a 16-query encode (512 token rows):
     // 1.05 -> 0.88 ms; four groups (one 1024-thread workgroup per CU) gave 0.90.  OFF by default: it trades the
-    // bit-identical-across-batch-sizes property for latency (sgpt_set_gemm_kgroups / env SGPT_KGROUPS=2).
-    const int kgmax = gemm_kgroups();
+    // bit-identical-across-batch-sizes property for latency (per ctx: sgpt_ctx_set_low_latency -> GemmArgs.kgroups).
+    const int kgmax = a.kgroups;
     constexpr bool splittable = EPI != EPI_SCORE && EPI != EPI_SCORE_FILTER;
     const int nkt = (a.K + CH * ElemTraits<T>::EPC - 1) / (CH * ElemTraits<T>::EPC);
     const long tiles = (long)MT * NT;
@@ -819,15 +834,6 @@ void launch(const GemmArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 4, 1>), dim3(grid), dim3(256), 0, s, a);
 }
 
-// which 256x256 kernel runs: env SGPT_GEMM_W at first use, or sgpt_set_gemm_variant() (in-process A/B of the two
-// MFMA shapes; the results agree to fp32 rounding).  bit 0: 32x32x16-MFMA kernel; bit 1: keep 256x256 tiles for
-// problems the small-tile rule would hand to the register-staged kernel (kernel tests of single-tile shapes)
-int g_variant = -1;
-int gemm_variant() {
-    if (g_variant < 0) g_variant = getenv("SGPT_GEMM_W") ? atoi(getenv("SGPT_GEMM_W")) : (SGPT_GEMM_W_DEFAULT ? 1 : 0);
-    return g_variant;
-}
-
 // 16-bit operand format H (bf16_t | f16_t): the 256x256 LDS-DMA kernel where the shape allows, else the register-staged one
 template <typename H>
 void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
@@ -835,10 +841,12 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     // Small problems (short query batches, USEB's 21-32 sentence calls): fewer than half a wave of 256x256 tiles
     // leaves most of the 256 CUs idle; the register-staged kernel's 128x128 / 64x64 tiles fill the chip instead.
     // Bit-identical results (see gemm_kernel), so the embeddings stay batch-invariant.  SGPT_NO_SMALL_TILE=1: A/B.
-    static const bool small_tiles = getenv("SGPT_NO_SMALL_TILE") == nullptr;
+    static const bool small_tiles = exp_env("SGPT_NO_SMALL_TILE") == nullptr;
     const bool scorer = epi == EPI_SCORE || epi == EPI_SCORE_FILTER;
-    const bool few = small_tiles && !(gemm_variant() & 2) && !scorer && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
-    static const bool use256 = getenv("SGPT_GEMM128") == nullptr;
+    // a.force256 (per ctx, sgpt_ctx_set_tile_policy): keep 256x256 tiles for problems the small-tile rule would hand to
+    // the register-staged kernel -- kernel-level tests of single-tile shapes
+    const bool few = small_tiles && !a.force256 && !scorer && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
+    static const bool use256 = exp_env("SGPT_GEMM128") == nullptr;
     const bool shape256 = a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128;
     // short query batches: the 64-row scorer tile (M = 64 padded query rows, N % 256 == 0, K % 64 == 0, K >= 128)
     if (scorer && a.M == 64 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128) {
@@ -849,9 +857,11 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_QKV) return launch<H, EPI_QKV, H, true>(a, s);   // caller checked gemm_qkv_one_launch()
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
-        // variant 1: the 32x32x16-MFMA re-tiling of the same kernel (gemm256w.hip); 0: the 16x16x32 one below
-        if ((gemm_variant() & 1) && (epi != EPI_STORE || o16))
+#ifdef SGPT_EXPERIMENTS
+        // experiment build only: the 32x32x16-MFMA re-tiling of the same kernel (gemm256w.hip; measured slower)
+        if (g_use_w && (epi != EPI_STORE || o16))
             return launch_gemm256w(Half<H>::is_f16 ? DT_F16 : DT_BF16, epi, a, s, deep_a);
+#endif
         if (epi == EPI_SCORE) return launch256d<H, EPI_SCORE, float, true>(a, s, deep_a);
         if (epi == EPI_SCORE_FILTER) return launch256d<H, EPI_SCORE_FILTER, float, true>(a, s, deep_a);
         if (epi == EPI_STORE && o16) return launch256d<H, EPI_STORE, H, true>(a, s, deep_a);
@@ -871,18 +881,24 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int set_gemm_variant(int v) { const int old = gemm_variant(); g_variant = v; return old; }
 // The fused QKV projection as ONE launch (EPI_QKV: q | k row-major, V^T scattered) when the q | k part alone would take
 // the small-tile kernel -- query-sized batches, where a launch costs ~8 us and the scatter stores are few; larger batches
 // keep the two launches with their own store epilogues.  Same sums either way: identical bits.
-bool gemm_qkv_one_launch(int M, int n_split) {
-    static const bool small_tiles = getenv("SGPT_NO_SMALL_TILE") == nullptr && getenv("SGPT_QKV_TWO") == nullptr;
-    return small_tiles && !(gemm_variant() & 2) && n_split % 128 == 0 && (long)(M / 256) * (n_split / 256) * 2 <= 256;
+bool gemm_qkv_one_launch(int M, int n_split, bool force256) {
+    static const bool small_tiles = exp_env("SGPT_NO_SMALL_TILE") == nullptr && exp_env("SGPT_QKV_TWO") == nullptr;
+    return small_tiles && !force256 && n_split % 128 == 0 && (long)(M / 256) * (n_split / 256) * 2 <= 256;
 }
-int set_gemm_kgroups(int g) { const int old = gemm_kgroups(); g_kgroups = g < 1 ? 1 : g; return old; }
+#ifdef SGPT_EXPERIMENTS
 int set_gemm_skew(int cycles) { const int old = g_skew; g_skew = cycles; return old; }
+int set_gemm_use_w(int on) { const int old = g_use_w; g_use_w = on ? 1 : 0; return old; }
+#endif
 
-void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
+void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;          // a zero-initialised descriptor means "no range shifts"
+    if (a.in_mul == 0.f) a.in_mul = 1.f;
+    if (a.out_mul == 0.f) a.out_mul = 1.f;
+    if (a.out_mul2 == 0.f) a.out_mul2 = 1.f;
+    if (a.kgroups < 1) a.kgroups = 1;
     if (dtype == DT_BF16) return launch_gemm16<bf16_t>(epi, out_dtype, a, s);
     if (dtype == DT_F16) return launch_gemm16<f16_t>(epi, out_dtype, a, s);
     if (epi == EPI_STORE) return launch<float, EPI_STORE, float, true>(a, s);

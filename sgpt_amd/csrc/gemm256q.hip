@@ -349,8 +349,10 @@ void launch256q(const GemmArgs& a, hipStream_t s) {
 // EPI_STORE / EPI_VT (out_dtype DT_BF16 | DT_F16, row-major / transposed), EPI_NONE
 bool gemm_fp8_shape_ok(int M, int N, int K) { return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 && K >= 256; }
 
-void launch_gemm_fp8(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
-    if (!gemm_fp8_shape_ok(a.M, a.N, a.K)) abort();
+void launch_gemm_fp8(int epi, int out_dtype, const GemmArgs& a0, hipStream_t s) {
+    if (!gemm_fp8_shape_ok(a0.M, a0.N, a0.K)) abort();
+    GemmArgs a = a0;          // the shared store epilogues read the f16 range-shift factors: none on this path
+    a.in_mul = a.out_mul = a.out_mul2 = 1.f;
     if (epi == EPI_BIAS_GELU) return launch256q<EPI_BIAS_GELU, bf16_t, true>(a, s);
     if (epi == EPI_BIAS_RESID) return launch256q<EPI_BIAS_RESID, bf16_t, true>(a, s);
     if (epi == EPI_NONE) return launch256q<EPI_NONE, bf16_t, true>(a, s);

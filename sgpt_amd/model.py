@@ -92,10 +92,19 @@ def _flatten(seqs, total: int) -> np.ndarray:
     """Ragged token lists -> one int32 vector, at C speed: a [B,S] ndarray is a reshape, lists of ndarrays a
     concatenate, lists of lists one itertools.chain pass (no per-token Python bytecode)."""
     if isinstance(seqs, np.ndarray) and seqs.ndim == 2:
-        return np.ascontiguousarray(seqs, dtype=np.int32).reshape(-1)
+        return _to_i32(seqs).reshape(-1)
     if len(seqs) and isinstance(seqs[0], np.ndarray):
-        return np.concatenate(seqs).astype(np.int32, copy=False)
+        return _to_i32(np.concatenate(seqs))
+    # (Python ints beyond int32 make numpy raise OverflowError here instead of wrapping)
     return np.fromiter(itertools.chain.from_iterable(seqs), dtype=np.int32, count=total)
+
+
+def _to_i32(a: np.ndarray) -> np.ndarray:
+    """Narrow token ids to int32 without letting an id >= 2^31 wrap into the vocabulary range (the range check of
+    SGPTModel.pack runs on the narrowed values)."""
+    if a.dtype != np.int32 and a.size and (int(a.max()) > np.iinfo(np.int32).max or int(a.min()) < np.iinfo(np.int32).min):
+        raise ValueError("token id out of range")
+    return np.ascontiguousarray(a, dtype=np.int32)
 
 
 def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None, bucket: Optional[Tuple[int, int, int]] = None) -> dict:
@@ -440,17 +449,69 @@ class SGPTModel:
         out.append(order[start:])
         return out
 
-    def _check_range(self):
-        """dtype='f16': fail loudly if an activation left the half range during the calls just issued."""
+    # ---- range guards (per model: a flag raised here is never blamed on another model of the same context) ----
+    def range_flags(self, reset: bool = True) -> int:
+        """The model's guard word since the last reset (syncs the stream; include/sgpt_hip.h::sgpt_model_range_check):
+        bit 0 = an f16 activation reached |v| >= 32768, bit 1 / 2 = an fp8mfma GELU output / attention context saturated."""
+        flagged = C.c_int32(0)
+        _lib.check(self.ctx.handle, self.ctx.lib.sgpt_model_range_check(self.handle, C.byref(flagged), 1 if reset else 0,
+                                                                        _stream_ptr(self.device)), "sgpt_model_range_check")
+        return int(flagged.value)
+
+    def range_shifts(self) -> np.ndarray:
+        """dtype='f16': the power-of-two down-shifts per block, int32[num_layers, 4] = (LayerNorm-1 output, q | k | v,
+        LayerNorm-2 output, GELU output).  All zero for a checkpoint whose activations stay inside the half range."""
+        out = np.zeros(self.cfg.num_layers * 4, dtype=np.int32)
+        _lib.check(self.ctx.handle, self.ctx.lib.sgpt_model_get_range_shifts(self.handle, out.ctypes.data_as(C.c_void_p), out.size),
+                   "sgpt_model_get_range_shifts")
+        return out.reshape(self.cfg.num_layers, 4)
+
+    def set_range_shifts(self, shifts) -> None:
+        """Pin the shifts found on an earlier run (reproducible embeddings across processes)."""
+        a = np.ascontiguousarray(np.asarray(shifts, dtype=np.int32).reshape(-1))
+        _lib.check(self.ctx.handle, self.ctx.lib.sgpt_model_set_range_shifts(self.handle, a.ctypes.data_as(C.c_void_p), a.size),
+                   "sgpt_model_set_range_shifts")
+
+    def _adapt_range(self) -> bool:
+        """dtype='f16', after a flagged call: raise the shifts of the classes that overflowed.  True = re-run the call."""
+        n = C.c_int32(0)
+        _lib.check(self.ctx.handle, self.ctx.lib.sgpt_model_range_adapt(self.handle, C.byref(n), _stream_ptr(self.device)),
+                   "sgpt_model_range_adapt")
+        return n.value > 0
+
+    def check_range(self, adapt: bool = False) -> bool:
+        """Fail loudly if a call since the last check left a format's range.  adapt=True (dtype='f16'): instead of raising,
+        raise the range shifts of the operand classes that overflowed and return True -- the caller re-runs its calls
+        (their results were not trustworthy); encode_ids / token_embeddings / the cross-encoder do exactly that."""
         if self.dtype not in ("f16", "fp8mfma"):
-            return
-        flags = self.ctx.range_check(reset=True)
-        if flags & 1:
-            raise SgptRangeError("dtype='f16': an activation reached |v| >= 32768 (IEEE-half range); "
-                                 "this checkpoint needs dtype='bf16'")
+            return False
+        flags = self.range_flags(reset=False)
+        if not flags:
+            return False
+        if flags & 1 and not flags & 6 and adapt and self.dtype == "f16" and self._adapt_range():
+            return True                      # (sgpt_model_range_adapt cleared bit 0 and the recorded magnitudes)
+        self.range_flags(reset=True)
         if flags & 2:
             raise SgptRangeError("dtype='fp8mfma': a GELU output saturated its e4m3 codes; re-run calibrate() on "
                                  "representative inputs (or with a larger margin)")
+        if flags & 4:
+            raise SgptRangeError("dtype='fp8mfma': an attention context saturated its e4m3 codes; re-run calibrate() on "
+                                 "representative inputs (or with a larger margin)")
+        raise SgptRangeError("dtype='f16': an activation reached |v| >= 32768 (IEEE-half range)" +
+                             (" and no range shift covers it; this checkpoint needs dtype='bf16'" if adapt else
+                              "; re-run the call under SGPTModel.guarded / check_range(adapt=True)"))
+
+    _check_range = check_range      # (name used before ABI v5)
+
+    def guarded(self, fn):
+        """Run `fn()` (a function that issues encode calls and returns their result) under the range guard: when an f16
+        activation class overflowed, its shift is raised and fn runs again with the new factors (at most a few rounds: a
+        round fixes every class that overflowed in it; a class pushed over the limit by an earlier fix is caught next)."""
+        for _ in range(8):
+            out = fn()
+            if not self.check_range(adapt=True):
+                return out
+        raise SgptRangeError("dtype='f16': the range shifts did not converge; this checkpoint needs dtype='bf16'")
 
     def _batched(self, seqs, pad_left, run) -> torch.Tensor:
         """Length-sorted token-budget batches -> `run(pb, out_rows)` per batch -> rows back in input order."""
@@ -461,13 +522,16 @@ class SGPTModel:
         lens = np.fromiter(map(len, seqs), dtype=np.int64, count=n)
         if (lens <= 0).any():
             raise ValueError("Empty items should be cleaned prior to running")
+        return self.guarded(lambda: self._batched_once(seqs, pad_left, run, lens))
+
+    def _batched_once(self, seqs, pad_left, run, lens) -> torch.Tensor:
+        n, d = len(seqs), self.cfg.hidden_size
         # everything fits one call: the packed layout has no padding to the longest sequence, so the length sort of the
         # reference (SentenceTransformer.py:148-149) buys nothing -- pack in input order, no un-sort pass
         alloc_total = int(((lens + ALIGN - 1) // ALIGN * ALIGN).sum())
         if alloc_total <= self.max_tokens_per_call:
             res = torch.empty((n, d), dtype=torch.float32, device=self.device)
             run(self.pack(seqs, pad_left), res)
-            self._check_range()
             return res
         plan = self.plan_batches(lens)
         sorted_rows = torch.empty((n, d), dtype=torch.float32, device=self.device)
@@ -479,7 +543,6 @@ class SGPTModel:
         order = torch.from_numpy(np.concatenate(plan)).pin_memory().to(self.device, non_blocking=True)
         res = torch.empty_like(sorted_rows)
         res[order] = sorted_rows                                   # un-sort (SentenceTransformer.py:205), one pass
-        self._check_range()
         return res
 
     def encode_ids_all_layers(self, seqs: Sequence[Sequence[int]], mode: str = "mean",
@@ -502,16 +565,17 @@ class SGPTModel:
         lens = np.fromiter(map(len, seqs), dtype=np.int64, count=n)
         if n == 0 or (lens <= 0).any():
             raise ValueError("Empty items should be cleaned prior to running")
-        out: List[Optional[torch.Tensor]] = [None] * n
-        for sel in self.plan_batches(lens):
-            sub = [seqs[i] for i in sel]
-            pb = self.pack(sub, None if pad_left is None else [pad_left[i] for i in sel])
-            _, hid = self.encode_packed(pb, layer_idx=layer_idx, return_hidden=True)
-            off = pb.seq_off.cpu().tolist()
-            for j, i in enumerate(sel.tolist()):
-                out[i] = hid[off[j]: off[j] + len(sub[j])].clone()
-        self._check_range()
-        return out
+        def once():
+            out: List[Optional[torch.Tensor]] = [None] * n
+            for sel in self.plan_batches(lens):
+                sub = [seqs[i] for i in sel]
+                pb = self.pack(sub, None if pad_left is None else [pad_left[i] for i in sel])
+                _, hid = self.encode_packed(pb, layer_idx=layer_idx, return_hidden=True)
+                off = pb.seq_off.cpu().tolist()
+                for j, i in enumerate(sel.tolist()):
+                    out[i] = hid[off[j]: off[j] + len(sub[j])].clone()
+            return out
+        return self.guarded(once)
 
 
 class EncodeGraph:
@@ -552,7 +616,7 @@ class EncodeGraph:
         return (self.pb.B, self.pb.T_pad, self.pb.max_alloc)
 
     def replay(self, seqs: Optional[Sequence[Sequence[int]]] = None,
-               pad_left: Optional[Sequence[int]] = None) -> torch.Tensor:
+               pad_left: Optional[Sequence[int]] = None, check_range: bool = True) -> torch.Tensor:
         """Re-run on new sentences whose packed layout falls in the same bucket (None: same inputs again).
         The returned tensor is the graph's static output buffer (rows past `pb.n_real` belong to bucket fillers)."""
         if seqs is not None:
@@ -561,10 +625,16 @@ class EncodeGraph:
             except ValueError as e:
                 raise ValueError(f"{e}: not this graph's bucket {self.bucket}") from None
             self.model._check_learnt(self.mode, self.pb)
-        if self.model.ctx.generation() != self.generation:
-            self._capture()                      # the workspace / pooling table moved since capture: stale pointers
-        self.graph.replay()
-        return self.out
+        for _ in range(8):
+            if self.model.ctx.generation() != self.generation:
+                self._capture()                  # the workspace / pooling table / range shifts moved since capture
+            self.graph.replay()
+            # range guard (a 4-byte read-back: syncs).  check_range=False keeps replay() asynchronous; the caller then owes
+            # a model.check_range() before trusting the rows.  An f16 overflow raises the shifts (-> generation moves ->
+            # re-capture) and the replay runs again.
+            if not check_range or not self.model.check_range(adapt=True):
+                return self.out
+        raise SgptRangeError("dtype='f16': the range shifts did not converge; this checkpoint needs dtype='bf16'")
 
 
 def load_state_dict(root: str) -> Dict[str, torch.Tensor]:

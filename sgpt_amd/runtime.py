@@ -114,8 +114,8 @@ class Context:
         return self.to_16(x, torch.bfloat16)
 
     def range_check(self, reset: bool = True) -> int:
-        """Range guards (syncs the stream): bit 0 = an f16 activation left the half range, bit 1 = an fp8mfma GELU output
-        saturated its e4m3 codes, since the last reset.  0 = clean."""
+        """Range guard of the ctx-level stand-alone ops (`linear` with f16 output; syncs the stream): bit 0 = an f16 value
+        left the half range since the last reset.  Models carry their own guard word (SGPTModel.check_range)."""
         flagged = C.c_int32(0)
         self._chk(self.lib.sgpt_range_check(self.handle, C.byref(flagged), 1 if reset else 0, _stream_ptr(self.device)),
                   "sgpt_range_check")
@@ -126,9 +126,14 @@ class Context:
         return int(self.lib.sgpt_ctx_generation(self.handle))
 
     def set_low_latency(self, on: bool) -> bool:
-        """Process-wide: k-groups for query-sized GEMM launches (include/sgpt_hip.h::sgpt_set_gemm_kgroups): ~16 % off a
+        """Per context: k-groups for query-sized GEMM launches (include/sgpt_hip.h::sgpt_ctx_set_low_latency): ~16 % off a
         16-query encode, at the price of bit-identical embeddings across batch sizes.  Returns the previous setting."""
-        return int(self.lib.sgpt_set_gemm_kgroups(2 if on else 1)) > 1
+        return bool(self.lib.sgpt_ctx_set_low_latency(self.handle, 1 if on else 0))
+
+    def set_tile_policy(self, force_256: bool) -> bool:
+        """Per context: keep the 256x256 LDS-DMA GEMM tiles even where the small-tile rule would apply (kernel tests of
+        single-tile shapes; identical bits either way).  Returns the previous policy."""
+        return bool(self.lib.sgpt_ctx_set_tile_policy(self.handle, 1 if force_256 else 0))
 
     def reserve(self, encode_bytes: int = 0, score_bytes: int = 0) -> None:
         self._chk(self.lib.sgpt_ctx_reserve(self.handle, encode_bytes, score_bytes), "sgpt_ctx_reserve")

@@ -112,30 +112,56 @@ def test_encode_f16_vs_golden(tag):
         assert maxabs(g2, fx[f"emb_{mode}"]) < TOL_F16_ABS * max(1.0, float(np.abs(fx[f"emb_{mode}"]).max())), mode
 
 
-def test_f16_range_guard_fails_loudly():
-    """f16 has 5 exponent bits.  Weights / LayerNorm parameters that cannot be represented are refused at load;
-    an activation that reaches |v| >= 32768 at run time raises from encode_ids (never a silent inf)."""
+def test_f16_range_shifts_cover_outliers_and_the_guard_stays_loud():
+    """f16 has 5 exponent bits.  Operand classes that would leave the format are stored under a power-of-two down-shift
+    which the consuming GEMM undoes on its fp32 accumulators (exact): a LayerNorm bound beyond the format is handled at
+    load, a run-time overflow (here: a GELU output of 5e4) raises exactly that class's shift and the call is re-run --
+    the result then agrees with the fp32 oracle like any other f16 result.  What no shift covers still fails loudly:
+    weights outside the format, and a direct encode_packed caller who never checks the guard is told by check_range()."""
     from sgpt_amd import SGPTConfig, SGPTModel
     from sgpt_amd._lib import SgptRangeError
     kw = dict(vocab_size=211, max_position_embeddings=96, hidden_size=128, num_layers=2, num_heads=2, window_size=8)
-    base = O.synth_weights(O.NeoConfig(**kw), seed=3, std=0.05)
+    cfg = O.NeoConfig(**kw)
+    base = O.synth_weights(cfg, seed=3, std=0.05)
     seqs = [[1, 2, 3, 4, 5], [7] * 40]
     w = dict(base); w["h.1.attn.attention.q_proj.weight"] = base["h.1.attn.attention.q_proj.weight"] * 0 + 1e5
     with pytest.raises(SgptRangeError):
         SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
-    w = dict(base); w["h.0.ln_2.weight"] = base["h.0.ln_2.weight"] * 0 + 4000.0          # 4000 * sqrt(128) > 32768
-    with pytest.raises(SgptRangeError):
-        SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
-    w = dict(base); w["h.1.mlp.c_fc.bias"] = base["h.1.mlp.c_fc.bias"] * 0 + 5e4          # gelu_new(5e4) = 5e4 -> f16 h
+
+    def rel(m, wts):
+        want = O.encode(wts, cfg, seqs, mode="weightedmean", batch_size=len(seqs))
+        got = m.encode_ids(seqs).cpu().numpy()
+        assert np.isfinite(got).all()
+        return float(np.abs(got - want).max() / np.abs(want).max())
+    # (1) LayerNorm gamma 4000: 4000 * sqrt(128) > 32768 -> load-time shift on the LayerNorm outputs of every block
+    w = dict(base); w["h.0.ln_2.weight"] = base["h.0.ln_2.weight"] * 0 + 4000.0
     m = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
-    with pytest.raises(SgptRangeError):
-        m.encode_ids(seqs)
+    sh = m.range_shifts()
+    assert (sh[:, 0] > 0).all() and (sh[:, 2] > 0).all() and (sh[:, [1, 3]] == 0).all()
+    e1 = rel(m, w)
     m.close()
-    mb = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="bf16")                     # bf16 takes the same weights
-    assert torch.isfinite(mb.encode_ids(seqs)).all()
-    mb.close()
+    # (2) an fc bias of 5e4 drives the GELU output past the format at run time: adapt + re-run inside encode_ids
+    w = dict(base); w["h.1.mlp.c_fc.bias"] = base["h.1.mlp.c_fc.bias"] * 0 + 5e4
+    m = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
+    assert (m.range_shifts() == 0).all()
+    e2 = rel(m, w)
+    sh = m.range_shifts()
+    assert sh[1, 3] >= 2 and sh[0].sum() == 0 and (sh[1, :3] == 0).all(), sh      # only block 1's GELU-output class moved
+    again = m.encode_ids(seqs).cpu().numpy()                                       # shifts are sticky: no second adaptation
+    assert np.array_equal(again, m.encode_ids(seqs).cpu().numpy()) and (m.range_shifts() == sh).all()
+    # a direct encode_packed caller owes the check: flagged calls raise from check_range() ...
+    m.set_range_shifts(np.zeros_like(sh))
+    m.encode_packed(m.pack(seqs))
+    with pytest.raises(SgptRangeError):
+        m.check_range()
+    # ... and pinned shifts reproduce the adapted result bit for bit
+    m.set_range_shifts(sh)
+    assert np.array_equal(again, m.encode_ids(seqs).cpu().numpy())
+    m.close()
+    print(f"f16 range shifts: LayerNorm-gamma case rel err {e1:.2e}, GELU-overflow case rel err {e2:.2e}")
+    assert e1 < 5e-3 and e2 < 5e-3
     ok = SGPTModel(SGPTConfig(**kw), base, device="cuda:0", dtype="f16")
-    assert torch.isfinite(ok.encode_ids(seqs)).all()                                       # and the flag was reset
+    assert torch.isfinite(ok.encode_ids(seqs)).all() and (ok.range_shifts() == 0).all()   # a clean model is untouched
     ok.close()
 
 
@@ -316,7 +342,7 @@ def test_query_sized_and_bulk_batches_give_identical_bits(dtype):
     once.  (The opt-in k-group mode gives this up; pinned off here.)"""
     fx, cfg_kw, *_ = load_case("cfg1_125m_32x64")
     m = build_model(cfg_kw, int(fx["seed"]), float(fx["std"]), dtype)
-    old_kg, old_budget = m.ctx.lib.sgpt_set_gemm_kgroups(1), m.max_tokens_per_call      # (the model is shared by the session)
+    old_kg, old_budget = m.ctx.set_low_latency(False), m.max_tokens_per_call      # (the model is shared by the session)
     try:
         rng = np.random.default_rng(21)
         few = [rng.integers(0, 50256, size=int(k)).tolist() for k in rng.integers(3, 40, size=12)]
@@ -327,7 +353,7 @@ def test_query_sized_and_bulk_batches_give_identical_bits(dtype):
         mid = m.encode_ids(bulk[:100], normalize=True)[: len(few)].cpu().numpy()      # ~11 k rows: 128x128 tiles
         assert np.array_equal(alone, inside) and np.array_equal(alone, mid)
     finally:
-        m.ctx.lib.sgpt_set_gemm_kgroups(old_kg)
+        m.ctx.set_low_latency(old_kg)
         m.max_tokens_per_call = old_budget
 
 
@@ -352,13 +378,13 @@ def test_encode_graph_capture_and_replay():
     # capacity bucket: any batch that fits (fewer / shorter / differently shaped sequences) replays the same graph
     # (equal to the eager call of the un-padded batch because every batch size produces the same bits -- the default;
     # the opt-in low-latency k-groups give that up, so the comparison pins the mode)
-    old_kg = m.ctx.lib.sgpt_set_gemm_kgroups(1)
+    old_kg = m.ctx.set_low_latency(False)
     gb = EncodeGraph(m, a, normalize=True, bucket=(64, 2048, 64))
     for n, hi in ((32, 33), (5, 60), (64, 17), (1, 2)):
         q = [rng.integers(0, 50256, size=int(k)).tolist() for k in rng.integers(1, hi, size=n)]
         got = gb.replay(q)[:n].cpu().numpy()
         assert gb.pb.n_real == n and np.abs(got - m.encode_ids(q, normalize=True).cpu().numpy()).max() < 1e-6
-    m.ctx.lib.sgpt_set_gemm_kgroups(old_kg)
+    m.ctx.set_low_latency(old_kg)
     with pytest.raises(ValueError):
         gb.replay([rng.integers(0, 50256, size=70).tolist()])       # longer than the bucket's A_cap
     with pytest.raises(ValueError):

@@ -22,12 +22,12 @@ def ctx():
     return get_context("cuda:0")
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["mfma16", "mfma32", "mfma16-forced256", "mfma32-forced256"])
+@pytest.fixture(params=[0, 2], ids=["default-tiles", "forced256"])
 def variant(request, ctx):
-    """bit 0: 32x32x16-MFMA kernel; bit 1: 256x256 tiles even when they leave most CUs idle (single-tile cases)."""
-    old = ctx.lib.sgpt_set_gemm_variant(request.param)
+    """2: 256x256 LDS-DMA tiles even when they leave most CUs idle (single-tile cases); 0: the default tile policy."""
+    old = ctx.set_tile_policy(request.param == 2)
     yield request.param
-    ctx.lib.sgpt_set_gemm_variant(old)
+    ctx.set_tile_policy(old)
 
 
 def gelu_new(u):
@@ -89,15 +89,17 @@ def test_linear_layout_is_not_transposed(ctx, variant, dt):
     assert torch.equal(out.float(), want)
 
 
-def test_linear_variants_agree(ctx):
-    """The two MFMA shapes accumulate the same products: fp32 outputs agree to accumulation-order noise."""
-    a, w, bias, resid = operands(4096, 3072, 768, "f16", seed=5)
+def test_linear_tile_policies_agree_bitwise(ctx):
+    """The 256x256 LDS-DMA kernel and the register-staged 128x128 / 64x64 one feed every output element the same MFMA
+    sequence: identical bits whichever the tile policy picks."""
+    a, w, bias, resid = operands(1024, 768, 768, "f16", seed=5)
     outs = []
-    for v in (0, 1):
-        old = ctx.lib.sgpt_set_gemm_variant(v)
-        outs.append(ctx.linear(a, w, bias, epi="resid", resid=resid))
-        ctx.lib.sgpt_set_gemm_variant(old)
-    assert float((outs[0] - outs[1]).abs().max()) < 2e-5 * float(outs[0].abs().max())
+    for force in (False, True):
+        old = ctx.set_tile_policy(force)
+        outs.append((ctx.linear(a, w, bias, epi="resid", resid=resid), ctx.linear(a, w, bias, epi="gelu"),
+                     ctx.linear(a, w, None, epi="store"), ctx.linear(a, w, None, epi="vt")))
+        ctx.set_tile_policy(old)
+    assert all(torch.equal(u, v) for u, v in zip(*outs))
 
 
 def test_f16_range_flag_raised_by_store_epilogue(ctx):
@@ -130,13 +132,13 @@ def test_k_group_launches_are_deterministic_and_match_the_unsplit_kernel(ctx, dt
     acc = a.float() @ w.float().T
     scale = float(acc.abs().max())
     tol32 = 1e-3 * math.sqrt(K / 64) * scale
-    old_kg = ctx.lib.sgpt_set_gemm_kgroups(1)                       # mode off (the default): one group
+    old_kg = ctx.set_low_latency(False)                             # mode off (the default): one group
     try:
         off = ctx.linear(a, w, bias, epi="resid", resid=resid)
-        ctx.lib.sgpt_set_gemm_kgroups(2)
+        ctx.set_low_latency(True)
         _k_group_checks(ctx, dt, M, N, K, a, w, bias, resid, acc, tol32, off)
     finally:
-        ctx.lib.sgpt_set_gemm_kgroups(old_kg)
+        ctx.set_low_latency(old_kg)
 
 
 def _k_group_checks(ctx, dt, M, N, K, a, w, bias, resid, acc, tol32, off):
@@ -160,9 +162,9 @@ def _k_group_checks(ctx, dt, M, N, K, a, w, bias, resid, acc, tol32, off):
     if M % 128 == 0:
         assert float(((vt.float() - want.T).abs() - ULP[dt] * want.T.abs()).max()) < tol32
     if M % 256 == 0 and N % 256 == 0 and K % 64 == 0:
-        old = ctx.lib.sgpt_set_gemm_variant(2)                       # 256x256 tiles, one workgroup per tile, k ascending
+        old = ctx.set_tile_policy(True)                              # 256x256 tiles, one workgroup per tile, k ascending
         ref = ctx.linear(a, w, bias, epi="resid", resid=resid)
-        ctx.lib.sgpt_set_gemm_variant(old)
+        ctx.set_tile_policy(old)
         assert float((x - ref).abs().max()) < 2e-5 * float(ref.abs().max())
         assert torch.equal(off, ref), "with the mode off every kernel produces the k-ascending sum, bit for bit"
         if M <= 1024 and (K // 64) % 2 == 0:      # (K = 2112: 33 k-steps do not split evenly -> one group, the control)
