@@ -89,7 +89,34 @@ def flops_per_sentence(S, L=12, d=768):
     return L * 24 * S * d * d + 2 * L * d * S * (S + 1)
 
 
-def hf_cpu_baseline(ocfg, ow, sample, repeats=3):
+def cpu_info():
+    """CPU model string, physical cores, logical CPUs of the box (lscpu; /proc/cpuinfo as the fallback)."""
+    model, phys, logical = None, None, os.cpu_count()
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {ln.split(":", 1)[0].strip(): ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ":" in ln}
+        model = kv.get("Model name")
+        phys = int(kv["Core(s) per socket"]) * int(kv["Socket(s)"])
+    except Exception:  # noqa: BLE001
+        try:
+            with open("/proc/cpuinfo") as f:
+                for ln in f:
+                    if ln.startswith("model name"):
+                        model = ln.split(":", 1)[1].strip()
+                        break
+        except OSError:
+            pass
+    return {"model": model, "physical_cores": phys, "logical_cpus": logical}
+
+
+def cpu_threads():
+    """Threads for the CPU legs: one per physical core (SMT siblings only contend for the FMA units), at most 64 -- a
+    128-sentence batch of 768-wide matmuls does not scale past that."""
+    info = cpu_info()
+    return max(1, min(64, info["physical_cores"] or info["logical_cpus"] or 1))
+
+
+def hf_cpu_baseline(ocfg, ow, sample, repeats=3, mask=None, hf=None):
     """The code the reference itself runs on a CPU: HF GPTNeoModel (fp32, eager attention, eval -- the
     un-vendored dependency behind beir_dense_retriever.py:204-205) + the raw weighted-mean pooling of :258-270 +
     F.normalize, on the host cores over a bounded sample; 1 warm-up + `repeats` timed passes, median."""
@@ -101,12 +128,13 @@ def hf_cpu_baseline(ocfg, ow, sample, repeats=3):
                       layer_norm_epsilon=ocfg.layer_norm_epsilon, attention_dropout=0.0, resid_dropout=0.0,
                       embed_dropout=0.0)
     hc._attn_implementation = "eager"
-    hf = GPTNeoModel(hc).eval()
-    hf.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ow.items()}, strict=False)
-    threads = min(64, os.cpu_count() or 1)     # more threads than that only oversubscribe a 64-sentence batch
+    if hf is None:
+        hf = GPTNeoModel(hc).eval()
+        hf.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ow.items()}, strict=False)
+    threads = cpu_threads()
     torch.set_num_threads(threads)
     ids = torch.tensor(sample, dtype=torch.long)
-    mask = torch.ones_like(ids)
+    mask = torch.ones_like(ids) if mask is None else torch.tensor(mask, dtype=torch.long)
 
     def run(i, m):
         with torch.no_grad():
@@ -124,7 +152,7 @@ def hf_cpu_baseline(ocfg, ow, sample, repeats=3):
     return emb.numpy(), {"value": round(len(sample) / dt, 2), "unit": "sentences/s", "cores": threads, "kind": "reference",
                          "sample": f"{len(sample)} sentences x {ids.shape[1]} tokens: HF GPTNeoModel fp32 eager + raw weighted-mean "
                                    f"pooling + normalise (the reference's CPU path), torch CPU, median of {repeats} passes "
-                                   f"({', '.join(f'{x:.1f}' for x in times)} s)"}
+                                   f"({', '.join(f'{x:.1f}' for x in times)} s)"}, hf
 
 
 def free_port():
@@ -149,7 +177,7 @@ def relaunch_distributed(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=25)          # 25 x 4096 = 102 400 >= configs[1]'s 100k documents
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chunk", type=int, default=4096, help="documents per step (per GPU)")
     ap.add_argument("--call", type=int, default=1024, help="documents per sgpt_encode call")
@@ -163,7 +191,7 @@ def main():
     ap.add_argument("--model", default="125m", choices=sorted(MODELS), help="SGPT size (default: the BASELINE metric's 125M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the queries/sec @ 1M-doc scoring leg")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="sentences in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="sentences in the bounded CPU-baseline sample (a slice of the 1024 x seq probe)")
     ap.add_argument("--no-varlen", action="store_true", help="skip the lengths ~U{16..128} leg")
     args = ap.parse_args()
 
@@ -212,7 +240,7 @@ def main():
     # queries: lengths U{4..32}; encoded sharded by rank, then ONE all-gather
     qrng = np.random.default_rng(7)
     queries = [qrng.integers(0, 50256, size=int(qrng.integers(4, 33))).tolist() for _ in range(args.nq)]
-    from sgpt_amd.dist import all_gather_queries, exchange_topk, shard_range
+    from sgpt_amd.dist import all_gather_queries, exchange_topk, shard_range, shard_sizes
     qlo, qhi = shard_range(args.nq, rank, world)
     mine = queries[qlo:qhi]
 
@@ -221,7 +249,7 @@ def main():
 
     def encode_queries():
         local_q = model.encode_ids(mine, normalize=True) if mine else torch.empty((0, d), device=dev)
-        return all_gather_queries(local_q, args.nq) if dist_on else local_q   # RCCL all-gather over xGMI
+        return all_gather_queries(ctx, local_q, shard_sizes(args.nq, world)) if dist_on else local_q   # ncclAllGather over xGMI (C ABI)
 
     def step(i, q, run):
         base = i * args.chunk
@@ -253,9 +281,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps):
         run = step(i, q, run)
-    if dist_on:   # exchange step: per-rank top-(k+1) lists -> every rank, merge
-        cv, ci = exchange_topk(run[0], run[1])
-        fv, fi = ctx.topk_merge(cv, ci, k1)
+    if dist_on:   # exchange step: per-rank top-(k+1) lists -> every rank, merged on the device (sgpt_exchange_topk)
+        fv, fi = exchange_topk(ctx, run[0], run[1], k1)
     else:
         fv, fi = run[0], run[1]
     sync()
@@ -272,18 +299,52 @@ def main():
     sentences = world * args.steps * args.chunk
     sent_per_s = sentences / dt
 
+    # ---- the same steps with the host side of the boundary inside the clock: every sgpt_encode call first packs its
+    # token ids from host memory (numpy [call, S] int64 -> the int32 arena in pinned memory) and copies them over PCIe
+    # (one non-blocking H2D per call, two pinned arenas alternating: the copy of call i+1 overlaps the encode of call i).
+    # `value` above starts with the packed ids resident in HBM (SURVEY 8d boundary); this is the PCIe-inclusive rate. ----
+    host_steps = min(args.steps, 8)
+    hrng = np.random.default_rng(3000 + rank)
+    host_ids = [[hrng.integers(0, min(50256, cfg.vocab_size), size=(min(args.call, args.chunk - c0), S), dtype=np.int64)
+                 for c0 in range(0, args.chunk, args.call)] for _ in range(host_steps)]
+
+    def host_step(i, run):
+        o = 0
+        for ids in host_ids[i]:
+            pb = model.pack(ids)                                    # host pack + pinned async H2D
+            model.encode_packed(pb, mode="weightedmean", normalize=True, out=emb32[o: o + pb.B])
+            o += pb.B
+        rows = corpus[i * args.chunk: (i + 1) * args.chunk]
+        if score_dt != torch.float32:
+            ctx.to_16(emb32, score_dt, out=rows)
+        else:
+            rows.copy_(emb32)
+        return ctx.score_topk(q, rows, k1, idx_base=rank * n_steps * args.chunk + i * args.chunk, run=run, dtype=score_dt)
+    hrun = host_step(0, None)
+    sync()
+    t = time.perf_counter()
+    for i in range(host_steps):
+        hrun = host_step(i, hrun)
+    sync()
+    hdt = time.perf_counter() - t
+    if dist_on:
+        th = torch.tensor([hdt], dtype=torch.float64, device=dev)
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        hdt = float(th.item())
+    sent_per_s_host = world * host_steps * args.chunk / hdt
+    del host_ids
+
     # ---- N > 1: the sharded search (per-rank score+top-k with a global index base -> exchange -> merge) must equal a
     # single-rank search over the same documents.  Checked on the first `m` rows of every rank's shard. ----
     shard_check = None
     if dist_on:
         m = min(2048, args.chunk)
         mine_rows = corpus[:m].contiguous()
-        all_rows = torch.empty((world * m, d), dtype=score_dt, device=dev)
-        dist.all_gather_into_tensor(all_rows, mine_rows)
+        from sgpt_amd.dist import get_comm
+        all_rows = get_comm(ctx).all_gather_rows(mine_rows, [m] * world)
         stride = n_steps * args.chunk                                  # global index base of rank r = r * stride
         sv, si, _ = ctx.score_topk(q, mine_rows, k1, idx_base=rank * stride, dtype=score_dt)
-        cv, ci = exchange_topk(sv, si)
-        mv, mi = ctx.topk_merge(cv, ci, k1)
+        mv, mi = exchange_topk(ctx, sv, si, k1)
         wv, wi, _ = ctx.score_topk(q, all_rows, k1, idx_base=0, dtype=score_dt)
         wi = (wi // m) * stride + wi % m
         same = bool(torch.equal(mi, wi)) and bool(torch.equal(mv, wv))
@@ -298,8 +359,7 @@ def main():
     def search_once(cmat):
         v, i, _ = ctx.score_topk(q, cmat, k1, idx_base=rank * cmat.shape[0], dtype=score_dt)
         if dist_on:
-            cv, ci = exchange_topk(v, i)
-            v, i = ctx.topk_merge(cv, ci, k1)
+            v, i = exchange_topk(ctx, v, i, k1)
         return v, i
 
     def time_search(cmat, reps=5):
@@ -333,12 +393,11 @@ def main():
 
             def once():
                 lq = model.encode_ids(sub, normalize=True) if sub else torch.empty((0, d), device=dev)
-                qq = all_gather_queries(lq, nq_sub) if dist_on else lq
+                qq = all_gather_queries(ctx, lq, shard_sizes(nq_sub, world)) if dist_on else lq
                 q2 = ctx._operand(qq, score_dt)
                 v2, i2, _ = ctx.score_topk(q2, big, k1, idx_base=rank * big.shape[0], dtype=score_dt)
                 if dist_on:
-                    cv2, ci2 = exchange_topk(v2, i2)
-                    v2, i2 = ctx.topk_merge(cv2, ci2, k1)
+                    v2, i2 = exchange_topk(ctx, v2, i2, k1)
             once()
             sync()
             t = time.perf_counter()
@@ -465,11 +524,21 @@ def main():
                   "gpu_vs_oracle_max_abs_emb_diff": float(np.abs(got - ce).max()),
                   "gpu_vs_oracle_max_abs_cos_diff": float(np.abs(gcos - ce @ ce.T).max())}
         try:
-            hf_emb, cpu = hf_cpu_baseline(ocfg, ow, sample)
+            hf_emb, cpu, hf = hf_cpu_baseline(ocfg, ow, sample)
             parity["gpu_vs_hf_max_abs_emb_diff"] = float(np.abs(got - hf_emb).max())
             parity["gpu_vs_hf_max_abs_cos_diff"] = float(np.abs(gcos - hf_emb @ hf_emb.T).max())
             parity["oracle_vs_hf_max_abs_emb_diff"] = float(np.abs(ce - hf_emb).max())
             cpu["checker_port"] = port
+            # BASELINE configs[0]: the reference's own CPU-runnable case, 32 sentences of 8..64 tokens (right-padded batch)
+            c1rng = np.random.default_rng(0)
+            c1 = [c1rng.integers(0, 50256, size=int(c1rng.integers(8, 65))).tolist() for _ in range(32)]
+            c1_ids, c1_mask = O.pad_batch(c1, pad_id=O.GPT2_PAD, side="right")
+            c1_emb, c1_res, _ = hf_cpu_baseline(ocfg, ow, c1_ids.tolist(), mask=c1_mask.tolist(), hf=hf)
+            c1_gpu = model.encode_ids(c1, normalize=True).cpu().numpy()
+            c1_res["gpu_vs_hf_max_abs_emb_diff"] = float(np.abs(c1_gpu - c1_emb).max())
+            c1_res["sample"] = "BASELINE configs[0]: 32 sentences of 8..64 tokens, one right-padded batch; " + c1_res["sample"]
+            cpu["cfg1_32x64"] = c1_res
+            del hf
         except Exception as e:  # noqa: BLE001 -- `transformers` missing on the box: the port is the baseline
             cpu = dict(port, hf_error=f"{type(e).__name__}: {e}"[:200])
         # queries/s of the reference's CPU search leg (exact_search.py:96-132 restated: cos_sim + top-k + heap merge per
@@ -483,13 +552,19 @@ def main():
         for _ in range(3):
             t = time.perf_counter()
             O.exact_search(qemb, [f"q{i}" for i in range(128)], cemb, [f"d{i}" for i in range(100_000)], args.topk, "cos_sim",
-                           chunk_size=50_000)
+                           chunk_size=50_000, backend="torch")
             qt.append(time.perf_counter() - t)
         cpu["search"] = {"value": round(128 / float(np.median(qt)), 1), "unit": "queries/s", "kind": "port",
                          "sample": "nq=128 vs 100k x 768 fp32 documents, cos_sim + top-k + per-query heap merge "
-                                   "(oracle.exact_search = exact_search.py:96-132), median of 3"}
+                                   "(oracle.exact_search(backend='torch') = exact_search.py:96-132 restated on the torch CPU "
+                                   "primitives the reference calls; the reference's file is Python under /root/reference and cannot "
+                                   "travel to the GPU box: scripts/cpu_search_ref_vs_port.py times the reference's own "
+                                   "DenseRetrievalExactSearch beside this port on the same inputs in the build container -> "
+                                   "profiles/r03_cpu_search_ref_vs_port.txt), median of 3",
+                         "cores": torch.get_num_threads()}
         cpu["gpu_vs_cpu_max_abs_emb_diff"] = parity["gpu_vs_oracle_max_abs_emb_diff"]
         cpu["parity"] = parity
+        cpu["cpu"] = cpu_info()
 
     out = {"metric": "encoded sentences/sec (SGPT-125M, seq_len 128, encode + weighted-mean pool + cosine top-10 "
                      "chunk loop)",
@@ -497,11 +572,16 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": ("BASELINE configs[1]: SGPT-125M" if args.model == "125m" else f"SGPT-{args.model.upper()}") +
-                                  "-shape random-init weights, " + args.dtype + " MFMA, "
+                                  "-shape random-init weights, " + args.dtype + " MFMA" +
+                                  (" (DEVIATION from configs[1]'s bf16: IEEE-half operands -- same width and MFMA rate class, 3 more "
+                                   "mantissa bits, the mode that meets the 1e-3 parity bar; --dtype bf16 times bf16)" if args.dtype == "f16" else "") + ", "
                                   f"{args.steps * args.chunk} docs/GPU x seq_len {S}, nq={args.nq}, cosine top-{args.topk} "
                                   f"(top_k+1 kept), corpus rows {'fp32' if args.dtype == 'fp32' else ('f16' if args.dtype == 'f16' else 'bf16')} in HBM",
                       "docs_per_step": args.chunk, "docs_per_encode_call": args.call, "seq_len": S, "nq": args.nq,
                       "top_k": args.topk, "parallelism": f"corpus-shard x{world}"},
+           "value_incl_host_pack_and_h2d": round(sent_per_s_host, 1),
+           "host_leg": f"{host_steps} of the same steps with every call's ids packed from host memory and copied over PCIe inside "
+                       "the clock (pinned double arena, async H2D overlapping the previous call's encode)",
            "queries_per_sec_at_job_corpus": round(qps_job, 1),
            "job_corpus_docs_per_gpu": args.steps * args.chunk,
            "queries_per_sec_at_1M_corpus": None if qps_1m is None else round(qps_1m, 1),

@@ -147,7 +147,7 @@ class DenseRetrievalExactSearch:
     query, the (k+1) best of {per-chunk top-(k+1) minus corpus_id == query_id} (:102-132)."""
 
     def __init__(self, model, batch_size: int = 128, corpus_chunk_size: int = 50000, score_dtype=torch.float32,
-                 prefetch_tokenize: bool = True, **kwargs):
+                 prefetch_tokenize: bool = True, ctx=None, group=None, distributed: Optional[bool] = None, **kwargs):
         self.model = model
         self.prefetch_tokenize = prefetch_tokenize
         self.batch_size = batch_size
@@ -156,43 +156,81 @@ class DenseRetrievalExactSearch:
         self.show_progress_bar = True
         self.convert_to_tensor = True
         self.score_dtype = score_dtype          # torch.float32: exact-fp32 MFMA; torch.float16 / bfloat16: 16-bit corpus in HBM
+        self.ctx = ctx                          # device context (default: the model's GPU)
+        self.group = group                      # torch.distributed process group of a multi-GPU search (default: WORLD)
+        self.distributed = distributed          # None: sharded search iff the group has more than one rank; True: whenever a
+                                                # group is initialised (a world of one runs the same collectives: tests)
         self.results = {}
+        self.last_shard = None                  # (rank, world, first document, one-past-last document) of the last search
 
     def _to_dev(self, ctx, x):
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.asarray(x))
         return x.to(device=ctx.device, dtype=torch.float32)
 
-    def search(self, corpus: Dict[str, Dict[str, str]], queries: Dict[str, str], top_k: int, score_function: str,
-               return_sorted: bool = False, **kwargs) -> Dict[str, Dict[str, float]]:
-        if score_function not in self.score_function_desc:
-            raise ValueError(
-                "score function: {} must be either (cos_sim) for cosine similarity or (dot) for dot product".format(
-                    score_function))
-        ctx = get_context(getattr(getattr(self.model, "model", None), "device", None))
-        logger.info("Encoding Queries...")
-        query_ids = list(queries.keys())
-        self.results = {qid: {} for qid in query_ids}
-        qlist = [(qid, queries[qid]) for qid in queries]
+    def _encode_queries(self, ctx, qlist):
+        if not qlist:
+            return None
         if hasattr(self.model, "encode_queries_device"):
             q_emb = self.model.encode_queries_device(qlist)
         else:
             q_emb = self.model.encode_queries(qlist, batch_size=self.batch_size,
                                               show_progress_bar=self.show_progress_bar,
                                               convert_to_tensor=self.convert_to_tensor)
-        q_emb = self._to_dev(ctx, q_emb)
+        return self._to_dev(ctx, q_emb)
+
+    def search(self, corpus: Dict[str, Dict[str, str]], queries: Dict[str, str], top_k: int, score_function: str,
+               return_sorted: bool = False, **kwargs) -> Dict[str, Dict[str, float]]:
+        """Single process: the reference's loop (exact_search.py:34-134) with scoring / top-k / merge on the GPU.
+
+        Under an initialised torch.distributed group of N > 1 ranks (one process per GPU, `torchrun ... beir_dense_retriever`)
+        the SAME call is the corpus-sharded search of SURVEY 8e: every rank takes one contiguous range of the
+        length-sorted corpus (cuts balanced on document length, dist.balanced_cuts -- equal counts would hand rank 0 the
+        longest documents), tokenises, encodes and scores only that range (its embeddings never leave its HBM); the
+        queries are encoded sharded and all-gathered once over RCCL; the per-rank top-(k+1) lists are exchanged and merged
+        on the device (C ABI: sgpt_allgather_rows, sgpt_exchange_topk).  Every rank returns the same, complete dict --
+        equal to the single-process result (the encoder is batch-invariant bit for bit, ties go to the lower index)."""
+        if score_function not in self.score_function_desc:
+            raise ValueError(
+                "score function: {} must be either (cos_sim) for cosine similarity or (dot) for dot product".format(
+                    score_function))
+        from .dist import balanced_cuts, get_comm, is_distributed
+        ctx = self.ctx if self.ctx is not None else get_context(getattr(getattr(self.model, "model", None), "device", None))
+        import torch.distributed as tdist
+        sharded = is_distributed(self.group) if self.distributed is None else (
+            bool(self.distributed) and tdist.is_available() and tdist.is_initialized())
+        comm = get_comm(ctx, self.group) if sharded else None
+        world, rank = (comm.world, comm.rank) if comm is not None else (1, 0)
+
+        logger.info("Encoding Queries...")
+        query_ids = list(queries.keys())
+        nq = len(query_ids)
+        self.results = {qid: {} for qid in query_ids}
+        qlist = [(qid, queries[qid]) for qid in queries]
+        if comm is not None and (nq >= 4 * world or world == 1):
+            # this rank's contiguous slice of the queries (cuts balanced on text length), then ONE all-gather
+            qcuts = balanced_cuts([len(q[1]) + 1 for q in qlist], world)
+            q_loc = self._encode_queries(ctx, qlist[qcuts[rank]: qcuts[rank + 1]])
+            q_emb = comm.all_gather_rows(q_loc, np.diff(qcuts).tolist())
+        else:
+            q_emb = self._encode_queries(ctx, qlist)       # (fewer queries than a handful per rank: every rank encodes them)
         if score_function == "cos_sim":
             q_emb = ctx.l2_normalize(q_emb)                                       # util.py:41 (once, not per chunk)
 
         logger.info("Sorting Corpus by document length (Longest first)...")
-        corpus_ids = sorted(corpus, key=lambda k: len(corpus[k].get("title", "") + corpus[k].get("text", "")),
-                            reverse=True)                                         # :66-70
-        clist = [(cid, corpus[cid]) for cid in corpus_ids]
+        doc_len = {k: len(corpus[k].get("title", "") + corpus[k].get("text", "")) for k in corpus}
+        corpus_ids = sorted(corpus, key=doc_len.__getitem__, reverse=True)        # :66-70
         pos_of = {cid: i for i, cid in enumerate(corpus_ids)}
         # corpus_id != query_id (:118) as an index: position of the doc carrying the query's id, or -1
         self_idx = torch.tensor([pos_of.get(qid, -1) for qid in query_ids], dtype=torch.int64, device=ctx.device)
+        if comm is not None:
+            ccuts = balanced_cuts([doc_len[c] + 1 for c in corpus_ids], world)
+            lo, hi = int(ccuts[rank]), int(ccuts[rank + 1])
+        else:
+            lo, hi = 0, len(corpus_ids)
+        self.last_shard = (rank, world, lo, hi)
+        clist = [(cid, corpus[cid]) for cid in corpus_ids[lo:hi]]                # this rank's documents only
 
-        nq = len(query_ids)
         run_val = run_idx = None
         itr = range(0, len(clist), self.corpus_chunk_size)
         # The host leg (tokenise + truncate + brackets) of chunk i+1 runs on a worker thread while the GPU encodes and
@@ -200,39 +238,55 @@ class DenseRetrievalExactSearch:
         ahead = self.prefetch_tokenize and hasattr(self.model, "tokenize_corpus")
         pool = ThreadPoolExecutor(max_workers=1) if ahead else None
         fut = None
+        # embedding-cache files are per chunk of the WHOLE sorted corpus in the reference; a sharded search numbers its
+        # chunks per rank, so the cache names carry the rank
+        tag = (lambda b: b) if comm is None else (lambda b: f"_r{rank}of{world}_{b}")
 
         def tokens_for(batch_num, start):
-            if not ahead or self.model.uses_embedding_cache(batch_num) or start >= len(clist):
+            if not ahead or self.model.uses_embedding_cache(tag(batch_num)) or start >= len(clist):
                 return None
             return pool.submit(self.model.tokenize_corpus, clist[start: start + self.corpus_chunk_size])
-        fut = tokens_for(0, 0)
-        for batch_num, start in enumerate(itr):
-            logger.info("Encoding Batch {}/{}...".format(batch_num + 1, len(itr)))
-            end = min(start + self.corpus_chunk_size, len(clist))
-            if ahead:
-                seqs = fut.result() if fut is not None else None
-                fut = tokens_for(batch_num + 1, end)
-                sub = self.model.encode_corpus_device(clist[start:end], batch_num=batch_num, seqs=seqs)
-            elif hasattr(self.model, "encode_corpus_device"):
-                sub = self.model.encode_corpus_device(clist[start:end], batch_num=batch_num)
-            else:
-                sub = self.model.encode_corpus(clist[start:end], batch_size=self.batch_size,
-                                               show_progress_bar=self.show_progress_bar,
-                                               convert_to_tensor=self.convert_to_tensor, batch_num=batch_num)
-            sub = self._to_dev(ctx, sub)
-            if score_function == "cos_sim":
-                sub = ctx.l2_normalize(sub, out_dtype=self.score_dtype)           # util.py:42
-            kk = min(top_k + 1, end - start)                                      # :104
-            val, idx, _ = ctx.score_topk(q_emb, sub, kk, idx_base=start, dtype=self.score_dtype)   # :96-108 (NaN -> -1)
-            if run_val is None:
-                cand_v, cand_i = val, idx
-            else:
-                cand_v, cand_i = torch.cat([run_val, val], dim=1), torch.cat([run_idx, idx], dim=1)
-            keep = min(top_k + 1, cand_v.shape[1])                                # :126
-            run_val, run_idx = ctx.topk_merge(cand_v, cand_i, keep, exclude_idx=self_idx)          # :118,121-132
+        try:
+            fut = tokens_for(0, 0)
+            for batch_num, start in enumerate(itr):
+                logger.info("Encoding Batch {}/{}...".format(batch_num + 1, len(itr)))
+                end = min(start + self.corpus_chunk_size, len(clist))
+                if ahead:
+                    seqs = fut.result() if fut is not None else None
+                    fut = tokens_for(batch_num + 1, end)
+                    sub = self.model.encode_corpus_device(clist[start:end], batch_num=tag(batch_num), seqs=seqs)
+                elif hasattr(self.model, "encode_corpus_device"):
+                    sub = self.model.encode_corpus_device(clist[start:end], batch_num=tag(batch_num))
+                else:
+                    sub = self.model.encode_corpus(clist[start:end], batch_size=self.batch_size,
+                                                   show_progress_bar=self.show_progress_bar,
+                                                   convert_to_tensor=self.convert_to_tensor, batch_num=tag(batch_num))
+                sub = self._to_dev(ctx, sub)
+                if score_function == "cos_sim":
+                    sub = ctx.l2_normalize(sub, out_dtype=self.score_dtype)           # util.py:42
+                kk = min(top_k + 1, end - start)                                      # :104
+                val, idx, _ = ctx.score_topk(q_emb, sub, kk, idx_base=lo + start, dtype=self.score_dtype)   # :96-108 (NaN -> -1)
+                if run_val is None:
+                    cand_v, cand_i = val, idx
+                else:
+                    cand_v, cand_i = torch.cat([run_val, val], dim=1), torch.cat([run_idx, idx], dim=1)
+                keep = min(top_k + 1, cand_v.shape[1])                                # :126
+                run_val, run_idx = ctx.topk_merge(cand_v, cand_i, keep, exclude_idx=self_idx)          # :118,121-132
+        finally:
+            if pool is not None:      # an exception in encode / score must not leave the worker (and its tokenizer) running
+                if fut is not None:
+                    fut.cancel()
+                pool.shutdown(wait=True)
 
-        if pool is not None:
-            pool.shutdown(wait=True)
+        if comm is not None:
+            # exchange: every rank's top-(k+1) list (padded with (-inf, -1); an empty range contributes only padding)
+            k1 = top_k + 1
+            pv = torch.full((nq, k1), float("-inf"), dtype=torch.float32, device=ctx.device)
+            pi = torch.full((nq, k1), -1, dtype=torch.int64, device=ctx.device)
+            if run_val is not None:
+                pv[:, : run_val.shape[1]] = run_val
+                pi[:, : run_idx.shape[1]] = run_idx
+            run_val, run_idx = comm.exchange_topk(pv, pi, min(k1, len(corpus_ids)), exclude_idx=self_idx)
         if run_val is not None:
             vals, idxs = run_val.cpu().numpy(), run_idx.cpu().numpy()
             for qi, qid in enumerate(query_ids):

@@ -1,34 +1,17 @@
 """SentenceTransformer-style surface (sentence_transformers/SentenceTransformer.py:107-255) over
 the HIP encoder: `encode(sentences, batch_size, ..., normalize_embeddings)` with the reference's
-return-type rules, plus its torch.distributed data-parallel branch (:153-175) re-done with ONE
-equal-size RCCL all-gather instead of the two-step pad-to-max gather of
-util.mismatched_sizes_all_gather (util.py:326-347)."""
+return-type rules, plus its torch.distributed data-parallel branch (:153-175) re-done with
+token-balanced shards and ONE RCCL all-gather (C ABI: sgpt_allgather_rows) instead of the two-step
+pad-to-max gather of util.mismatched_sizes_all_gather (util.py:326-347)."""
 from typing import List, Optional, Union
 
 import numpy as np
 import torch
 
-from .model import SGPTModel
-from .runtime import get_context
+from .dist import balanced_cuts, get_comm, is_distributed, shard_sizes  # noqa: F401  (shard_sizes: re-exported)
+from .model import ALIGN, SGPTModel
+from .runtime import get_context  # noqa: F401
 from .tokenization import TextPipeline
-
-
-def shard_sizes(n: int, world_size: int) -> List[int]:
-    """Contiguous shard sizes of SentenceTransformer.encode (:159-160)."""
-    return [n // world_size + (1 if r < n % world_size else 0) for r in range(world_size)]
-
-
-def all_gather_rows(local: torch.Tensor, sizes: List[int], group=None) -> torch.Tensor:
-    """All-gather of per-rank row blocks with known sizes: pad to max(sizes) (the sizes are a pure
-    function of (n, world) so no size exchange is needed), one all_gather_into_tensor, trim."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    mx = max(sizes)
-    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
 
 
 class SentenceTransformerSGPT:
@@ -84,8 +67,7 @@ class SentenceTransformerSGPT:
         if output_value != "sentence_embedding":
             raise ValueError("output_value must be 'sentence_embedding' or 'token_embeddings'")
 
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if is_distributed():
             emb = self.encode_ids_distributed(seqs, normalize_embeddings)
         else:
             emb = self.model.encode_ids(seqs, mode=self.pooling_mode, normalize=normalize_embeddings)
@@ -102,21 +84,25 @@ class SentenceTransformerSGPT:
     def encode_ids_distributed(self, seqs, normalize_embeddings: bool = False, group=None) -> torch.Tensor:
         """The torch.distributed data-parallel branch of SentenceTransformer.encode (:153-175): every rank sorts the
         SAME list by length (longest first, :148-149 -- appendix A.10: the un-sort below relies on all ranks agreeing
-        on this order, so the sort is stable and keyed on the token count only), encodes its contiguous shard of the
-        sorted list (:159-163), ONE equal-size all-gather puts the shards back together in sorted order, and the
-        inverse permutation restores the input order (:205).  Every rank returns the full [n, d] matrix."""
-        import torch.distributed as dist
-        world, r = dist.get_world_size(group), dist.get_rank(group)
-        order = np.argsort(np.fromiter((-len(s) for s in seqs), dtype=np.int64, count=len(seqs)), kind="stable")
-        sizes = shard_sizes(len(seqs), world)
-        lim = np.cumsum([0] + sizes)
-        mine = [seqs[i] for i in order[lim[r]: lim[r + 1]]]
+        on this order, so the sort is stable and keyed on the token count only) and encodes one CONTIGUOUS shard of the
+        sorted list.  The reference cuts equal sentence counts (:159-163), which gives rank 0 the longest sentences
+        (U{16..128} tokens, 8 ranks: 1.7x the mean token load); here the cuts balance the token rows each rank packs
+        (dist.balanced_cuts: max / mean <= 1 + one sentence).  ONE all-gather (every rank knows every count) puts the
+        shards back together in sorted order, and the inverse permutation restores the input order (:205).  Every rank
+        returns the full [n, d] matrix."""
+        ctx = getattr(self.model, "ctx", None)
+        comm = get_comm(ctx, group)
+        lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+        order = np.argsort(-lens, kind="stable")
+        cuts = balanced_cuts((lens[order] + ALIGN - 1) // ALIGN * ALIGN, comm.world)
+        counts = np.diff(cuts).tolist()
+        mine = [seqs[i] for i in order[cuts[comm.rank]: cuts[comm.rank + 1]]]
         d = self.get_sentence_embedding_dimension()
         if mine:
             local = self.model.encode_ids(mine, mode=self.pooling_mode, normalize=normalize_embeddings)
         else:                                                     # more ranks than sentences
             local = torch.empty((0, d), dtype=torch.float32, device=getattr(self.model, "device", "cpu"))
-        gathered = all_gather_rows(local, sizes, group)
+        gathered = comm.all_gather_rows(local, counts)
         emb = torch.empty_like(gathered)
         emb[torch.from_numpy(order).to(gathered.device)] = gathered              # un-sort (:205)
         return emb

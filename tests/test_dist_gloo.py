@@ -24,10 +24,16 @@ def _free_port():
 
 
 class StubCtx:
-    """numpy stand-in for sgpt_amd.runtime.Context with the two calls sharded_score_topk makes."""
+    """numpy stand-in for sgpt_amd.runtime.Context with the calls the sharded search makes (no HIP device here).  Not a
+    `Context`, so sgpt_amd.dist.get_comm gives it the gloo transport (`TorchComm`); a real Context always gets RCCL."""
+    device = torch.device("cpu")
+
+    def l2_normalize(self, x, out_dtype=torch.float32):
+        return torch.from_numpy(O.normalize(np.asarray(x, dtype=np.float32)))
 
     def score_topk(self, q, corpus, k, idx_base=0, run=None, dtype=None):
-        sc = O.cos_sim(q.numpy(), corpus.numpy())
+        sc = O.dot_score(q.numpy(), corpus.numpy())        # rows are normalised by the caller for cos_sim (util.py:41-43)
+        sc[np.isnan(sc)] = -1
         v, i = O.topk_rows(sc, k)
         return torch.from_numpy(v), torch.from_numpy(i + idx_base), k
 
@@ -36,13 +42,17 @@ class StubCtx:
         if exclude_idx is not None:
             v[i == exclude_idx.numpy()[:, None]] = -np.inf
         # descending score, ties -> ascending index (the contract of sgpt_topk_merge)
+        v[i < 0] = -np.inf                                    # idx < 0: not a candidate
         order = np.lexsort((i, -v), axis=1)[:, :k]
-        return torch.from_numpy(np.take_along_axis(v, order, 1)), torch.from_numpy(np.take_along_axis(i, order, 1))
+        ov, oi = np.take_along_axis(v, order, 1), np.take_along_axis(i, order, 1).copy()
+        oi[np.isneginf(ov)] = -1                              # ignored / excluded candidates leave as (-inf, -1)
+        return torch.from_numpy(ov), torch.from_numpy(oi)
 
 
 class FakeEncoder:
     """Deterministic stand-in for SGPTModel: the embedding of a sentence depends only on its ids."""
     device = "cpu"
+    ctx = StubCtx()
 
     class cfg:
         hidden_size = 8
@@ -81,28 +91,31 @@ def _init(rank, world, port):
 def _search_worker(rank, world, port, out, nq, N, d, k):
     _init(rank, world, port)
     try:
-        from sgpt_amd.dist import all_gather_queries, exchange_topk, shard_range, sharded_score_topk
+        from sgpt_amd.dist import all_gather_queries, exchange_topk, shard_range, shard_sizes, sharded_score_topk
         rng = np.random.default_rng(0)                      # same data on both ranks
         q = rng.standard_normal((nq, d)).astype(np.float32)
         c = rng.standard_normal((N, d)).astype(np.float32)
         c[7] = c[3]                                         # a duplicated document: tie -> the lower index wins
         qlo, qhi = shard_range(nq, rank, world)
         clo, chi = shard_range(N, rank, world)
-        q_all = all_gather_queries(torch.from_numpy(q[qlo:qhi]), nq)
+        ctx = StubCtx()
+        q_all = all_gather_queries(ctx, torch.from_numpy(q[qlo:qhi]), shard_sizes(nq, world))
         ok = torch.equal(q_all, torch.from_numpy(q))
+        qn, cn = O.normalize(q), O.normalize(c)             # sharded_score_topk takes normalised rows (cos_sim = dot of those)
         # the product's sharded search, end to end, with the self-match rule on two queries
         excl = np.full(nq, -1, dtype=np.int64)
         excl[2], excl[5] = 11, N - 1
-        fv, fi = sharded_score_topk(StubCtx(), torch.from_numpy(q[qlo:qhi]), nq, torch.from_numpy(c[clo:chi]), k,
+        fv, fi = sharded_score_topk(ctx, torch.from_numpy(qn[qlo:qhi]), nq, torch.from_numpy(cn[clo:chi]), k,
                                     idx_base=clo, exclude_idx=torch.from_numpy(excl))
         sc = O.cos_sim(q, c)
         sc[np.arange(nq), excl] = np.where(excl >= 0, -np.inf, sc[np.arange(nq), excl])
         wv, wi = O.topk_rows(sc, k)
         ok = ok and np.array_equal(fi.numpy(), wi) and np.allclose(fv.numpy(), wv, atol=1e-6)
-        # the exchange alone: [nq, world*k], rank-major inside a row
+        # the exchange alone (all-gather of the per-rank lists + merge): the global top-k without the exclusion
         v, i = O.topk_rows(O.cos_sim(q, c[clo:chi]), k)
-        cv, ci = exchange_topk(torch.from_numpy(v), torch.from_numpy(i + clo))
-        ok = ok and cv.shape == (nq, world * k) and np.array_equal(ci[:, rank * k:(rank + 1) * k].numpy(), i + clo)
+        cv, ci = exchange_topk(ctx, torch.from_numpy(v), torch.from_numpy(i + clo), k)
+        gv, gi = O.topk_rows(O.cos_sim(q, c), k)
+        ok = ok and cv.shape == (nq, k) and np.array_equal(ci.numpy(), gi) and np.allclose(cv.numpy(), gv, atol=1e-6)
         out.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -146,3 +159,96 @@ def test_shard_range_partition():
         spans = [shard_range(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_balanced_cuts_bound_the_token_load():
+    """the contiguous cut of the length-sorted list balances TOKENS.  U{16..128} lengths, 8 ranks:
+    equal sentence counts (the reference's rule, SentenceTransformer.py:159-163) give rank 0 ~1.7x the mean load; the
+    balanced cut keeps max / mean <= 1.05 (here: within one sentence of the ideal)."""
+    from sgpt_amd.dist import balanced_cuts, shard_sizes
+    rng = np.random.default_rng(0)
+    for n, world in [(100_000, 8), (4096, 8), (1000, 2), (4096, 3)]:
+        lens = np.sort(rng.integers(16, 129, size=n))[::-1]                 # longest first
+        alloc = (lens + 7) // 8 * 8
+        cuts = balanced_cuts(alloc, world)
+        assert cuts[0] == 0 and cuts[-1] == n and (np.diff(cuts) >= 0).all()
+        load = np.array([alloc[cuts[r]: cuts[r + 1]].sum() for r in range(world)], dtype=np.float64)
+        assert load.max() / load.mean() <= 1.05, (n, world, load)
+        assert load.max() - load.mean() <= alloc.max()                       # within one sentence of the ideal cut
+        lim = np.cumsum([0] + shard_sizes(n, world))
+        eq = np.array([alloc[lim[r]: lim[r + 1]].sum() for r in range(world)], dtype=np.float64)
+        if world == 8:
+            assert eq.max() / eq.mean() > 1.5                                 # what the equal-count rule would have done
+    # degenerate inputs: fewer items than ranks, empty list, one giant item
+    assert balanced_cuts([5], 4).tolist()[-1] == 1 and (np.diff(balanced_cuts([5], 4)) >= 0).all()
+    assert balanced_cuts([], 3).tolist() == [0, 0, 0, 0]
+    c = balanced_cuts([1000, 1, 1, 1], 2)
+    assert c.tolist() == [0, 1, 4]
+
+
+class TextModel:
+    """Generic BEIR-style model for the text API (encode_queries / encode_corpus on (id, text) tuples): embeddings depend
+    only on the text, so a sharded and a single-process search must agree exactly."""
+
+    @staticmethod
+    def _emb(text):
+        a = np.frombuffer(text.encode(), dtype=np.uint8).astype(np.float64)
+        return np.array([np.sin(0.11 * j * a.sum() + 0.7 * j) + 0.05 * len(a) * (j % 3) + np.cos(a[: 1 + j % max(1, len(a))].sum())
+                         for j in range(16)], dtype=np.float32)
+
+    def encode_queries(self, queries, batch_size=None, **kw):
+        return torch.from_numpy(np.stack([self._emb(t) for _, t in queries]))
+
+    def encode_corpus(self, corpus, batch_size=None, **kw):
+        return torch.from_numpy(np.stack([self._emb((d.get("title", "") + " " + d["text"]).strip()) for _, d in corpus]))
+
+
+def _text_data(n_docs, n_queries):
+    rng = np.random.default_rng(5)
+    words = ["alpha", "beta", "gamma", "delta", "eps", "zeta", "eta", "theta", "iota", "kappa"]
+    corpus = {f"d{i}": {"title": " ".join(rng.choice(words, size=int(rng.integers(0, 3)))),
+                        "text": " ".join(rng.choice(words, size=int(rng.integers(1, 40))))} for i in range(n_docs)}
+    queries = {f"q{i}": " ".join(rng.choice(words, size=int(rng.integers(1, 8)))) for i in range(n_queries)}
+    # query ids that collide with corpus ids: the corpus_id != query_id rule (exact_search.py:118) across shards
+    queries["d3"] = "alpha beta"
+    queries[f"d{n_docs - 1}"] = "kappa"
+    return corpus, queries
+
+
+def _text_search_worker(rank, world, port, out, n_docs, n_queries, chunk, top_k, fn):
+    _init(rank, world, port)
+    try:
+        from sgpt_amd.beir import DenseRetrievalExactSearch
+        corpus, queries = _text_data(n_docs, n_queries)
+        dres = DenseRetrievalExactSearch(TextModel(), corpus_chunk_size=chunk, ctx=StubCtx())
+        got = dres.search(corpus, queries, top_k, fn)                         # distributed branch (world 2)
+        out.put((rank, got, dres.last_shard))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("n_docs,n_queries,chunk,fn", [(137, 21, 50, "cos_sim"), (137, 21, 50, "dot"), (1, 9, 50, "cos_sim")])
+def test_two_rank_text_search_equals_single_process(n_docs, n_queries, chunk, fn):
+    """DenseRetrievalExactSearch.search under torch.distributed: token-balanced contiguous corpus
+    ranges, sharded query encode + one all-gather, local top-(k+1) with global indices, exchange + merge -- the dict every
+    rank returns equals the single-process dict (ids and scores), including the corpus_id == query_id rule and a rank with
+    an empty range (n_docs = 1)."""
+    from sgpt_amd.beir import DenseRetrievalExactSearch
+    top_k = 5
+    corpus, queries = _text_data(n_docs, n_queries)
+    single = DenseRetrievalExactSearch(TextModel(), corpus_chunk_size=chunk, ctx=StubCtx()).search(corpus, queries, top_k, fn)
+    res = _run(_text_search_worker, 2, n_docs, n_queries, chunk, top_k, fn)
+    ranges = []
+    for rank, got, shard in res:
+        assert shard[0] == rank and shard[1] == 2
+        ranges.append(shard[2:])
+        assert set(got) == set(single)
+        for qid in single:
+            assert set(got[qid]) == set(single[qid]), (rank, qid)
+            assert qid not in got[qid]                                          # the self-match never comes back
+            for cid, sc in single[qid].items():
+                assert abs(got[qid][cid] - sc) <= 1e-6, (rank, qid, cid)
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == n_docs       # a partition of the corpus
+    if n_docs == 1:
+        assert ranges[0][1] - ranges[0][0] == 0 or ranges[1][1] - ranges[1][0] == 0          # one rank had nothing to score

@@ -1,7 +1,9 @@
-"""-m gpu: the multi-GPU code paths on the real "nccl" backend (= RCCL on ROCm).  One GPU is enough to prove that RCCL
-loads, that all_gather_into_tensor runs on device tensors and that the product's sharding code (sgpt_amd.dist,
-SentenceTransformerSGPT.encode_ids_distributed) gives the single-process result: the process group has world_size 1,
-so every collective degenerates to a copy through RCCL.  The same functions run with world_size 2 on gloo in
+"""-m gpu: the multi-GPU code paths on RCCL through the C ABI (sgpt_comm_init / sgpt_allgather_rows / sgpt_exchange_topk,
+sgpt_amd/csrc/comm.hip).  One GPU is enough to prove that librccl loads into the process next to torch's, that the
+communicator comes up from a unique id bootstrapped over torch.distributed, that the collectives run on device tensors
+on the caller's stream, and that the product's sharding code (sgpt_amd.dist, SentenceTransformerSGPT.encode_ids_distributed,
+DenseRetrievalExactSearch.search) gives the single-process result: the process group has world_size 1, so every
+collective degenerates to a copy through RCCL.  The same functions run with world_size 2 on gloo in
 tests/test_dist_gloo.py; bench.py --gpus N is the N-rank run."""
 import os
 import socket
@@ -34,15 +36,19 @@ def nccl_group():
 
 def test_rccl_sharded_search_equals_local_search(nccl_group):
     from sgpt_amd import get_context
-    from sgpt_amd.dist import all_gather_queries, exchange_topk, sharded_score_topk
+    from sgpt_amd.dist import RcclComm, all_gather_queries, exchange_topk, get_comm, sharded_score_topk
     ctx = get_context("cuda:0")
+    comm = get_comm(ctx)
+    assert isinstance(comm, RcclComm) and ctx.lib.sgpt_comm_world(ctx.handle) == 1 and ctx.lib.sgpt_comm_rank(ctx.handle) == 0
     g = torch.Generator(device="cpu").manual_seed(3)
     nq, N, d, k = 100, 20_000, 768, 11
     q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).cuda()
     c = torch.nn.functional.normalize(torch.randn(N, d, generator=g), dim=1).cuda().to(torch.float16)
     assert nccl_group.get_backend() == "nccl"
-    q_all = all_gather_queries(q, nq)                                  # RCCL all_gather_into_tensor
-    assert torch.equal(q_all, q)
+    q_all = all_gather_queries(ctx, q, [nq])                           # ncclAllGather through sgpt_allgather_rows
+    assert torch.equal(q_all, q) and q_all.data_ptr() != q.data_ptr()
+    i64 = torch.arange(7 * 3, dtype=torch.int64, device="cuda").reshape(7, 3)
+    assert torch.equal(comm.all_gather_rows(i64, [7]), i64)           # any row type: bytes
     excl = torch.full((nq,), -1, dtype=torch.int64)
     excl[4] = 777 + 12
     fv, fi = sharded_score_topk(ctx, q, nq, c, k, idx_base=777, exclude_idx=excl, dtype=torch.float16)
@@ -50,8 +56,12 @@ def test_rccl_sharded_search_equals_local_search(nccl_group):
     mv, mi = ctx.topk_merge(wv, wi, k, exclude_idx=excl)
     assert torch.equal(fi, mi) and torch.equal(fv, mv)
     assert (fi[4] != 789).all()
-    cv, ci = exchange_topk(wv, wi)
+    cv, ci = exchange_topk(ctx, wv, wi)                               # gather + merge, no exclusion: the list itself
     assert torch.equal(cv, wv) and torch.equal(ci, wi)
+    cv, ci = exchange_topk(ctx, wv, wi, k_out=5, exclude_idx=excl)    # fewer columns out, exclusion in the merge
+    assert torch.equal(cv, mv[:, :5]) and torch.equal(ci, mi[:, :5])
+    with pytest.raises(ValueError):
+        comm.all_gather_rows(q[:3], [nq])                             # the shard plan and the local rows disagree
 
 
 def test_rccl_distributed_encode_equals_local_encode(nccl_group):
@@ -70,6 +80,31 @@ def test_rccl_distributed_encode_equals_local_encode(nccl_group):
     assert got.is_cuda and got.shape == want.shape and float((got - want).abs().max()) < 1e-6
     ref = O.encode(O.synth_weights(O.NeoConfig(**kw), seed=11, std=0.08), O.NeoConfig(**kw), seqs, normalize_embeddings=True)
     assert np.abs(got.cpu().numpy() - ref).max() < 5e-3
+
+
+def test_rccl_text_search_sharded_branch_equals_plain_search(nccl_group):
+    """DenseRetrievalExactSearch.search with the sharded branch forced on (a world of one runs the same collectives):
+    balanced corpus range, query all-gather, local top-(k+1) with global indices, sgpt_exchange_topk -- same dict as the
+    plain single-process search, on the real encoder through the text API."""
+    from helpers import build_model
+    from sgpt_amd.beir import CustomEmbedder, DenseRetrievalExactSearch
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    kw = dict(vocab_size=211, max_position_embeddings=96, hidden_size=128, num_layers=4, num_heads=2, window_size=8)
+    m = build_model(kw, 11, 0.08, "f16")
+    emb = CustomEmbedder(model_name="synthetic/tiny", model=m, tokenizer=SyntheticTokenizer(211), method="weightedmean",
+                         specb=True, maxseqlen=64)
+    rng = np.random.default_rng(4)
+    words = ["alpha", "beta", "gamma", "delta", "eps", "zeta", "eta", "theta"]
+    corpus = {f"d{i}": {"title": "t", "text": " ".join(rng.choice(words, size=int(rng.integers(1, 50))))} for i in range(300)}
+    queries = {f"q{i}": " ".join(rng.choice(words, size=int(rng.integers(1, 9)))) for i in range(13)}
+    queries["d7"] = "alpha beta gamma"
+    plain = DenseRetrievalExactSearch(emb, corpus_chunk_size=128).search(corpus, queries, 10, "cos_sim")
+    dres = DenseRetrievalExactSearch(emb, corpus_chunk_size=128, distributed=True)
+    got = dres.search(corpus, queries, 10, "cos_sim")
+    assert dres.last_shard == (0, 1, 0, 300)
+    assert set(got) == set(plain) and "d7" not in got["d7"]
+    for qid in plain:
+        assert got[qid] == plain[qid], qid
 
 
 def _run_bench(args, env_extra, timeout=600):
