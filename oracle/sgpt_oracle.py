@@ -434,6 +434,29 @@ def synth_weights_streams(cfg, seed: int = 0, std: float = 0.02, threads: Option
         return dict(ex.map(gen, enumerate(spec)))
 
 
+def engineer_outliers(w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """In place: outlier structure of the kind real GPT-Neo / GPT-2 checkpoints carry, on seeded GPT-Neo weights
+    (12+ layers, d >= 768) -- the 16-bit paths must survive it inside the parity bar:
+      * two embedding channels x 100 (outlier feature dimensions from the first layer on);
+      * block 2: two output channels of mlp.c_proj x 300 (weights and bias): "massive activations" of a few hundred in
+        the residual stream against a typical magnitude of ~1, carried through all later LayerNorms;
+      * blocks 1 and 6: two hidden units of mlp.c_fc x 100 (GELU outputs ~100 against ~0.3);
+      * block 5: ln_1 gamma x 10 on the massive channels;
+      * block 3: two hidden units of mlp.c_fc x 1e5 whose GELU output (~1e5) is beyond the IEEE-half range (65504), read
+        by mlp.c_proj through columns x 0.01 -- the case the f16 range shifts exist for.
+    Deterministic; tests/golden/make_golden_large.py applies it before the HF run, the GPU test before loading."""
+    w["wte.weight"][:, [7, 300]] *= F32(100.0)
+    w["h.2.mlp.c_proj.weight"][[138, 447], :] *= F32(300.0)
+    w["h.2.mlp.c_proj.bias"][[138, 447]] *= F32(300.0)
+    for blk in (1, 6):
+        w[f"h.{blk}.mlp.c_fc.weight"][[11, 1234], :] *= F32(100.0)
+        w[f"h.{blk}.mlp.c_fc.bias"][[11, 1234]] *= F32(100.0)
+    w["h.5.ln_1.weight"][[138, 447]] *= F32(10.0)
+    w["h.3.mlp.c_fc.weight"][[5, 77], :] *= F32(1e5)
+    w["h.3.mlp.c_proj.weight"][:, [5, 77]] *= F32(0.01)
+    return w
+
+
 def alibi_slopes(n_head: int) -> np.ndarray:
     """build_alibi_tensor slopes (HF:bloom:62-79), float32."""
     import math

@@ -125,12 +125,14 @@ def flat(seqs):
     return np.concatenate([np.asarray(s, dtype=np.int32) for s in seqs]), np.asarray([len(s) for s in seqs], dtype=np.int32)
 
 
-def case(tag, arch, cfg_kw, seed, std, groups, Pooling, U, ES, topk=10):
+def case(tag, arch, cfg_kw, seed, std, groups, Pooling, U, ES, topk=10, outliers=False):
     """groups: list of (name, seqs, pad_side, batch, is_query).  Every group is encoded by the reference loop in its own
     batches; all document groups form the corpus, all query groups the queries."""
     t0 = time.time()
     cfg = {"gpt_neo": O.NeoConfig, "gptj": O.GPTJConfig, "bloom": O.BloomConfig}[arch](**cfg_kw)
     w = O.synth_weights_streams(cfg, seed=seed, std=std)
+    if outliers:
+        O.engineer_outliers(w)
     print(f"[{tag}] weights: {sum(v.size for v in w.values()) / 1e9:.2f} G parameters in {time.time() - t0:.0f} s", flush=True)
     model = hf_build(arch, cfg, w)
     pm = Pooling.Pooling(cfg.hidden_size, pooling_mode_weightedmean_tokens=True, pooling_mode_mean_tokens=False)
@@ -174,7 +176,7 @@ def case(tag, arch, cfg_kw, seed, std, groups, Pooling, U, ES, topk=10):
     assert worst < 2e-5, worst
     ids_flat, lens = flat(seqs_all)
     srt = -np.sort(-cos, axis=1)
-    meta = dict(tag=tag, arch=arch, cfg=cfg_kw, seed=seed, std=std, topk=topk, n_docs=int((isq == 0).sum()), n_queries=int(isq.sum()),
+    meta = dict(tag=tag, arch=arch, cfg=cfg_kw, seed=seed, std=std, topk=topk, outliers=bool(outliers), n_docs=int((isq == 0).sum()), n_queries=int(isq.sum()),
                 groups=[dict(name=g[0], pad_side=g[2], batch=g[3], is_query=bool(g[4]), n=len(g[1])) for g in groups],
                 oracle_vs_hf_rel=worst, emb_norm_range=[float(np.linalg.norm(emb, axis=1).min()), float(np.linalg.norm(emb, axis=1).max())],
                 cos_range=[float(cos.min()), float(cos.max())], min_gap_rank10_11=float((srt[:, topk - 1] - srt[:, topk]).min()))
@@ -187,7 +189,7 @@ def case(tag, arch, cfg_kw, seed, std, groups, Pooling, U, ES, topk=10):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"neo13b", "gptj6b", "bloom7b1"}
+    which = set(sys.argv[1:]) or {"neo13b", "gptj6b", "bloom7b1", "outlier125m"}
     torch.set_grad_enabled(False)
     torch.set_num_threads(os.cpu_count() or 1)
     Pooling = G.load_file_module("ref_pooling", f"{G.ST}/models/Pooling.py")
@@ -204,6 +206,16 @@ def main():
         qs = [O.specb_wrap(rng.integers(0, 50256, size=int(n)).tolist(), is_query=True) for n in rng.integers(4, 31, size=32)]
         case("cfg3_neo13b_specb", "gpt_neo", dict(O.SGPT_1_3B), seed=3, std=0.02,
              groups=[("docs", docs, "right", 8, False), ("queries", qs, "right", 16, True)], Pooling=Pooling, U=U, ES=ES)
+    if "outlier125m" in which:
+        # SGPT-125M shape with ENGINEERED OUTLIERS (oracle.engineer_outliers: a handful of embedding / fc /
+        # LayerNorm channels x 100...1000 as real GPT-Neo checkpoints have, plus two hidden units whose GELU output leaves the
+        # IEEE-half range): 256 documents x 128 tokens (the 256x256-tile kernels) + 32 queries
+        rng = np.random.default_rng(61)
+        docs = [rng.integers(0, 50256, size=128).tolist() for _ in range(256)]
+        qs = [rng.integers(0, 50256, size=int(n)).tolist() for n in rng.integers(4, 33, size=32)]
+        case("outlier_125m", "gpt_neo", dict(O.SGPT_125M), seed=6, std=0.02,
+             groups=[("docs", docs, "right", 32, False), ("queries", qs, "right", 32, True)], Pooling=Pooling, U=U, ES=ES,
+             outliers=True)
     if "gptj6b" in which:
         # configs[3]: SGPT-5.8B = GPT-J-6B shape (vocabulary shrunk), 96 documents x 128 tokens + 32 queries
         rng = np.random.default_rng(41)

@@ -5,6 +5,8 @@ tests/golden/cfg3_neo13b_specb.npz, cfg4_gptj6b.npz, cfg5_bloom7b1.npz hold what
 bloom-7b1 (30 layers, d 4096, 32 heads; left- and right-padded batches) shape: HF model fp32 eager -> the reference's
 Pooling.py (weightedmean) -> the reference's util.cos_sim -> the reference's DenseRetrievalExactSearch top-10
 (tests/golden/make_golden_large.py; the weights are regenerated here from the seed, one numpy stream per tensor).
+outlier_125m.npz: the same chain on SGPT-125M-shape weights with engineered outliers (a handful of embedding / fc / LayerNorm
+channels x 100...1000, two GELU outputs beyond the f16 range): the default mode encodes it inside the bar, no exception.
 
 Every case goes through the HIP path in ONE sgpt_encode call whose projections all run on the 256x256-tile throughput
 kernels (the launch shapes are checked), then through the 16-bit scorer.
@@ -29,6 +31,9 @@ BAR = 1e-3
 TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16, "fp8": torch.bfloat16, "fp8mfma": torch.bfloat16}
 # max |cos - cos_ref| allowed per case and operand format; f16 is the north_star bar, the others ~1.5 x measured (r03)
 BUDGET = {
+    # SGPT-125M shape with engineered outliers (oracle.engineer_outliers): the default f16 mode must encode
+    # it inside the bar -- two hidden units of block 3 leave the half range and get a power-of-two shift on the way
+    "outlier_125m": {"f16": BAR, "bf16": 6e-3},
     "cfg3_neo13b_specb": {"f16": BAR, "bf16": 6e-3},
     "cfg4_gptj6b": {"f16": BAR, "bf16": 6e-3, "fp8mfma": 8e-2},
     "cfg5_bloom7b1": {"f16": BAR, "bf16": 6e-3, "fp8": 8e-2, "fp8mfma": 8e-2},
@@ -46,6 +51,8 @@ def case_weights(tag, meta):
         cfg = {"gpt_neo": O.NeoConfig, "gptj": O.GPTJConfig, "bloom": O.BloomConfig}[arch](**meta["cfg"])
         t = time.time()
         _weights[tag] = O.synth_weights_streams(cfg, seed=meta["seed"], std=meta["std"])
+        if meta.get("outliers"):
+            O.engineer_outliers(_weights[tag])
         print(f"{tag}: {sum(v.size for v in _weights[tag].values()) / 1e9:.2f} G parameters regenerated in {time.time() - t:.0f} s")
     return _weights[tag]
 
@@ -122,5 +129,8 @@ def test_full_shape_cosine_and_ranked_top10_vs_reference(tag, dtype):
     for q in range(len(qi)):
         for doc in set(idx[q].tolist()) - set(ref_top[q].tolist()):
             assert ref_sorted[q, k - 1] - ref_cos[q, doc] < 2 * budget, (q, doc)
-    if dtype == "f16":
+    if dtype == "f16" and meta.get("outliers"):
+        # the GELU output of block 3 (two hidden units at ~1e5) was moved under a shift by the guarded re-run; nothing else
+        assert shifts[3, 3] >= 2 and int(shifts.sum()) == int(shifts[3, 3]), shifts.tolist()
+    elif dtype == "f16":
         assert shifts is not None and int(shifts.max()) == 0        # std-0.02 random-init weights stay inside the half range
