@@ -16,7 +16,7 @@ M = int(os.environ.get("M", 131072))
 ROUNDS = int(os.environ.get("ROUNDS", 5))
 DT = {"bf16": 1, "f16": 3}
 dts = [d for d in os.environ.get("DTYPES", "f16,bf16").split(",") if d]
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
 skews = [int(v) for v in os.environ.get("SKEWS", "0").split(",")]
 shapes = [("qk    store", 0, True, M, 1536, 768), ("v     vt   ", 4, True, M, 768, 768), ("oproj resid", 2, False, M, 768, 768),
           ("fc1   gelu ", 1, True, M, 3072, 768), ("fc2   resid", 2, False, M, 768, 3072), ("kloop none ", 5, True, M, 3072, 768)]
@@ -29,8 +29,11 @@ for rnd in range(ROUNDS):
     for dt in dts:
         for v in variants:
           for sk in skews:
-            ctx.lib.sgpt_set_gemm_variant(v)
-            ctx.lib.sgpt_set_gemm_skew(sk)
+            if hasattr(ctx.lib, "sgpt_exp_set_gemm_w"):        # experiment build (SGPT_EXPERIMENTS=1): the A/B knobs exist
+                ctx.lib.sgpt_exp_set_gemm_w(v & 1)
+                ctx.lib.sgpt_exp_set_gemm_skew(sk)
+            elif v or sk:
+                raise SystemExit("VARIANTS / SKEWS other than 0 need the experiment build (SGPT_EXPERIMENTS=1 python -m sgpt_amd.build)")
             for name, epi, o16, m, n, k in shapes:
                 ms = C.c_float(0)
                 ctx._chk(ctx.lib.sgpt_bench_gemm(ctx.handle, DT[dt], epi, DT[dt] if o16 else 0, m, n, k, 10, C.byref(ms)), "bench_gemm")

@@ -16,6 +16,11 @@ SOURCES = ["gemm.hip", "gemm256q.hip", "attn.hip", "elementwise.hip", "topk.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result"] + (["-DSGPT_EXPERIMENTS"] if EXPERIMENTS else []) + os.environ.get("SGPT_EXTRA_FLAGS", "").split()
 OBJ_SUFFIX = ".exp.o" if EXPERIMENTS else ".o"
+# SGPT_LIB_TAG=name (with SGPT_EXTRA_FLAGS=-D...): a second build of the same ABI for same-box A/B runs (scripts/ab_libs.sh
+# selects it through SGPT_HIP_LIB): libsgpt_hip_<name>.so, its own object files
+if os.environ.get("SGPT_LIB_TAG"):
+    LIB = os.path.join(LIBDIR, f"libsgpt_hip_{os.environ['SGPT_LIB_TAG']}.so")
+    OBJ_SUFFIX = f".{os.environ['SGPT_LIB_TAG']}.o"
 
 
 def _hipcc():

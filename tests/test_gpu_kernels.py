@@ -339,6 +339,29 @@ def test_score_topk_threshold_filtered_chunks_are_exact(ctx, case, dt16):
         assert (idx >= N - 64).all() and (val[:, :-1] >= val[:, 1:]).all()
 
 
+@pytest.mark.parametrize("nq", [2048, 16], ids=["256-row tile", "64-row tile"])
+def test_score_topk_filtered_chunks_nan_and_negative_thresholds(ctx, nq):
+    """The filter epilogues reject a row's tile on the raw maximum (NaNs dropped) unless the query's threshold lies below
+    -1, where a NaN score -- counted as -1 (exact_search.py:99) -- can still enter the top-k: dot-product scores far below
+    -1 with NaN documents spread over the corpus must come back exactly as the materialise-and-select loop returns them
+    (the NaN documents rank above every real score here), and a query whose scores are all positive must not see them."""
+    d, k = 128, 10
+    N = 70_000 if nq > 64 else 300_000          # (nq = 16: 131 072-document chunks -> the filtered path starts at 262 144)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    u = torch.randn(d, generator=g)
+    q = -(torch.randn(nq, d, generator=g).abs() * u.sign()) * 2.0           # <q, u> < 0: every real score is very negative
+    c = torch.randn(N, d, generator=g) * 0.1 + u[None, :] * 3.0
+    q[1] = -q[1]                                                             # one query with positive scores throughout
+    c[torch.tensor([5, 20_000, 40_001, N - 1])] = float("nan")               # NaN rows in the first chunk, later chunks, the tail
+    q, c = q.cuda().to(torch.float16), c.cuda().to(torch.float16)
+    val, idx, n = ctx.score_topk(q, c, k)
+    wv, wi, wn = _sliced_classic(ctx, q, c, k, 16384 if nq > 64 else 100_000)
+    assert n == wn == k and torch.equal(val, wv) and torch.equal(idx, wi)
+    nan_docs = {5, 20_000, 40_001, N - 1}
+    assert set(idx[0, :4].tolist()) == nan_docs and (val[0, :4] == -1).all() and (val[0, 4:] < -1).all()
+    assert not (set(idx[1].tolist()) & nan_docs) and (val[1] > 0).all()
+
+
 def test_topk_ties_take_lowest_indices_in_every_path(ctx):
     """Equal scores at the k-th place: the lowest INDICES win, whatever the position in the candidate row --
     shuffled (score, index) lists in a merge (radix path, second radix select over the indices), the
