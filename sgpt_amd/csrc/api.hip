@@ -832,21 +832,32 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     static const bool classic_only = exp_env("SGPT_SCORE_CLASSIC") != nullptr;
     // Capacity and growth: a filtered chunk of len = growth * seen documents expects ~k * growth survivors per query
     // (the threshold is the k-th best of `seen` documents); the merge sorts the candidates in 2048 LDS slots.
-    const int cap = k <= 64 ? 256 : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
+    // The merge kernel sorts up to 2048 candidates per query in LDS and its cost follows the ACTUAL count, so the lists are as
+    // long as that allows (bounded to 64 MiB of list memory for very large nq; never below the round-2 capacity of 256).
+    int cap = 2048 - ((k > 64) ? k : 0);
+    if (k > 64 && 4 * k < cap) cap = 4 * k;
+    { const long by_mem = (long)(((size_t)64 << 20) / ((size_t)nq * 12)); if (by_mem < cap) cap = by_mem < 256 ? 256 : (int)by_mem; }
+    if (cap > 2048 - k) cap = 2048 - k;
     const bool half_growth = 2 * cap < 5 * k;          // k > ~340: cap < 2.5 k -> grow by half, expect ~k/2 per chunk
-    // Chunks grow by doubling even where the lists would hold more (k = 11: cap = 23 k): growing 4x per chunk was measured
-    // (-10 % at nq = 128) and rejected -- the expected count k * len / seen assumes exchangeable document order, and a corpus
-    // whose score distribution drifts along the index (the reference sorts documents by length, exact_search.py:66-71;
-    // bench.py's 1 M shard starts with its variable-length documents) then overflows the lists and pays the 12x slower
-    // materialised recomputation.  Doubling keeps 23x head-room over the expectation.
-    const int growth = 1;
+    // Chunk growth: a chunk of len = g * seen expects ~k * g survivors per query; g keeps 6x head-room under the capacity
+    // (k = 11: g = 31 -- a 1 M-document pass is first chunk + two filtered chunks instead of first + six doubling ones: fewer
+    // launches, and each persistent launch runs long enough to stream).  Round 2 doubled (g = 1) with 256-entry lists because
+    // 4x growth overflowed them on corpora whose score distribution drifts along the index (the reference sorts documents
+    // by length, exact_search.py:66-71); the head-room is now the same 6x .. 23x at eight times the capacity, and an
+    // overflowing chunk is still recomputed on its own.
+    int growth = cap / (6 * k);
+    growth = growth < 1 ? 1 : (growth > 64 ? 64 : growth);
     const bool filt = fast && !classic_only && k <= 1024 && chunk % 256 == 0 && N >= 2 * chunk;
 
-    // A filtered chunk whose candidate lists overflow is recomputed by materialise + select, in pieces of `chunk`
-    // documents like the un-filtered loop: the score tile stays in the Infinity Cache (measured: 1 GiB tiles made the
-    // recomputation 6x slower than the plain materialised loop).  Its launches are predicated and exit at once otherwise.
-    const long fchunk = chunk;
-    const long n_flags = 64 + N / (1L << 19) + 1;      // one overflow flag per filtered chunk (doubling, then 2^19 each)
+    // A filtered chunk whose candidate lists overflow is recomputed by materialise + select in pieces whose fp32 score tile
+    // stays in the Infinity Cache (measured: 1 GiB tiles made the recomputation 6x slower than the plain materialised
+    // loop).  Its launches are predicated and exit at once otherwise -- for short query batches one piece covers a whole
+    // chunk (nq = 16: 2.6 M documents per 160 MiB tile), so a pass carries 2 predicated launches per chunk, not 2 per 131 072
+    // documents.
+    long fchunk = (long)(budget / ((size_t)nq * 4)) / 256 * 256;
+    if (fchunk > (long)align_up((size_t)N, 256)) fchunk = (long)align_up((size_t)N, 256);
+    if (fchunk < chunk) fchunk = chunk;
+    const long n_flags = 64 + N / (1L << 19) + 1;      // one overflow flag per filtered chunk
     const size_t sc_bytes = align_up((size_t)nq * fchunk * 4, 256);
     const size_t tv_bytes = align_up((size_t)nq * k * 4, 256), ti_bytes = align_up((size_t)nq * k * 8, 256);
     const size_t qp_bytes = fast ? align_up((size_t)nq_pad * d * 2, 256) : 0;
@@ -952,7 +963,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         while (n256 - seen >= 256) {
             long len = half_growth ? (seen / 2 / 256 * 256 > 256 ? seen / 2 / 256 * 256 : 256) : seen * growth;
             if (len > n256 - seen) len = n256 - seen;
-            if (len > (1L << 19)) len = 1L << 19;
+            if (len > (1L << 21)) len = 1L << 21;
             if (len >= unit) len = len / unit * unit;
             GemmArgs g{};
             g.A = qpad; g.lda = d; g.M = nq_pad; g.m_valid = nq; g.K = d;

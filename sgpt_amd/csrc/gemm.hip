@@ -39,11 +39,6 @@ constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 #define SGPT_SMALL_PF 2
 #endif
 constexpr int CH = 8;  // 16-byte chunks per row per k-step
-#ifdef SGPT_NO_RESID_FOLD      // A/B builds only (SGPT_LIB_TAG): the residual added in the epilogue, as up to round 2
-constexpr bool RESID_FOLD = false;
-#else
-constexpr bool RESID_FOLD = true;
-#endif
 
 // A/B switches of the measurement scripts exist only in the experiment build (`SGPT_EXPERIMENTS=1 python -m sgpt_amd.build`
 // -> libsgpt_hip_exp.so, loaded through SGPT_HIP_LIB): the shipped library reads no environment variable and holds no
@@ -209,27 +204,6 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Residual epilogue, folded: the accumulators (of k-group 0) start as the residual tile -- the start value and MFMA
-    // sequence of gemm256d_kernel's folded path, so both kernels keep producing identical bits.  Elements outside the
-    // matrix start at 0 and are never stored.
-    const bool fold_resid = RESID_FOLD && EPI == EPI_BIAS_RESID && sizeof(T) == 2 && p.in_mul == 1.0f;
-    if constexpr (EPI == EPI_BIAS_RESID) {
-        if (fold_resid && kg == 0) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int m = m0 + wm * (16 * NI) + i * 16 + fr;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int n = n0 + wn * (16 * NI) + j * 16 + 4 * g;
-                    if (m < p.m_valid && n + 3 < N) {
-                        const float4 v = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
-                        acc[i][j] = f32x4{v.x, v.y, v.z, v.w};
-                    }
-                }
-            }
-        }
-    }
-
     auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -354,10 +328,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
                 const float bsc = EPI == EPI_BIAS_GELU ? 1.0f : om;
                 if constexpr (EPI == EPI_BIAS_RESID) {
                     // acc (* in_mul) + (bias + resid): the association of gemm256_kernel's epilogue, bit for bit
-                    // (folded: the residual already sits inside acc, and bias + 0 is added)
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                    const bool in_acc = fold_resid && full;
-                    const float4 rr = in_acc ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
+                    const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
                     v[0] = __builtin_fmaf(v[0], cs, bb.x + rr.x); v[1] = __builtin_fmaf(v[1], cs, bb.y + rr.y);
                     v[2] = __builtin_fmaf(v[2], cs, bb.z + rr.z); v[3] = __builtin_fmaf(v[3], cs, bb.w + rr.w);
                 } else if (EPI == EPI_BIAS_GELU || ((EPI == EPI_STORE || EPI == EPI_QKV) && p.bias != nullptr)) {
@@ -504,23 +476,6 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     int tile = blockIdx.x, m0 = 0, n0 = 0;
     while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
     if (tile >= tiles_total) return;
-    // Residual epilogue, folded (see gemm256_epilogue.inc): the accumulators start as the residual tile -- MFMA C operand --
-    // so that the 256 KiB of residual reads per tile overlap the k-loop instead of sitting in the epilogue.  Same start value
-    // and MFMA sequence as gemm_kernel's folded path: identical bits from either kernel.  (A range-shifted launch,
-    // in_mul != 1, keeps the residual in the epilogue: resid / in_mul would put an ALU op behind every load.)
-    const bool fold_resid = RESID_FOLD && EPI == EPI_BIAS_RESID && sizeof(T) == 2 && p.in_mul == 1.0f;
-    if constexpr (EPI == EPI_BIAS_RESID) {
-        if (fold_resid) {
-            const float* r0 = p.resid + (long)(m0 + wm * 128 + fr) * p.ldo + n0 + wn * 64 + 4 * g;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 v = *reinterpret_cast<const float4*>(r0 + (long)(i * 16) * p.ldo + j * 16);
-                    acc[i][j] = f32x4{v.x, v.y, v.z, v.w};
-                }
-        }
-    }
     // per-lane source rows of the two operands for the current tile
     const bf16_t* asrc = Ag + (long)m0 * p.lda;          // wave-uniform tile bases
     const bf16_t* wsrc = Wg + (long)n0 * p.ldw;
@@ -643,9 +598,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         {
             const int sdf = sd + 2 >= 3 ? sd - 1 : sd + 2;
             char* scr = reinterpret_cast<char*>(lds) + (wave < 4 ? deep_off(sdf) : shal_off(ss ^ 1)) + (wave & 3) * 8192;
-#define SGPT_EPI_RESID_FOLD 1
 #include "gemm256_epilogue.inc"
-#undef SGPT_EPI_RESID_FOLD
         }
         STAMP(3);
         ++dbg_tile;

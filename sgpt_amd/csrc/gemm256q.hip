@@ -231,15 +231,21 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(const GemmArgs p) {
                         }
                     }
                 } else {                   // lane: rows m = 4g .. 4g+3 of block i, column n = fr of block j
+                    // i outermost: ONE float4 of row scales live at a time.  (Written j-outermost, the compiler hoisted all
+                    // eight row-scale loads over the j loop -- 32 VGPRs on top of 128 accumulators and the 48 fragment
+                    // registers of the next tile's first k-step -- and spilled 85-102 VGPRs in every EPI_VT variant.)
+                    float sw[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float sw = p.w_scale[n0 + wn * 64 + j * 16 + fr] * p.a_scalar;
+                    for (int j = 0; j < 4; ++j) sw[j] = p.w_scale[n0 + wn * 64 + j * 16 + fr] * p.a_scalar;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            float4 sa = make_float4(1.f, 1.f, 1.f, 1.f);
-                            if (p.a_scale) sa = *reinterpret_cast<const float4*>(p.a_scale + m0 + wm * 128 + i * 16 + 4 * g);
-                            acc[i][j][0] *= sa.x * sw; acc[i][j][1] *= sa.y * sw; acc[i][j][2] *= sa.z * sw; acc[i][j][3] *= sa.w * sw;
+                    for (int i = 0; i < 8; ++i) {
+                        float4 sa = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (p.a_scale) sa = *reinterpret_cast<const float4*>(p.a_scale + m0 + wm * 128 + i * 16 + 4 * g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[i][j][0] *= sa.x * sw[j]; acc[i][j][1] *= sa.y * sw[j]; acc[i][j][2] *= sa.z * sw[j]; acc[i][j][3] *= sa.w * sw[j];
                         }
+                        __builtin_amdgcn_sched_barrier(0);     // keep the next row block's scale load behind this block's multiplies
                     }
                 }
                 OutT* out = static_cast<OutT*>(p.out);
