@@ -477,7 +477,7 @@ def main():
     # HBM bytes per launch from the committed PMC passes of this same command (profiles/, rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 corrections applied there); null if not collected
     traffic, traffic_source = None, None
-    for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if args.dtype in ("bf16", "f16") and args.call * S == 131072 and os.path.exists(tpath):
             with open(tpath) as f:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM bytes per GEMM launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc.sh
-(bench.py --steps 1 --warmup 1: 2 steps x 4 calls x 12 blocks = 96 full-size launches per projection, issued after
-the short query-encode launches, so the LAST 96 dispatches of a kernel are the T = 131 072-token ones; the
+(bench.py --steps 1 --warmup 1 --no-varlen: (2 timed-loop + 2 host-leg) steps x 4 calls x 12 blocks >= 96 full-size launches per
+projection, issued after the short query-encode launches, so the LAST 96 dispatches of a kernel are the T = 131 072-token ones; the
 residual kernel serves two projections per block, alternating out-proj / fc2).  Corrections as calibrated on
 layernorm_kernel on gfx950: FETCH_SIZE (KiB) x 2, WRITE_SIZE (KiB) as reported.
 usage: pmc_traffic.py FETCH.db WRITE.db > profiles/rNN_pmc_traffic.json"""

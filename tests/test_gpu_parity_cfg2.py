@@ -54,6 +54,11 @@ def test_cfg2_cosine_and_ranked_top10_vs_reference(fx, dtype):
     print(f"cfg2 {dtype}: max|emb-ref|/||ref|| = {rel:.2e}, normalised max|emb-ref| = {e_dev:.2e}, "
           f"max|cos-ref| = {c_dev:.2e} over {cos.size} pairs")
     assert np.isfinite(cos).all()
+    if os.environ.get("SGPT_PARITY_LOG"):
+        import json
+        with open(os.environ["SGPT_PARITY_LOG"], "a") as f:
+            f.write(json.dumps(dict(case="cfg2_125m_1024x128", dtype=dtype, rows=131072, rel_emb=rel, max_abs_norm_emb=e_dev,
+                                    max_abs_cos=c_dev, budget=BUDGET[dtype], n_queries=len(queries), n_docs=int(docs.shape[0]))) + "\n")
     assert c_dev < BUDGET[dtype] and e_dev < BUDGET[dtype]
     # ranked top-10 through the fused scorer: every returned score within the budget of the reference score of that
     # pair; rank-for-rank scores within the budget of the reference's ranked scores; a document outside the reference
