@@ -832,21 +832,16 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     static const bool classic_only = exp_env("SGPT_SCORE_CLASSIC") != nullptr;
     // Capacity and growth: a filtered chunk of len = growth * seen documents expects ~k * growth survivors per query
     // (the threshold is the k-th best of `seen` documents); the merge sorts the candidates in 2048 LDS slots.
-    // The merge kernel sorts up to 2048 candidates per query in LDS and its cost follows the ACTUAL count, so the lists are as
-    // long as that allows (bounded to 64 MiB of list memory for very large nq; never below the round-2 capacity of 256).
-    int cap = 2048 - ((k > 64) ? k : 0);
-    if (k > 64 && 4 * k < cap) cap = 4 * k;
-    { const long by_mem = (long)(((size_t)64 << 20) / ((size_t)nq * 12)); if (by_mem < cap) cap = by_mem < 256 ? 256 : (int)by_mem; }
-    if (cap > 2048 - k) cap = 2048 - k;
+    const int cap = k <= 64 ? 256 : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
     const bool half_growth = 2 * cap < 5 * k;          // k > ~340: cap < 2.5 k -> grow by half, expect ~k/2 per chunk
-    // Chunk growth: a chunk of len = g * seen expects ~k * g survivors per query; g keeps 6x head-room under the capacity
-    // (k = 11: g = 31 -- a 1 M-document pass is first chunk + two filtered chunks instead of first + six doubling ones: fewer
-    // launches, and each persistent launch runs long enough to stream).  Round 2 doubled (g = 1) with 256-entry lists because
-    // 4x growth overflowed them on corpora whose score distribution drifts along the index (the reference sorts documents
-    // by length, exact_search.py:66-71); the head-room is now the same 6x .. 23x at eight times the capacity, and an
-    // overflowing chunk is still recomputed on its own.
-    int growth = cap / (6 * k);
-    growth = growth < 1 ? 1 : (growth > 64 ? 64 : growth);
+    // Chunks grow by doubling even where the lists could hold more.  Two schedules were measured against it and rejected:
+    //   round 2: 4x growth with 256-entry lists -- overflowed on corpora whose score distribution drifts along the index (the
+    //            reference sorts documents by length, exact_search.py:66-71) and paid the materialised recomputation;
+    //   round 3: 2048-entry lists with growth cap / 6k (k = 11: first chunk + two filtered chunks per 1 M documents, 6x
+    //            head-room) -- fewer launches, but ~330 survivors per query and chunk instead of ~11 go through the
+    //            epilogue's append path: the filtered GEMM went from 1.45 to 1.58 ms per pass (nq = 1000), nq = 64 from 0.47
+    //            to 0.52 ms, and a drift at 10 % of the corpus from 2.2 to 3.5 ms (profiles/r03_score_schedule.txt).
+    const int growth = 1;
     const bool filt = fast && !classic_only && k <= 1024 && chunk % 256 == 0 && N >= 2 * chunk;
 
     // A filtered chunk whose candidate lists overflow is recomputed by materialise + select in pieces whose fp32 score tile
@@ -963,7 +958,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         while (n256 - seen >= 256) {
             long len = half_growth ? (seen / 2 / 256 * 256 > 256 ? seen / 2 / 256 * 256 : 256) : seen * growth;
             if (len > n256 - seen) len = n256 - seen;
-            if (len > (1L << 21)) len = 1L << 21;
+            if (len > (1L << 19)) len = 1L << 19;
             if (len >= unit) len = len / unit * unit;
             GemmArgs g{};
             g.A = qpad; g.lda = d; g.M = nq_pad; g.m_valid = nq; g.K = d;
