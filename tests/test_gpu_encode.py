@@ -165,6 +165,32 @@ def test_f16_range_shifts_cover_outliers_and_the_guard_stays_loud():
     ok.close()
 
 
+def test_encode_graph_replay_adapts_range_shifts():
+    """A captured graph carries the range-shift factors as kernel arguments: when a replay overflows an f16 class, replay()
+    raises that class's shift (the context generation moves), re-captures and runs again -- the rows equal the eager,
+    guarded encode_ids of the same sentences; check_range=False leaves the check to the caller."""
+    from sgpt_amd import EncodeGraph, SGPTConfig, SGPTModel
+    from sgpt_amd._lib import SgptRangeError
+    kw = dict(vocab_size=211, max_position_embeddings=96, hidden_size=128, num_layers=2, num_heads=2, window_size=8)
+    w = dict(O.synth_weights(O.NeoConfig(**kw), seed=3, std=0.05))
+    w["h.1.mlp.c_fc.bias"] = w["h.1.mlp.c_fc.bias"] * 0 + 5e4
+    seqs = [[1, 2, 3, 4, 5], [7] * 40, [9, 8, 7]]
+    m = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
+    try:
+        g = EncodeGraph(m, seqs, normalize=True)              # captured with all shifts 0: its kernels overflow
+        assert (m.range_shifts() == 0).all()
+        got = g.replay().clone()
+        assert m.range_shifts()[1, 3] >= 2 and torch.isfinite(got).all()
+        want = m.encode_ids(seqs, normalize=True)
+        assert torch.equal(got, want)
+        m.set_range_shifts(np.zeros((2, 4), np.int32))        # back to the overflowing factors; the caller owes the check
+        g.replay(check_range=False)
+        with pytest.raises(SgptRangeError):
+            m.check_range()
+    finally:
+        m.close()
+
+
 def test_encode_bf16_vs_oracle_with_dequantised_weights():
     """for bf16 runs the oracle uses the de-quantised (bf16-rounded) matmul weights, so weight
     rounding is common-mode and only activation rounding remains."""
