@@ -94,6 +94,13 @@ typedef struct {
                                            tests report max |dcos| and top-10 overlap against the fp32 oracle instead */
     const uint8_t* layer_is_local;  /* host, [n_layers]: 1 = sliding-window layer (HF:gpt_neo:66) */
     int32_t rotary_dim;      /* GPT-J: leading dims of every head that get rotary position embedding (64) */
+    int32_t qk_split;        /* SGPT_F16 / SGPT_BF16 only.  1 = split-precision Q / K projection: the LayerNorm output a and the
+                                Wq / Wk weights enter the projection as hi + lo pairs of 16-bit values (a_hi.W_hi + a_lo.W_hi +
+                                a_hi.W_lo: one GEMM over K' = 3 d on the same MFMA), i.e. to ~2^-22 instead of 2^-11 each; q / k
+                                are stored in 16 bits as before.  For GPT-Neo (attention without 1/sqrt(dh), HF:gpt_neo:110) the
+                                path LayerNorm -> Wq / Wk -> q / k carries 80 % of the 16-bit deviation at d = 2048:
+                                SGPT-1.3B shape goes from 8.7e-4 / 1.11e-3 (cosine / embedding) to well inside the 1e-3 bar, for
+                                three times the FLOPs of one of the five projections.  0 (default) = off */
 } sgpt_model_desc;
 
 /* One named fp32 weight tensor under its HF state-dict name

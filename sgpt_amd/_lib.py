@@ -20,7 +20,7 @@ class ModelDesc(C.Structure):
     _fields_ = [("arch", C.c_int32), ("n_layers", C.c_int32), ("d_model", C.c_int32), ("n_heads", C.c_int32),
                 ("d_ffn", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("window", C.c_int32),
                 ("ln_eps", C.c_float), ("attn_scale", C.c_float), ("compute_dtype", C.c_int32),
-                ("layer_is_local", C.POINTER(C.c_uint8)), ("rotary_dim", C.c_int32)]
+                ("layer_is_local", C.POINTER(C.c_uint8)), ("rotary_dim", C.c_int32), ("qk_split", C.c_int32)]
 
 
 class TensorView(C.Structure):

@@ -17,6 +17,7 @@
 
 struct LayerW {
     void* w_qkv = nullptr;   // [3d, d]  (q rows, k rows, v rows)
+    void* w_qk3 = nullptr;   // qk_split: [2d, 3d] = [W_hi | W_hi | W_lo] of the q and k rows
     void* w_o = nullptr;     // [d, d]
     void* w_fc = nullptr;    // [ffn, d]
     void* w_proj = nullptr;  // [d, ffn]
@@ -112,7 +113,7 @@ struct Prof {  // brackets one GEMM launch with events when profiling is on
 };
 
 void gemm(sgpt_ctx* c, int dtype, int epi, int out_dtype, const GemmArgs& a0, hipStream_t s) {
-    Prof p(c, s, 2.0 * (double)a0.m_valid * a0.N * a0.K);
+    Prof p(c, s, 2.0 * (double)a0.m_valid * a0.N * (a0.k_algo > 0 ? a0.k_algo : a0.K));   // algorithmic FLOPs (split blocks not counted)
     GemmArgs a = a0;
     a.kgroups = c->kgroups; a.force256 = c->force256;     // per-ctx policies (no process-global state)
     launch_gemm(dtype, epi, out_dtype, a, s);
@@ -223,6 +224,8 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         return fail(c, SGPT_ERR_INVALID, "bad compute_dtype");
     if (gptj && (d->rotary_dim <= 0 || d->rotary_dim > dh || d->rotary_dim % 2))
         return fail(c, SGPT_ERR_INVALID, "GPT-J needs an even rotary_dim in (0, head_dim]");
+    if (d->qk_split != 0 && d->compute_dtype != SGPT_F16 && d->compute_dtype != SGPT_BF16)
+        return fail(c, SGPT_ERR_INVALID, "qk_split applies to SGPT_F16 / SGPT_BF16 models");
 
     std::unordered_map<std::string, const sgpt_tensor_view*> byname;
     for (size_t i = 0; i < nt; ++i) byname[tv[i].name] = &tv[i];
@@ -339,6 +342,9 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
             l.s_fc = (float*)dalloc((size_t)ffn * 4); l.s_proj = (float*)dalloc((size_t)dm * 4);
         }
         if (st != SGPT_OK) break;
+        const bool split = m->d.qk_split != 0;
+        if (split) { l.w_qk3 = dalloc((size_t)2 * dm * 3 * dm * 2); if (!l.w_qk3) break; }
+        const int dt16 = f16 ? DT_F16 : DT_BF16;
         if (bloom) {
             const float* wq = find(p + "self_attention.query_key_value.weight", (int64_t)3 * dm * dm);
             const float* bq = find(p + "self_attention.query_key_value.bias", (int64_t)3 * dm);
@@ -347,8 +353,16 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
             launch_qkv_deinterleave(wq, stage, H, dh, dm, 0);          // rows [h,3,dh] -> [q | k | v]
             launch_qkv_deinterleave(bq, l.b_qkv, H, dh, 1, 0);
             pack_rows(stage, (int64_t)3 * dm, dm, l.w_qkv, 0, l.s_qkv);
+            if (split) launch_pack_split_rows(stage, (long)2 * dm, dm, l.w_qk3, dt16, 0);      // q and k rows
             pack_w(p + "self_attention.dense.weight", dm, dm, l.w_o, 0, l.s_o);
         } else {
+            if (split) {
+                const float* wq = find(p + attn + "q_proj.weight", (int64_t)dm * dm);
+                const float* wk = find(p + attn + "k_proj.weight", (int64_t)dm * dm);
+                if (!wq || !wk) break;
+                launch_pack_split_rows(wq, dm, dm, l.w_qk3, dt16, 0);
+                launch_pack_split_rows(wk, dm, dm, (bf16_t*)l.w_qk3 + (size_t)dm * 3 * dm, dt16, 0);
+            }
             pack_w(p + attn + "q_proj.weight", dm, dm, l.w_qkv, 0, l.s_qkv);
             pack_w(p + attn + "k_proj.weight", dm, dm, l.w_qkv, dm, l.s_qkv);
             pack_w(p + attn + "v_proj.weight", dm, dm, l.w_qkv, (int64_t)2 * dm, l.s_qkv);
@@ -446,8 +460,11 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_x = carve((size_t)T * dm * 4);                        // residual stream fp32
-    const size_t o_a = carve((size_t)T * dm * esz);                      // LN output (GPT-Neo: also attention ctx)
-    const size_t o_c = gptj ? carve((size_t)T * dm * esz) : o_a;         // GPT-J: ctx separate (ln_1 output feeds the MLP too)
+    // qk_split: the LayerNorm-1 output is [hi | lo | hi] rows of 3 * d (the Q / K projection contracts over all three blocks,
+    // everything else reads the first), and the attention context gets its own buffer
+    const bool split = m->d.qk_split != 0 && bf && m->d.compute_dtype != SGPT_FP8W && m->d.compute_dtype != SGPT_FP8M;
+    const size_t o_a = carve((size_t)T * dm * esz * (split ? 3 : 1));    // LN output (GPT-Neo: also attention ctx)
+    const size_t o_c = (gptj || split) ? carve((size_t)T * dm * esz) : o_a;   // GPT-J: ctx separate (ln_1 output feeds the MLP too)
     const size_t o_qkv = carve(((size_t)T + SLACK) * 3 * dm * esz);      // bf16: [T][2d] qk + V^T [d][T]; fp32: [T][3d]
     const size_t o_h = carve((size_t)T * ffn * esz);                     // MLP hidden (FP8M: e4m3 codes in the same region)
     // FP8M: fp8 MFMA on all four projections when the shapes fit the 256x256x128 kernel and the activation scales are
@@ -482,7 +499,7 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     } else {
         HIPC(c, hipMemsetAsync((float*)qkv + (size_t)T * 3 * dm, 0, SLACK * 3 * dm * esz, s));
     }
-    if (gptj || mlp8) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz, s));   // (fp8: stale bytes would decode to NaN codes)
+    if (gptj || mlp8 || split) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz, s));   // (fp8: stale bytes would decode to NaN codes)
     launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, m->d.vocab, m->d.max_pos, s);
     if (m->emb_ln_g) launch_layernorm(x, m->emb_ln_g, m->emb_ln_b, x, SGPT_F32, T, dm, m->d.ln_eps, s);   // BLOOM :499
     for (int li = 0; li < n_layers_run; ++li) {
@@ -533,12 +550,22 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             { Prof pr(c, s, 2.0 * T * (double)dm * dm); launch_gemm_fp8(EPI_BIAS_RESID, 0, q, s); }
             q.resid = nullptr;
         } else {
-        launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln1));
+        if (split) launch_layernorm_split(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln1));
+        else launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln1));
         if (bf) {
             // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]
             g.W = l.w_qkv; g.out = qkv; g.ldo = 2 * dm; g.bias = l.b_qkv;                           // bias: BLOOM only
             g.in_mul = pow2f(k_ln1); g.out_mul = g.out_mul2 = pow2f(-k_qkv); g.range_amax = f16m ? slots + RS_QKV : nullptr;
-            if (gemm_qkv_one_launch(T, 2 * dm, c->force256 != 0)) {        // query-sized batch: one launch (a launch costs ~8 us there)
+            if (split) {
+                // a_hi.W_hi + a_lo.W_hi + a_hi.W_lo as ONE contraction over K' = 3d; V from the hi block alone
+                g.lda = 3 * dm; g.K = 3 * dm; g.ldw = 3 * dm; g.k_algo = dm; g.W = l.w_qk3; g.N = 2 * dm;
+                gemm(c, dt, EPI_STORE, dt, g, s);
+                g.K = dm; g.ldw = dm; g.k_algo = 0;
+                g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; g.N = dm; g.out = vt; g.ldo = T;
+                g.bias = l.b_qkv ? l.b_qkv + 2 * dm : nullptr;
+                gemm(c, dt, EPI_VT, dt, g, s);
+                g.lda = dm;
+            } else if (gemm_qkv_one_launch(T, 2 * dm, c->force256 != 0)) {        // query-sized batch: one launch (a launch costs ~8 us there)
                 g.N = 3 * dm; g.n_split = 2 * dm; g.out2 = vt; g.ldo2 = T;
                 gemm(c, dt, EPI_QKV, dt, g, s);
                 g.out2 = nullptr; g.n_split = 0;
@@ -580,7 +607,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             { Prof pr(c, s, 2.0 * T * (double)ffn * dm); launch_gemm_fp8(EPI_BIAS_RESID, 0, q, s); }
         } else {
             if (!gptj) launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln2));
-            g.A = a; g.lda = dm; g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
+            g.A = a; g.lda = (gptj && split) ? 3 * dm : dm;      // GPT-J: ln_1's output again -- the hi block of a split row
+            g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
             g.in_mul = pow2f(k_ln2); g.out_mul = pow2f(-k_h); g.range_amax = f16m ? slots + RS_H : nullptr;
             gemm(c, dt, EPI_BIAS_GELU, dt, g, s);
             if (m->calibrating) launch_absmax16(h, (long)T * ffn, dt, m->h_amax + li, s);   // FP8M calibration: range of this block's GELU output

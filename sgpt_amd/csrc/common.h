@@ -231,6 +231,7 @@ struct GemmArgs {
     //   in_mul  = product of the operands' up-shifts (an operand stored as v * 2^-k contributes 2^k),
     //   out_mul = 2^-k of the tensor this launch writes (EPI_QKV: out_mul for q | k, out_mul2 for V^T).
     float in_mul, out_mul, out_mul2;
+    int k_algo;         // 0, or the K of the un-split problem when K carries split-precision blocks (profiling counts 2*M*N*k_algo)
     int kgroups;        // per-ctx low-latency mode: 2 = k-groups for under-filled small-tile launches (0 / 1 = off)
     int force256;       // per-ctx tile policy: 1 = keep 256x256 tiles even where the small-tile rule would apply (kernel tests)
     // EPI_QKV
@@ -283,6 +284,11 @@ void launch_embed(const int* ids, const int* pos, const float* wte, const float*
                   int max_pos, hipStream_t s);
 void launch_layernorm(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
                       float eps, hipStream_t s, float out_mul = 1.0f);   // out_mul: f16 range shift (power of two)
+// split-precision Q / K projection (elementwise.hip): LayerNorm output as [hi | lo | hi] rows of 3 * d, weights as
+// [W_hi | W_hi | W_lo] rows of 3 * cols
+void launch_layernorm_split(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
+                            float eps, hipStream_t s, float out_mul);
+void launch_pack_split_rows(const float* src, long rows, long cols, void* dst, int out_dtype, hipStream_t s);
 // LayerNorm -> e4m3fn codes q[T,d] + one power-of-two scale per row (+ optionally the same rows in a 16-bit format)
 void launch_layernorm_q8(const float* x, const float* g, const float* b, void* q, float* scale, void* out16, int out16_dtype,
                          int T, int d, float eps, hipStream_t s);

@@ -109,6 +109,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// LayerNorm for the split-precision Q / K projection (sgpt_model_desc.qk_split): the normalised row a is written as
+// [hi | lo | hi] with hi = round16(a), lo = round16(a - hi) -- three K blocks of a [T, 3d] operand.  Against weights packed as
+// [W_hi | W_hi | W_lo] (pack_split_rows_kernel) one ordinary GEMM over K' = 3d computes a_hi.W_hi + a_lo.W_hi + a_hi.W_lo:
+// the product of the two operands to ~2^-22 instead of 2^-11 each, on the 16-bit MFMA, with no kernel of its own.  The V
+// projection (and GPT-J's MLP) read the first block alone (lda = 3d, K = d): the plain 16-bit LayerNorm output.
+template <typename OutT, int NV>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              const float* __restrict__ b, uint16_t* __restrict__ out, int T,
+                                                              int d, float eps, float out_mul) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const int lane = threadIdx.x & 63;
+    RowLN<NV> r;
+    r.load(x + (long)row * d, d, lane);
+    r.normalize(g, b, d, eps, lane);
+    uint16_t* o = out + (long)row * 3 * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            const float v0 = r.v[i].x * out_mul, v1 = r.v[i].y * out_mul, v2 = r.v[i].z * out_mul, v3 = r.v[i].w * out_mul;
+            const uint32_t h01 = Half<OutT>::pack2(v0, v1), h23 = Half<OutT>::pack2(v2, v3);
+            const uint32_t l01 = Half<OutT>::pack2(v0 - Half<OutT>::lo(h01), v1 - Half<OutT>::hi(h01));
+            const uint32_t l23 = Half<OutT>::pack2(v2 - Half<OutT>::lo(h23), v3 - Half<OutT>::hi(h23));
+            *reinterpret_cast<uint2*>(o + c) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(o + d + c) = make_uint2(l01, l23);
+            *reinterpret_cast<uint2*>(o + 2 * d + c) = make_uint2(h01, h23);
+        }
+    }
+}
+
+// weights of the split-precision projection: src fp32 [rows, cols] -> dst 16-bit [rows, 3 * cols] = [W_hi | W_hi | W_lo]
+template <typename H>
+__global__ __launch_bounds__(256) void pack_split_rows_kernel(const float* __restrict__ src, long rows, long cols,
+                                                              uint16_t* __restrict__ dst) {
+    const long n = rows * cols, stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
+        const long r = e / cols, c = e - r * cols;
+        const float w = src[e];
+        const uint32_t hi = Half<H>::pack2(w, 0.0f);
+        const uint16_t lo = f32_to_h<H>(w - Half<H>::lo(hi));
+        uint16_t* o = dst + r * 3 * cols + c;
+        o[0] = (uint16_t)(hi & 0xffffu); o[cols] = (uint16_t)(hi & 0xffffu); o[2 * cols] = lo;
+    }
+}
+
 // LayerNorm whose output feeds an fp8-MFMA GEMM (gemm256q.hip): the normalised row is quantised to OCP e4m3fn codes under
 // ONE power-of-two scale per row -- the smallest 2^k with max|row| / 2^k <= 448 (the rule of fp8_quant_rows_kernel) --
 // which factors out of the GEMM's k-sum and is applied to its accumulators.  Optionally the same row is also written in
@@ -520,6 +566,28 @@ void launch_layernorm(const float* x, const float* g, const float* b, void* out,
     else if (nv <= 4) { LN_CASE(4) } else if (nv <= 8) { LN_CASE(8) } else if (nv <= 10) { LN_CASE(10) }
     else { LN_CASE(16) }
 #undef LN_CASE
+}
+
+void launch_layernorm_split(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
+                            float eps, hipStream_t s, float out_mul) {
+#define LS_CASE(NV)                                                                                              \
+    if (out_dtype == DT_F16)                                                                                     \
+        hipLaunchKernelGGL((layernorm_split_kernel<f16_t, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,     \
+                           (uint16_t*)out, T, d, eps, out_mul);                                                  \
+    else                                                                                                         \
+        hipLaunchKernelGGL((layernorm_split_kernel<bf16_t, NV>), dim3((T + 3) / 4), dim3(256), 0, s, x, g, b,    \
+                           (uint16_t*)out, T, d, eps, 1.0f);
+    const int nv = (d + 255) / 256;
+    if (nv <= 1) { LS_CASE(1) } else if (nv <= 2) { LS_CASE(2) } else if (nv <= 3) { LS_CASE(3) }
+    else if (nv <= 4) { LS_CASE(4) } else if (nv <= 8) { LS_CASE(8) } else if (nv <= 10) { LS_CASE(10) }
+    else { LS_CASE(16) }
+#undef LS_CASE
+}
+
+void launch_pack_split_rows(const float* src, long rows, long cols, void* dst, int out_dtype, hipStream_t s) {
+    const int grid = cap_grid((rows * cols + 255) / 256);
+    if (out_dtype == DT_F16) hipLaunchKernelGGL(pack_split_rows_kernel<f16_t>, dim3(grid), dim3(256), 0, s, src, rows, cols, (uint16_t*)dst);
+    else hipLaunchKernelGGL(pack_split_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, rows, cols, (uint16_t*)dst);
 }
 
 void launch_layernorm_q8(const float* x, const float* g, const float* b, void* q, float* scale, void* out16, int out16_dtype,

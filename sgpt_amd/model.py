@@ -221,9 +221,16 @@ class SGPTModel:
 
     def __init__(self, cfg: SGPTConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device=None,
                  dtype: str = "f16", ctx: Optional[Context] = None, max_tokens_per_call: int = 131072,
-                 calibrate: bool = True):
+                 calibrate: bool = True, precise_qk: bool = False):
+        """precise_qk (dtype 'f16' / 'bf16'): split-precision Q / K projection -- the LayerNorm output and the Wq / Wk weights
+        enter it as hi + lo pairs of 16-bit values (three K blocks on the same MFMA).  GPT-Neo has no 1/sqrt(dh) in its
+        attention; at d >= 2048 the path LayerNorm -> Wq / Wk -> q / k carries 80 % of the 16-bit deviation from the fp32
+        reference: with it SGPT-1.3B shape sits well inside the 1e-3 bar, for +2x the FLOPs of the Q / K projection
+        (~ -20 % throughput at that size).  Off by default; pointless for GPT-J / BLOOM (6e-5 without it)."""
         if dtype in ("fp16", "float16", "half"):
             dtype = "f16"
+        if precise_qk and dtype not in ("f16", "bf16"):
+            raise ValueError("precise_qk applies to dtype 'f16' / 'bf16'")
         if dtype not in ("f16", "bf16", "fp32", "fp8", "fp8mfma"):
             raise ValueError("dtype must be 'f16' (IEEE-half MFMA operands, range-guarded: the 1e-3-parity mode), "
                              "'bf16' (bf16 MFMA operands), 'fp32' (exact fp32 MFMA), "
@@ -248,7 +255,9 @@ class SGPTModel:
                          attn_scale=float(1.0 / np.sqrt(np.float32(dh))) if (gptj or bloom) else 1.0,   # HF:gptj:148, HF:bloom:186 / HF:gpt_neo:110
                          compute_dtype={"f16": SGPT_F16, "bf16": SGPT_BF16, "fp32": SGPT_F32, "fp8": SGPT_FP8W,
                                         "fp8mfma": SGPT_FP8M}[dtype],
-                         layer_is_local=C.cast(local, C.POINTER(C.c_uint8)), rotary_dim=cfg.rotary_dim if gptj else 0)
+                         layer_is_local=C.cast(local, C.POINTER(C.c_uint8)), rotary_dim=cfg.rotary_dim if gptj else 0,
+                         qk_split=1 if precise_qk else 0)
+        self.precise_qk = bool(precise_qk)
         if gptj:
             weights = dict(weights)
             weights["rotary.sin"], weights["rotary.cos"] = rotary_tables(cfg.max_position_embeddings, cfg.rotary_dim)

@@ -35,10 +35,10 @@ def oracle_cfg_weights(cfg_kw, seed, std, bf16_linear=False):
     return cfg, O.synth_weights(cfg, seed=seed, std=std, bf16_linear=bf16_linear)
 
 
-def build_model(cfg_kw, seed, std, dtype):
+def build_model(cfg_kw, seed, std, dtype, precise_qk=False):
     """SGPTModel on cuda:0 with the oracle's seeded synthetic weights (cached per test session)."""
     from sgpt_amd import SGPTConfig, SGPTModel
-    key = (repr(sorted(cfg_kw.items())), seed, std, dtype)
+    key = (repr(sorted(cfg_kw.items())), seed, std, dtype, precise_qk)
     if key not in _models:
         _, w = oracle_cfg_weights(cfg_kw, seed, std)
         if "n_embd" in cfg_kw:
@@ -47,7 +47,7 @@ def build_model(cfg_kw, seed, std, dtype):
             scfg = SGPTConfig.from_hf_dict(dict(cfg_kw, model_type="bloom"))
         else:
             scfg = SGPTConfig(**cfg_kw)
-        _models[key] = SGPTModel(scfg, w, device="cuda:0", dtype=dtype)
+        _models[key] = SGPTModel(scfg, w, device="cuda:0", dtype=dtype, precise_qk=precise_qk)
     return _models[key]
 
 

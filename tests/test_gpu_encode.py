@@ -165,6 +165,39 @@ def test_f16_range_shifts_cover_outliers_and_the_guard_stays_loud():
     ok.close()
 
 
+@pytest.mark.parametrize("tag", ["tiny_right", "tiny_left", "tiny_gptj_right", "tiny_bloom_left", "cfg3_125m_specb_s300"])
+def test_precise_qk_split_projection_vs_reference(tag):
+    """SGPTModel(precise_qk=True): LayerNorm output and Wq / Wk as hi + lo pairs through ONE GEMM over K' = 3d.  Same
+    interface, every family; against the reference fixtures it must be at least as close as the plain f16 path (it removes
+    two of the three roundings on the way to q and k) and close to it (the other roundings are untouched)."""
+    fx, cfg_kw, seqs, pad_left, *_ = load_case(tag)
+    ref = fx["emb_weightedmean"]
+    plain = build_model(cfg_kw, int(fx["seed"]), float(fx["std"]), "f16")
+    from sgpt_amd import SGPTConfig, SGPTModel
+    from helpers import oracle_cfg_weights
+    _, w = oracle_cfg_weights(cfg_kw, int(fx["seed"]), float(fx["std"]))
+    if "n_embd" in cfg_kw:
+        scfg = SGPTConfig.from_hf_dict(dict(cfg_kw, model_type="gptj"))
+    elif "n_layer" in cfg_kw:
+        scfg = SGPTConfig.from_hf_dict(dict(cfg_kw, model_type="bloom"))
+    else:
+        scfg = SGPTConfig(**cfg_kw)
+    m = SGPTModel(scfg, w, device="cuda:0", dtype="f16", precise_qk=True)
+    try:
+        got = m.encode_ids(seqs, pad_left=pad_left).cpu().numpy()
+        again = m.encode_ids(seqs[::-1], pad_left=pad_left[::-1]).cpu().numpy()[::-1]
+    finally:
+        m.close()
+    base = plain.encode_ids(seqs, pad_left=pad_left).cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    e_split, e_plain = maxabs(got, ref) / scale, maxabs(base, ref) / scale
+    print(f"{tag} precise_qk: max|emb-ref| / max|ref| = {e_split:.2e} (plain f16 {e_plain:.2e})")
+    assert np.isfinite(got).all() and e_split < 1.5 * e_plain + 1e-4 and e_split < TOL_F16_ABS
+    assert maxabs(got, base) / scale < 2 * TOL_F16_ABS
+    if all(p == 0 for p in pad_left):
+        assert np.array_equal(got, again)                      # batch order does not change the bits
+
+
 def test_encode_graph_replay_adapts_range_shifts():
     """A captured graph carries the range-shift factors as kernel arguments: when a replay overflows an f16 class, replay()
     raises that class's shift (the context generation moves), re-captures and runs again -- the rows equal the eager,

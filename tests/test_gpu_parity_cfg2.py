@@ -21,8 +21,8 @@ from oracle import sgpt_oracle as O
 pytestmark = pytest.mark.gpu
 
 BAR = 1e-3                                   # north_star tolerance
-BUDGET = {"f16": BAR, "bf16": 2.5e-3}        # max |cos - cos_ref| allowed per operand format
-TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
+BUDGET = {"f16": BAR, "f16+qk": BAR, "bf16": 2.5e-3}        # max |cos - cos_ref| allowed per operand format ("+qk": precise_qk)
+TORCH_DT = {"f16": torch.float16, "f16+qk": torch.float16, "bf16": torch.bfloat16}
 
 
 @pytest.fixture(scope="module")
@@ -30,12 +30,12 @@ def fx():
     return np.load(os.path.join(GOLDEN, "cfg2_125m_1024x128.npz"))
 
 
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dtype", ["f16", "f16+qk", "bf16"])
 def test_cfg2_cosine_and_ranked_top10_vs_reference(fx, dtype):
     from helpers import build_model
     from sgpt_amd import get_context
     ctx = get_context("cuda:0")
-    m = build_model(dict(O.SGPT_125M), 1, 0.02, dtype)
+    m = build_model(dict(O.SGPT_125M), 1, 0.02, dtype.split("+")[0], precise_qk=dtype.endswith("+qk"))
     m.max_tokens_per_call = 1024 * 128
     docs = fx["doc_ids"].astype(np.int64)                              # [1024, 128]
     qlens = fx["query_lens"].tolist()
@@ -78,5 +78,5 @@ def test_cfg2_cosine_and_ranked_top10_vs_reference(fx, dtype):
             assert ref_sorted[qi, 9] - ref_cos[qi, doc] < 2 * BUDGET[dtype], (qi, doc)
     print(f"cfg2 {dtype}: top-10 id overlap with the reference: mean {np.mean(overlap):.2f} / 10, min {min(overlap)}; "
           f"identical ranking for {int(sum(np.array_equal(idx[i], ref_top[i]) for i in range(len(queries))))} of {len(queries)} queries")
-    if dtype == "f16":
+    if dtype.startswith("f16"):
         assert np.mean(overlap) > 9.5
