@@ -11,7 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIXTURE = {"125m": "cfg2_125m_1024x128", "1.3b": "cfg3_neo13b_specb", "2.7b": None, "5.8b": "cfg4_gptj6b", "bloom-7b1": "cfg5_bloom7b1"}
-SPECS = ["125m f16", "125m bf16", "125m fp8mfma", "1.3b f16", "1.3b bf16", "2.7b f16", "5.8b f16", "5.8b bf16", "5.8b fp8mfma",
+# (1.3b / 2.7b f16: the model default there is the split-precision Q / K projection; "f16-qk" rows time the plain projection)
+SPECS = ["125m f16", "125m bf16", "125m fp8mfma", "1.3b f16", "1.3b f16-qk", "1.3b bf16", "2.7b f16", "2.7b f16-qk", "5.8b f16", "5.8b bf16", "5.8b fp8mfma",
          "bloom-7b1 f16", "bloom-7b1 bf16", "bloom-7b1 fp8", "bloom-7b1 fp8mfma"]
 parity = {}
 for ln in open(sys.argv[1]):
@@ -21,7 +22,8 @@ with open(sys.argv[2], "w") as out:
     for spec in SPECS:
         model, dtype = spec.split()
         ch = "4096" if model == "125m" else "1024"
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", model, "--dtype", dtype, "--steps", "3", "--warmup", "1",
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", model, "--dtype", dtype.split("-")[0],
+                            "--precise-qk", "off" if dtype.endswith("-qk") else "auto", "--steps", "3", "--warmup", "1",
                             "--chunk", ch, "--no-cpu-baseline", "--no-1m", "--no-varlen"], capture_output=True, text=True, timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if not line:
