@@ -228,7 +228,8 @@ def _text_search_worker(rank, world, port, out, n_docs, n_queries, chunk, top_k,
 
 
 @pytest.mark.timeout(240)
-@pytest.mark.parametrize("n_docs,n_queries,chunk,fn", [(137, 21, 50, "cos_sim"), (137, 21, 50, "dot"), (1, 9, 50, "cos_sim")])
+@pytest.mark.parametrize("n_docs,n_queries,chunk,fn", [(137, 21, 50, "cos_sim"), (137, 21, 50, "dot"), (1, 9, 50, "cos_sim"),
+                                                       (60, 1, 7, "cos_sim")])      # 3 queries < 4 per rank: every rank encodes them all
 def test_two_rank_text_search_equals_single_process(n_docs, n_queries, chunk, fn):
     """DenseRetrievalExactSearch.search under torch.distributed: token-balanced contiguous corpus
     ranges, sharded query encode + one all-gather, local top-(k+1) with global indices, exchange + merge -- the dict every
@@ -252,3 +253,22 @@ def test_two_rank_text_search_equals_single_process(n_docs, n_queries, chunk, fn
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == n_docs       # a partition of the corpus
     if n_docs == 1:
         assert ranges[0][1] - ranges[0][0] == 0 or ranges[1][1] - ranges[1][0] == 0          # one rank had nothing to score
+
+
+def test_balanced_cuts_properties():
+    """Property test: the cuts are a monotone partition, a pure function of (weights, world), and no rank is heavier than the
+    mean by more than the heaviest item."""
+    from hypothesis import given, settings, strategies as st
+    from sgpt_amd.dist import balanced_cuts
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(min_value=1, max_value=2048), min_size=0, max_size=300), st.integers(min_value=1, max_value=9))
+    def check(weights, world):
+        c = balanced_cuts(weights, world)
+        assert c.shape == (world + 1,) and c[0] == 0 and c[-1] == len(weights) and (np.diff(c) >= 0).all()
+        assert np.array_equal(c, balanced_cuts(list(weights), world))
+        if weights:
+            w = np.asarray(weights)
+            load = np.array([w[c[r]: c[r + 1]].sum() for r in range(world)], dtype=np.float64)
+            assert load.sum() == w.sum() and load.max() <= w.sum() / world + w.max()
+    check()
