@@ -371,7 +371,8 @@ sgpt_status sgpt_prof_read(sgpt_ctx* ctx, int64_t* launches, double* ms, double*
 /* Per-ctx run-time policies (the library holds no process-global mutable state and reads no environment variable).
  * sgpt_ctx_set_low_latency: on = 1 lets GEMM launches that have fewer 64x64 tiles than workgroup slots (query-sized batches)
  *   split each tile's k range over two groups of waves that run concurrently and add their fp32 accumulators in a fixed
- *   order: a 16-query SGPT-125M encode drops from 1.05 to 0.88 ms.  Deterministic, but the sum is no longer the k-ascending
+ *   order (launches with >= 6 k-steps of 128 elements per group).  It was worth 16 % on a 16-query SGPT-125M encode before
+ *   the query-sized launches got 128-element k-steps (round 3), ~1 % since (0.82 -> 0.81 ms).  Deterministic, but the sum is no longer the k-ascending
  *   one every other kernel produces, so with the mode on an embedding depends (at 16-bit operand-rounding level, <= 5e-4 on
  *   normalised bf16 embeddings) on whether its batch was small enough to take this path.  Off (default), every batch size
  *   produces identical bits.  Returns the previous setting.

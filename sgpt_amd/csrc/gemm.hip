@@ -38,6 +38,12 @@ constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 #ifndef SGPT_SMALL_PF
 #define SGPT_SMALL_PF 2
 #endif
+#ifndef SGPT_DEEP_TILES
+#define SGPT_DEEP_TILES 512
+#endif
+#ifndef SGPT_KG16_MIN
+#define SGPT_KG16_MIN 6
+#endif
 constexpr int CH = 8;  // 16-byte chunks per row per k-step
 
 // A/B switches of the measurement scripts exist only in the experiment build (`SGPT_EXPERIMENTS=1 python -m sgpt_amd.build`
@@ -106,14 +112,17 @@ template <> struct OutRange<f16_t> { typedef RangeTrack<f16_t> type; };
 // order, no atomics, nothing leaves the CU); the sum differs from the k-ascending one only by fp32 rounding.
 // (A split over several workgroups per tile with a ticket counter was tried first: the device-scope fences it needs
 // write back the XCD's L2 once per workgroup and cost 58 us per launch -- 4x slower than not splitting.)
-template <typename T, int EPI, typename OutT, bool SWAP, int NI, int KG>
+template <typename T, int EPI, typename OutT, bool SWAP, int NI, int KG, int CHS = CH>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const GemmArgs p) {
+    // CHS = 16-byte chunks per LDS row = k-step depth (8: 64 16-bit elements; 16: 128, the query-sized launches' setting)
     constexpr int BM = 32 * NI, BN = 32 * NI;
+    constexpr int NP = NI * CHS / 8;          // load passes: 256 threads cover 256 / CHS rows x CHS chunks per pass
+    constexpr int RPP = 256 / CHS;
     if (p.pred != nullptr && *p.pred == 0) return;   // predicated (fallback) launch that is not needed
     constexpr int EPC = ElemTraits<T>::EPC;
-    constexpr int BK = CH * EPC;
+    constexpr int BK = CHS * EPC;
     static_assert(KG == 1 || NI == 2, "k-groups are for the 64x64 tile (32 KiB of LDS per group)");
-    __shared__ __attribute__((aligned(16))) uint4 lds_all[KG][2][2][BM * CH];  // 64 KiB (128x128) / 32 KiB per group (64x64)
+    __shared__ __attribute__((aligned(16))) uint4 lds_all[KG][2][2][BM * CHS];  // 64 KiB (128x128) / 32 or 64 KiB per group (64x64)
     const int kg = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
     auto& lds = lds_all[kg];
 
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int t = threadIdx.x & 255;
-    const int lr = t >> 3, lc = t & 7;
+    const int lr = t / CHS, lc = t % CHS;
     const T* __restrict__ Ag = static_cast<const T*>(p.A);
     const T* __restrict__ Wg = static_cast<const T*>(p.W);
     // group kg covers k-steps [kb, kb + nk); the launcher picks KG > 1 only when the steps divide evenly, so every group
@@ -144,11 +153,11 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
     const int nk = (K + BK - 1) / BK / KG;
     const int kb = kg * nk;
 
-    long arow[NI], wrow[NI];
+    long arow[NP], wrow[NP];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        int ra = m0 + lr + 32 * i; ra = ra < M ? ra : M - 1;
-        int rw = n0 + lr + 32 * i; rw = rw < N ? rw : N - 1;
+    for (int i = 0; i < NP; ++i) {
+        int ra = m0 + lr + RPP * i; ra = ra < M ? ra : M - 1;
+        int rw = n0 + lr + RPP * i; rw = rw < N ? rw : N - 1;
         arow[i] = (long)ra * p.lda;
         wrow[i] = (long)rw * p.ldw;
     }
@@ -158,20 +167,20 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
     // in flight every k-step cost exactly that (fc2 at 512 tokens: 48 steps = 63 us for 2.4 GFLOP); with PF in flight
     // the steady state is latency / PF.  Order of the MFMA operations per output element is unchanged (k ascending).
     constexpr int PF = SGPT_SMALL_PF;
-    uint4 ra_[PF][NI], rw_[PF][NI];
+    uint4 ra_[PF][NP], rw_[PF][NP];
     auto gload = [&](int set, int kt) {
         kt += kb;
         const int kc = kt * BK + lc * EPC;
         if (kt * BK + BK <= K) {  // block-uniform: full k-step (every encoder GEMM)
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 ra_[set][i] = *reinterpret_cast<const uint4*>(Ag + arow[i] + kc);
                 rw_[set][i] = *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc);
             }
         } else {  // K tail (scoring with d not a multiple of the k-step): zero-fill chunks past K
             const bool ok = kc < K;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 ra_[set][i] = ok ? *reinterpret_cast<const uint4*>(Ag + arow[i] + kc) : make_uint4(0, 0, 0, 0);
                 rw_[set][i] = ok ? *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc) : make_uint4(0, 0, 0, 0);
             }
@@ -180,16 +189,16 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
     auto gload_full = [&](int set, int kt) {
         const int kc = (kb + kt) * BK + lc * EPC;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int i = 0; i < NP; ++i) {
             ra_[set][i] = *reinterpret_cast<const uint4*>(Ag + arow[i] + kc);
             rw_[set][i] = *reinterpret_cast<const uint4*>(Wg + wrow[i] + kc);
         }
     };
     auto lstore = [&](int set, int buf) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int row = lr + 32 * i;
-            const int off = row * CH + (lc ^ (row & 7));
+        for (int i = 0; i < NP; ++i) {
+            const int row = lr + RPP * i;
+            const int off = row * CHS + (lc ^ (row & (CHS - 1)));
             lds[buf][0][off] = ra_[set][i];
             lds[buf][1][off] = rw_[set][i];
         }
@@ -206,17 +215,17 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int buf) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < CHS / 4; ++ks) {
             uint4 af[NI], wf[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int row = wm * (16 * NI) + i * 16 + fr;
-                af[i] = lds[buf][0][row * CH + ((4 * ks + g) ^ (row & 7))];
+                af[i] = lds[buf][0][row * CHS + ((4 * ks + g) ^ (row & (CHS - 1)))];
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int row = wn * (16 * NI) + j * 16 + fr;
-                wf[j] = lds[buf][1][row * CH + ((4 * ks + g) ^ (row & 7))];
+                wf[j] = lds[buf][1][row * CHS + ((4 * ks + g) ^ (row & (CHS - 1)))];
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
     __syncthreads();
     int k0 = 0;
     // steady state: every step prefetches a full k-step and hands one to LDS -- no conditions inside, so the compiler's
-    // s_waitcnt placement stays counted (vmcnt(2 * NI * (PF - 1))) instead of collapsing to vmcnt(0) at block merges
+    // s_waitcnt placement stays counted (vmcnt(2 * NP * (PF - 1))) instead of collapsing to vmcnt(0) at block merges
     for (; k0 + 2 * PF < nk; k0 += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {        // register-set indices are compile-time after unrolling
@@ -818,21 +827,30 @@ void launch(const GemmArgs& a, hipStream_t s) {
     const int mt_per_xcd = (MT + 7) / 8;
     const int bands = (mt_per_xcd + 7) / 8;
     const int grid = 8 * bands * 8 * NT;
+    // Query-sized launches (at most one resident round of 64x64 tiles: 2 workgroups x 256 CUs) walk 128-element k-steps
+    // (CHS = 16): half as many load -> LDS -> MFMA round trips on each tile's serial chain, same MFMA order per output
+    // element, so results stay bit-identical.  16-query encode (512 token rows) 0.97 -> 0.82 ms; with more tiles than that
+    // the 64-KiB stages cost occupancy instead (3072 rows: 1.77 -> 1.85 ms), so those keep 64-element steps.  Threshold
+    // sweep 256 / 512 / 1024 tiles and 256-element steps (128 KiB of LDS, slower everywhere): profiles/r03_small_kstep_ab.txt.
+    const long tiles = (long)MT * NT;
+    const bool deep = small && tiles <= SGPT_DEEP_TILES;
     // two k-groups (split-K inside the workgroup, see gemm_kernel) when the 64x64 tiles leave workgroup slots empty (two
-    // 512-thread workgroups fit a CU); each group keeps >= 3 k-steps.  Measured on a 16-query encode (512 token rows):
-    // 1.05 -> 0.88 ms; four groups (one 1024-thread workgroup per CU) gave 0.90.  OFF by default: it trades the
-    // bit-identical-across-batch-sizes property for latency (per ctx: sgpt_ctx_set_low_latency -> GemmArgs.kgroups).
+    // 512-thread workgroups fit a CU).  OFF by default: it trades the bit-identical-across-batch-sizes property for
+    // latency (per ctx: sgpt_ctx_set_low_latency -> GemmArgs.kgroups).
     const int kgmax = a.kgroups;
     constexpr bool splittable = EPI != EPI_SCORE && EPI != EPI_SCORE_FILTER;
-    const int nkt = (a.K + CH * ElemTraits<T>::EPC - 1) / (CH * ElemTraits<T>::EPC);
-    const long tiles = (long)MT * NT;
-    int KG = 1;
-    if (small && splittable && kgmax >= 2 && tiles <= 512 && nkt % 2 == 0 && nkt / 2 >= 3) KG = 2;
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int nkt16 = (a.K + 16 * EPC - 1) / (16 * EPC);
     if constexpr (splittable) {
-        if (KG == 2) { hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 2, 2>), dim3(grid), dim3(512), 0, s, a); return; }
+        if (deep && kgmax >= 2) {
+            if (nkt16 % 2 == 0 && nkt16 / 2 >= SGPT_KG16_MIN) {
+                hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 2, 2, 16>), dim3(grid), dim3(512), 0, s, a); return;
+            }
+        }
     }
-    if (small) hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 2, 1>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 4, 1>), dim3(grid), dim3(256), 0, s, a);
+    if (deep) hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 2, 1, 16>), dim3(grid), dim3(256), 0, s, a);
+    else if (small) hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 2, 1, 8>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<T, EPI, OutT, SWAP, 4, 1, 8>), dim3(grid), dim3(256), 0, s, a);
 }
 
 // 16-bit operand format H (bf16_t | f16_t): the 256x256 LDS-DMA kernel where the shape allows, else the register-staged one

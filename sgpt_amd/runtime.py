@@ -126,8 +126,8 @@ class Context:
         return int(self.lib.sgpt_ctx_generation(self.handle))
 
     def set_low_latency(self, on: bool) -> bool:
-        """Per context: k-groups for query-sized GEMM launches (include/sgpt_hip.h::sgpt_ctx_set_low_latency): ~16 % off a
-        16-query encode, at the price of bit-identical embeddings across batch sizes.  Returns the previous setting."""
+        """Per context: k-groups for query-sized GEMM launches (include/sgpt_hip.h::sgpt_ctx_set_low_latency): ~1 % off a
+        16-query encode since round 3 (16 % before), at the price of bit-identical embeddings across batch sizes.  Returns the previous setting."""
         return bool(self.lib.sgpt_ctx_set_low_latency(self.handle, 1 if on else 0))
 
     def set_tile_policy(self, force_256: bool) -> bool:
