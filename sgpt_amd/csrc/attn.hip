@@ -20,6 +20,9 @@
 
 #include "common.h"
 
+#ifndef SGPT_ATTN_STAGES
+#define SGPT_ATTN_STAGES 1
+#endif
 #ifndef SGPT_ATTN_NT_LOAD
 #define SGPT_ATTN_NT_LOAD 1   // K / V^T tiles are read once per (sequence, head): non-temporal loads (+0.2 % end to end)
 #endif
@@ -51,8 +54,9 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
     constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
     constexpr int NT = 512, QB = 128;                          // 8 waves x 16 queries per block
     constexpr int ORS = DH * 2 + 16;                           // output-transpose row stride (bytes)
-    __shared__ __attribute__((aligned(16))) uint4 Ks[64 * CPR];
-    __shared__ __attribute__((aligned(16))) uint4 Vs[DH * 8];
+    constexpr int NB = (DH <= 64 && SGPT_ATTN_STAGES == 2) ? 2 : 1;   // LDS stages of the K / V^T tiles
+    __shared__ __attribute__((aligned(16))) uint4 Ks[NB][64 * CPR];
+    __shared__ __attribute__((aligned(16))) uint4 Vs[NB][DH * 8];
     __shared__ __attribute__((aligned(16))) char Os[8][16 * ORS];
     const int sq = blockIdx.z, head = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -101,13 +105,11 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
             if (c < DH * 8) vreg[u] = ldg16u<ATTN_NT_LOAD>(vt + (long)row * p.ldvt + s0 + j0 + ch * 8);
         }
     };
-    if (j_lo <= j_hi) tile_load(j_lo);
-    for (int j0 = j_lo; j0 <= j_hi; j0 += 64) {
-        __syncthreads();                             // previous tile fully consumed
+    auto tile_store = [&](int b) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int c = t + NT * u, row = c / CPR, ch = c % CPR;
-            if (c < 64 * CPR) Ks[row * CPR + (ch ^ (row & 7))] = kreg[u];
+            if (c < 64 * CPR) Ks[b][row * CPR + (ch ^ (row & 7))] = kreg[u];
         }
 #pragma unroll
         for (int u = 0; u < VU; ++u) {
@@ -118,14 +120,31 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
                 // MFMA, so a fragment is ONE ds_read_b128 (it was two ds_read_b64 from chunks two apart, and with them most
                 // of this kernel's time at S >= 256).  The 16 loaded bytes (keys 8ch..8ch+7) go to two chunks, 8 bytes each.
                 const int blk = ch >> 2, w = ch & 3, hf = w >> 1, g0 = 2 * (w & 1);
-                char* vrow = reinterpret_cast<char*>(&Vs[row * 8]);
+                char* vrow = reinterpret_cast<char*>(&Vs[b][row * 8]);
                 *reinterpret_cast<uint2*>(vrow + ((4 * blk + g0) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vreg[u].x, vreg[u].y);
                 *reinterpret_cast<uint2*>(vrow + ((4 * blk + g0 + 1) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vreg[u].z, vreg[u].w);
             }
         }
-        __syncthreads();
-        if (j0 + 64 <= j_hi) tile_load(j0 + 64);     // next tile's loads fly under this tile's MFMAs and softmax
-        if (!wave_on || j0 > q0 + 15) continue;      // nothing visible for this wave in this tile
+    };
+    // NB = 2 (DH = 64): two LDS stages, ONE barrier per key tile -- tile j+1 is written into the other stage behind tile
+    // j's MFMAs, and the barrier at the end of the step both publishes it and retires stage j.  NB = 1 (wider heads, where
+    // a second stage would cost a resident workgroup): store, barrier, consume, barrier.
+    int cur = 0;
+    if (j_lo <= j_hi) {
+        tile_load(j_lo);
+        if constexpr (NB == 2) { tile_store(0); __syncthreads(); }
+    }
+    for (int j0 = j_lo; j0 <= j_hi; j0 += 64) {
+        if constexpr (NB == 1) {
+            __syncthreads();                         // previous tile fully consumed
+            tile_store(0);
+            __syncthreads();
+        }
+        const bool more = j0 + 64 <= j_hi;
+        if (more) tile_load(j0 + 64);                // next tile's loads fly under this tile's MFMAs and softmax
+        if (wave_on && j0 <= q0 + 15) {              // else: nothing visible for this wave in this tile
+        const uint4* __restrict__ Kc = Ks[cur];
+        const uint4* __restrict__ Vc = Vs[cur];
         // ---- S^T = K.Q^T : 4 tiles of [16 keys][16 queries] ----
         f32x4 s[4];
 #pragma unroll
@@ -134,36 +153,54 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
             const int row = nt * 16 + fr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const uint4 kv = Ks[row * CPR + ((ks * 4 + g) ^ (row & 7))];
+                const uint4 kv = Kc[row * CPR + ((ks * 4 + g) ^ (row & 7))];
                 s[nt] = Half<H>::mfma16(kv, qf[ks], s[nt]);
             }
         }
-        // (Measured at S = 512, where this kernel is 19 % of a step and neither HBM- nor MFMA-bound -- 657 us per 131 072
-        // tokens against 60 us of MFMA issue: skipping the mask on fully visible tiles and a log2-domain softmax (one
-        // multiply less per score) changed nothing; asking for 6 or 8 waves per SIMD instead of 4 spills and costs 30-40 %.
-        // What is left is the two barriers per 64-key tile with two workgroups per CU.)
+        // Softmax in the log2 domain: t = s * (scale * log2 e) [+ alibi * log2 e], p = 2^(t - m).  SQ counters at S = 512
+        // (profiles/r03_attn_pmc.txt) put this kernel's VALU at 77 % busy with 4 waves per SIMD -- 255 VALU instructions per
+        // 64-key tile and wave, half of them the per-score mask (key index, two compares, select, int -> float for the
+        // ALiBi term).  A tile every query of the fragment sees whole (all but the diagonal tile of a fragment, and the
+        // window's low edge) takes the lean path: one multiply per score.  Elsewhere the compares run against
+        // compile-time offsets of one per-lane distance.
+        const float c2 = p.scale * 1.44269504088896341f;
+        // (DH = 128: the second code path costs 14 spilled VGPRs at 4 waves per SIMD -- lean path for DH = 64 only)
+        const bool full = DH <= 64 && (j0 + 63 <= q0) && (p.window <= 0 || j0 > q0 + 15 - p.window);
         float mx = -INFINITY;
+        if (full && slope == 0.f) {                  // wave-uniform
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kj = j0 + nt * 16 + 4 * g + r;
-                const bool vis = (kj <= qi) && (p.window <= 0 || kj > qi - p.window);
-                const float v = vis ? s[nt][r] * p.scale + slope * (float)kj : -INFINITY;
-                s[nt][r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 4; ++r) s[nt][r] *= c2;
+                mx = fmaxf(mx, fmaxf(fmaxf(s[nt][0], s[nt][1]), fmaxf(s[nt][2], s[nt][3])));
             }
+        } else {
+            const int dq = qi - (j0 + 4 * g);         // key offset o = 16 nt + r is visible iff o <= dq (and o > dq - window)
+            const int dw = p.window > 0 ? dq - p.window : -(1 << 30);
+            const float s2 = slope * 1.44269504088896341f;
+            const float ab = s2 * (float)(j0 + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = nt * 16 + r;
+                    const bool vis = (o <= dq) && (o > dw);
+                    const float v = vis ? __builtin_fmaf(s[nt][r], c2, __builtin_fmaf(s2, (float)o, ab)) : -INFINITY;
+                    s[nt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float ps = 0.f;
         uint32_t pw[8];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const float e0 = __expf(s[nt][0] - m_new), e1 = __expf(s[nt][1] - m_new);
-            const float e2 = __expf(s[nt][2] - m_new), e3 = __expf(s[nt][3] - m_new);
+            const float e0 = __builtin_amdgcn_exp2f(s[nt][0] - m_new), e1 = __builtin_amdgcn_exp2f(s[nt][1] - m_new);
+            const float e2 = __builtin_amdgcn_exp2f(s[nt][2] - m_new), e3 = __builtin_amdgcn_exp2f(s[nt][3] - m_new);
             ps += (e0 + e1) + (e2 + e3);
             pw[nt * 2] = Half<H>::pack2(e0, e1);          // probabilities in [0, 1]: inside either format's range
             pw[nt * 2 + 1] = Half<H>::pack2(e2, e3);
@@ -182,9 +219,15 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
             for (int dt = 0; dt < DT; ++dt) {
                 const int row = dt * 16 + fr;
                 // chunk 4*step + g of the k-slot-permuted row = this lane group's eight k-slots (see the staging store)
-                const uint4 vu = Vs[row * 8 + ((4 * step + g) ^ (row & 7))];
+                const uint4 vu = Vc[row * 8 + ((4 * step + g) ^ (row & 7))];
                 o[dt] = Half<H>::mfma16(vu, pu, o[dt]);
             }
+        }
+        }
+        if constexpr (NB == 2) {
+            if (more) tile_store(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
         }
     }
     if (!wave_on) return;
