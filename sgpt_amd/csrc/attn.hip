@@ -20,6 +20,18 @@
 
 #include "common.h"
 
+#ifndef SGPT_ATTN_PERMLANE
+#define SGPT_ATTN_PERMLANE 1
+#endif
+#ifndef SGPT_ATTN_Q32
+#define SGPT_ATTN_Q32 0   // 1: also build / use the two-fragments-per-wave variant for head_dim 64 (A/B builds)
+#endif
+#ifndef SGPT_ATTN_Q32_WAVES
+#define SGPT_ATTN_Q32_WAVES 3   // 4-wave blocks: resident blocks per CU
+#endif
+#ifndef SGPT_ATTN_Q32_MINLEN
+#define SGPT_ATTN_Q32_MINLEN 64
+#endif
 #ifndef SGPT_ATTN_STAGES
 #define SGPT_ATTN_STAGES 1
 #endif
@@ -39,6 +51,23 @@ namespace {
 #endif
 constexpr bool ATTN_NT = SGPT_ATTN_NT != 0;
 
+// max over the four 16-lane rows of a wave (lane ^ 16, lane ^ 32) with gfx950's VALU row swaps instead of two ds_bpermute
+// round trips through the LDS queue: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of
+// its second, v_permlane32_swap the upper half of the first with the lower half of the second.
+#if SGPT_ATTN_PERMLANE
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+#else
+__device__ __forceinline__ float xor16_max(float v) { return fmaxf(v, __shfl_xor(v, 16, 64)); }
+__device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+#endif
+
 // ---- K / V^T tiles of 64 keys staged in LDS and shared by the block's 8 waves ----
 // (A direct-from-global predecessor re-fetched every K/V fragment once per wave with 16 scattered 64-byte pieces
 // per instruction and one dependent global round trip per 8 MFMAs: 2.4 % MFMA-busy; removed in round 2.)
@@ -49,22 +78,26 @@ constexpr bool ATTN_NT = SGPT_ATTN_NT != 0;
 // and every wave takes its MFMA operands from there.  Same math / lane maps as above.
 // H = bf16_t | f16_t: the 16-bit format of q / k / V^T, of the probabilities fed to the P.V MFMA and of the context
 // OUT8: the context leaves as e4m3 codes of ctx / out_scale (fp8 out-projection operand) instead of the 16-bit format
-template <typename H, int DH, bool OUT8>
-__global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(const AttnArgs p) {
+// NQ = 16-query fragments per wave.  NQ = 1: 8 waves x 16 queries.  NQ = 2 (DH = 64): 4 waves x 32 queries -- every K / V^T
+// fragment read from LDS feeds two MFMAs, halving the LDS bytes per query; the SQ counters at S = 512 put the LDS array
+// right behind the VALU as this kernel's busiest unit (profiles/r03_attn_pmc.txt).
+template <typename H, int DH, bool OUT8, int NQ>
+__global__ __launch_bounds__(NQ == 1 ? 512 : 256, NQ == 1 ? ATTN_WAVES_PER_SIMD : SGPT_ATTN_Q32_WAVES) void attn16_lds_kernel(const AttnArgs p) {
     constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
-    constexpr int NT = 512, QB = 128;                          // 8 waves x 16 queries per block
+    constexpr int NW = NQ == 1 ? 8 : 4;                        // waves per block
+    constexpr int NT = 64 * NW, QW = 16 * NQ, QB = 128;        // QW queries per wave, QB = NW * QW per block
     constexpr int ORS = DH * 2 + 16;                           // output-transpose row stride (bytes)
     constexpr int NB = (DH <= 64 && SGPT_ATTN_STAGES == 2) ? 2 : 1;   // LDS stages of the K / V^T tiles
     __shared__ __attribute__((aligned(16))) uint4 Ks[NB][64 * CPR];
     __shared__ __attribute__((aligned(16))) uint4 Vs[NB][DH * 8];
-    __shared__ __attribute__((aligned(16))) char Os[8][16 * ORS];
+    __shared__ __attribute__((aligned(16))) char Os[NW][16 * ORS];
     const int sq = blockIdx.z, head = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int s0 = p.seq_off[sq];
     const int alloc = p.seq_off[sq + 1] - s0;
     const int qb0 = blockIdx.x * QB;
     if (qb0 >= alloc) return;                       // whole block out of range (uniform)
-    const int q0 = qb0 + wave * 16;
+    const int q0 = qb0 + wave * QW;
     const bool wave_on = q0 < alloc;
     const int fr = lane & 15, g = lane >> 4;
 
@@ -72,16 +105,22 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
     const bf16_t* __restrict__ kb = static_cast<const bf16_t*>(p.k) + (long)head * DH;
     const bf16_t* __restrict__ vt = static_cast<const bf16_t*>(p.v) + (long)head * DH * p.ldvt;
 
-    uint4 qf[KS];
+    // (query rows past the allocation belong to the next sequence or to the padding of the token axis: loaded, never stored)
+    uint4 qf[NQ][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        qf[ks] = *reinterpret_cast<const uint4*>(qb + (long)(s0 + q0 + fr) * p.ldq + ks * 32 + 8 * g);
+    for (int f = 0; f < NQ; ++f)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            qf[f][ks] = *reinterpret_cast<const uint4*>(qb + (long)(s0 + q0 + 16 * f + fr) * p.ldq + ks * 32 + 8 * g);
 
-    f32x4 o[DT];
+    f32x4 o[NQ][DT];
+    float m_run[NQ], l_run[NQ];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -1e30f, l_run = 0.f;
-    const int qi = q0 + fr;
+    for (int f = 0; f < NQ; ++f) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[f][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run[f] = -1e30f; l_run[f] = 0.f;
+    }
     const float slope = p.alibi ? p.alibi[head] : 0.f;
 
     int j_lo = 0;
@@ -126,14 +165,16 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
             }
         }
     };
-    // NB = 2 (DH = 64): two LDS stages, ONE barrier per key tile -- tile j+1 is written into the other stage behind tile
-    // j's MFMAs, and the barrier at the end of the step both publishes it and retires stage j.  NB = 1 (wider heads, where
-    // a second stage would cost a resident workgroup): store, barrier, consume, barrier.
+    // NB = 2: two LDS stages, ONE barrier per key tile -- tile j+1 is written into the other stage behind tile j's MFMAs,
+    // and the barrier at the end of the step both publishes it and retires stage j.  Measured: no gain (the waves do not
+    // wait for the barriers, profiles/r03_attn_pmc.txt), so NB = 1 is what ships: store, barrier, consume, barrier.
     int cur = 0;
     if (j_lo <= j_hi) {
         tile_load(j_lo);
         if constexpr (NB == 2) { tile_store(0); __syncthreads(); }
     }
+    const float c2 = p.scale * 1.44269504088896341f;
+    const float s2 = slope * 1.44269504088896341f;
     for (int j0 = j_lo; j0 <= j_hi; j0 += 64) {
         if constexpr (NB == 1) {
             __syncthreads();                         // previous tile fully consumed
@@ -142,19 +183,21 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
         }
         const bool more = j0 + 64 <= j_hi;
         if (more) tile_load(j0 + 64);                // next tile's loads fly under this tile's MFMAs and softmax
-        if (wave_on && j0 <= q0 + 15) {              // else: nothing visible for this wave in this tile
+        if (wave_on && j0 <= q0 + QW - 1) {          // else: nothing visible for this wave in this tile
         const uint4* __restrict__ Kc = Ks[cur];
         const uint4* __restrict__ Vc = Vs[cur];
-        // ---- S^T = K.Q^T : 4 tiles of [16 keys][16 queries] ----
-        f32x4 s[4];
+        // ---- S^T = K.Q^T : 4 tiles of [16 keys][16 queries] per fragment ----
+        f32x4 s[NQ][4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < NQ; ++f) s[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int row = nt * 16 + fr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const uint4 kv = Kc[row * CPR + ((ks * 4 + g) ^ (row & 7))];
-                s[nt] = Half<H>::mfma16(kv, qf[ks], s[nt]);
+#pragma unroll
+                for (int f = 0; f < NQ; ++f) s[f][nt] = Half<H>::mfma16(kv, qf[f][ks], s[f][nt]);
             }
         }
         // Softmax in the log2 domain: t = s * (scale * log2 e) [+ alibi * log2 e], p = 2^(t - m).  SQ counters at S = 512
@@ -163,64 +206,70 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
         // ALiBi term).  A tile every query of the fragment sees whole (all but the diagonal tile of a fragment, and the
         // window's low edge) takes the lean path: one multiply per score.  Elsewhere the compares run against
         // compile-time offsets of one per-lane distance.
-        const float c2 = p.scale * 1.44269504088896341f;
-        // (DH = 128: the second code path costs 14 spilled VGPRs at 4 waves per SIMD -- lean path for DH = 64 only)
-        const bool full = DH <= 64 && (j0 + 63 <= q0) && (p.window <= 0 || j0 > q0 + 15 - p.window);
-        float mx = -INFINITY;
-        if (full && slope == 0.f) {                  // wave-uniform
+        uint32_t pw[NQ][8];
+#pragma unroll
+        for (int f = 0; f < NQ; ++f) {
+            const int qf0 = q0 + 16 * f, qi = qf0 + fr;
+            // (DH = 128: the second code path costs 14 spilled VGPRs at 4 waves per SIMD -- lean path for DH = 64 only)
+            const bool full = DH <= 64 && (j0 + 63 <= qf0) && (p.window <= 0 || j0 > qf0 + 15 - p.window);
+            float mx = -INFINITY;
+            if (full && slope == 0.f) {                  // wave-uniform
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[f][nt][r] *= c2;
+                    mx = fmaxf(mx, fmaxf(fmaxf(s[f][nt][0], s[f][nt][1]), fmaxf(s[f][nt][2], s[f][nt][3])));
+                }
+            } else {
+                const int dq = qi - (j0 + 4 * g);         // key offset o = 16 nt + r is visible iff o <= dq (and o > dq - window)
+                const int dw = p.window > 0 ? dq - p.window : -(1 << 30);
+                const float ab = s2 * (float)(j0 + 4 * g);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int oo = nt * 16 + r;
+                        const bool vis = (oo <= dq) && (oo > dw);
+                        const float v = vis ? __builtin_fmaf(s[f][nt][r], c2, __builtin_fmaf(s2, (float)oo, ab)) : -INFINITY;
+                        s[f][nt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            }
+            mx = xor16_max(mx);                      // the other three lane groups' keys of this query: two VALU lane swaps
+            mx = xor32_max(mx);                      // (ds_bpermute round trips sat on every tile's dependent chain)
+            const float m_new = fmaxf(m_run[f], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+            m_run[f] = m_new;
+            float ps = 0.f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[nt][r] *= c2;
-                mx = fmaxf(mx, fmaxf(fmaxf(s[nt][0], s[nt][1]), fmaxf(s[nt][2], s[nt][3])));
+                const float e0 = __builtin_amdgcn_exp2f(s[f][nt][0] - m_new), e1 = __builtin_amdgcn_exp2f(s[f][nt][1] - m_new);
+                const float e2 = __builtin_amdgcn_exp2f(s[f][nt][2] - m_new), e3 = __builtin_amdgcn_exp2f(s[f][nt][3] - m_new);
+                ps += (e0 + e1) + (e2 + e3);
+                pw[f][nt * 2] = Half<H>::pack2(e0, e1);          // probabilities in [0, 1]: inside either format's range
+                pw[f][nt * 2 + 1] = Half<H>::pack2(e2, e3);
             }
-        } else {
-            const int dq = qi - (j0 + 4 * g);         // key offset o = 16 nt + r is visible iff o <= dq (and o > dq - window)
-            const int dw = p.window > 0 ? dq - p.window : -(1 << 30);
-            const float s2 = slope * 1.44269504088896341f;
-            const float ab = s2 * (float)(j0 + 4 * g);
+            l_run[f] = l_run[f] * alpha + ps;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = nt * 16 + r;
-                    const bool vis = (o <= dq) && (o > dw);
-                    const float v = vis ? __builtin_fmaf(s[nt][r], c2, __builtin_fmaf(s2, (float)o, ab)) : -INFINITY;
-                    s[nt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float ps = 0.f;
-        uint32_t pw[8];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const float e0 = __builtin_amdgcn_exp2f(s[nt][0] - m_new), e1 = __builtin_amdgcn_exp2f(s[nt][1] - m_new);
-            const float e2 = __builtin_amdgcn_exp2f(s[nt][2] - m_new), e3 = __builtin_amdgcn_exp2f(s[nt][3] - m_new);
-            ps += (e0 + e1) + (e2 + e3);
-            pw[nt * 2] = Half<H>::pack2(e0, e1);          // probabilities in [0, 1]: inside either format's range
-            pw[nt * 2 + 1] = Half<H>::pack2(e2, e3);
-        }
-        l_run = l_run * alpha + ps;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
+            for (int dt = 0; dt < DT; ++dt) {
+                o[f][dt][0] *= alpha; o[f][dt][1] *= alpha; o[f][dt][2] *= alpha; o[f][dt][3] *= alpha;
+            }
         }
         // ---- O^T += V^T . P^T, two 32-key steps; k-slot j <-> key 32*step + 16*(j>>2) + 4g + (j&3) ----
 #pragma unroll
         for (int step = 0; step < 2; ++step) {
-            uint4 pu;
-            pu.x = pw[step * 4]; pu.y = pw[step * 4 + 1]; pu.z = pw[step * 4 + 2]; pu.w = pw[step * 4 + 3];
+            uint4 pu[NQ];
+#pragma unroll
+            for (int f = 0; f < NQ; ++f) {
+                pu[f].x = pw[f][step * 4]; pu[f].y = pw[f][step * 4 + 1]; pu[f].z = pw[f][step * 4 + 2]; pu[f].w = pw[f][step * 4 + 3];
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int row = dt * 16 + fr;
                 // chunk 4*step + g of the k-slot-permuted row = this lane group's eight k-slots (see the staging store)
                 const uint4 vu = Vc[row * 8 + ((4 * step + g) ^ (row & 7))];
-                o[dt] = Half<H>::mfma16(vu, pu, o[dt]);
+#pragma unroll
+                for (int f = 0; f < NQ; ++f) o[f][dt] = Half<H>::mfma16(vu, pu[f], o[f][dt]);
             }
         }
         }
@@ -231,44 +280,52 @@ __global__ __launch_bounds__(512, ATTN_WAVES_PER_SIMD) void attn16_lds_kernel(co
         }
     }
     if (!wave_on) return;
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_run;
     // O^T tile dt: lane holds head-dim elements dt*16 + 4g + r of query fr.  Transpose through a per-wave
     // LDS slice so every store instruction writes whole rows with 16 B per lane (the direct
     // 8-B-per-lane form wrote 3.6x the bytes: 32-B pieces of 16 different lines per instruction).
+    // (The slice is private to the wave and LDS operations of one wave execute in order: fragment f + 1's writes queue
+    // behind fragment f's reads.)
     char* os = Os[wave];
-    if constexpr (OUT8) {
-        constexpr int ORS8 = DH + 16, CPR8 = DH / 16, RPI8 = 64 / CPR8;
-        const float sc = inv / p.out_scale;
-        float amax = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const float v0 = o[dt][0] * sc, v1 = o[dt][1] * sc, v2 = o[dt][2] * sc, v3 = o[dt][3] * sc;
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
-            *reinterpret_cast<uint32_t*>(os + fr * ORS8 + dt * 16 + 4 * g) = pack_fp8x4(v0, v1, v2, v3);
-        }
-        if (p.range_flag != nullptr && !(amax <= 448.f)) atomicOr(p.range_flag, 4);   // bit 2: attention context (bit 1: GELU output)
-        uint8_t* obase = static_cast<uint8_t*>(p.ctx) + (long)(s0 + q0) * p.ldo + (long)head * DH;
+    for (int f = 0; f < NQ; ++f) {
+        const int qf0 = q0 + 16 * f;
+        if (qf0 >= alloc) break;
+        float lr = l_run[f];
+        lr += __shfl_xor(lr, 16, 64);
+        lr += __shfl_xor(lr, 32, 64);
+        const float inv = 1.0f / lr;
+        if constexpr (OUT8) {
+            constexpr int ORS8 = DH + 16, CPR8 = DH / 16, RPI8 = 64 / CPR8;
+            const float sc = inv / p.out_scale;
+            float amax = 0.f;
 #pragma unroll
-        for (int h = 0; h < 16 / RPI8; ++h) {
-            const int row = h * RPI8 + lane / CPR8, ch = lane % CPR8;
-            const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS8 + ch * 16);
-            if (q0 + row < alloc) gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 16, v);   // rows past the allocation are the next sequence's
-        }
-    } else {
+            for (int dt = 0; dt < DT; ++dt) {
+                const float v0 = o[f][dt][0] * sc, v1 = o[f][dt][1] * sc, v2 = o[f][dt][2] * sc, v3 = o[f][dt][3] * sc;
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
+                *reinterpret_cast<uint32_t*>(os + fr * ORS8 + dt * 16 + 4 * g) = pack_fp8x4(v0, v1, v2, v3);
+            }
+            if (p.range_flag != nullptr && !(amax <= 448.f)) atomicOr(p.range_flag, 4);   // bit 2: attention context (bit 1: GELU output)
+            uint8_t* obase = static_cast<uint8_t*>(p.ctx) + (long)(s0 + qf0) * p.ldo + (long)head * DH;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            *reinterpret_cast<uint2_a*>(os + fr * ORS + (dt * 16 + 4 * g) * 2) =
-                make_uint2(Half<H>::pack2(o[dt][0] * inv, o[dt][1] * inv), Half<H>::pack2(o[dt][2] * inv, o[dt][3] * inv));   // a convex
-        // combination of V rows: bounded by max|V|, which the V projection's epilogue already range-checked (f16)
-        constexpr int RPI = 64 / CPR;                    // rows per store instruction
-        bf16_t* obase = static_cast<bf16_t*>(p.ctx) + (long)(s0 + q0) * p.ldo + (long)head * DH;
+            for (int h = 0; h < 16 / RPI8; ++h) {
+                const int row = h * RPI8 + lane / CPR8, ch = lane % CPR8;
+                const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS8 + ch * 16);
+                if (qf0 + row < alloc) gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 16, v);   // rows past the allocation are the next sequence's
+            }
+        } else {
 #pragma unroll
-        for (int h = 0; h < 16 / RPI; ++h) {
-            const int row = h * RPI + lane / CPR, ch = lane % CPR;
-            const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
-            if (q0 + row < alloc) gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);   // (allocations are multiples of 8 rows)
+            for (int dt = 0; dt < DT; ++dt)
+                *reinterpret_cast<uint2_a*>(os + fr * ORS + (dt * 16 + 4 * g) * 2) =
+                    make_uint2(Half<H>::pack2(o[f][dt][0] * inv, o[f][dt][1] * inv), Half<H>::pack2(o[f][dt][2] * inv, o[f][dt][3] * inv));   // a convex
+            // combination of V rows: bounded by max|V|, which the V projection's epilogue already range-checked (f16)
+            constexpr int RPI = 64 / CPR;                    // rows per store instruction
+            bf16_t* obase = static_cast<bf16_t*>(p.ctx) + (long)(s0 + qf0) * p.ldo + (long)head * DH;
+#pragma unroll
+            for (int h = 0; h < 16 / RPI; ++h) {
+                const int row = h * RPI + lane / CPR, ch = lane % CPR;
+                const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
+                if (qf0 + row < alloc) gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);   // (allocations are multiples of 8 rows)
+            }
         }
     }
 }
@@ -327,14 +384,26 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
 
 void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.max_alloc_len + 127) / 128, a.H, a.B);
-#define ATTN_CASE(H, O8)                                                                                   \
-    if (a.dh == 64) hipLaunchKernelGGL((attn16_lds_kernel<H, 64, O8>), grid, dim3(512), 0, s, a);          \
-    else if (a.dh == 128) hipLaunchKernelGGL((attn16_lds_kernel<H, 128, O8>), grid, dim3(512), 0, s, a);   \
-    else if (a.dh == 256) hipLaunchKernelGGL((attn16_lds_kernel<H, 256, O8>), grid, dim3(512), 0, s, a);   \
+#if SGPT_ATTN_Q32
+    // head_dim 64: two 16-query fragments per wave (4-wave blocks of the same 128 queries) once sequences have more than one
+    // 64-key tile.  Measured against eight 16-query waves: seq 512 +0.6 %, seq 300 -0.4 %, seq 128 -0.3 % at three blocks per
+    // CU, -5 % at two (profiles/r03_attn_pmc.txt) -- what the second fragment adds in independent work per wave it takes
+    // away in resident waves.  Not used by default.
+    const bool q32 = a.max_alloc_len > SGPT_ATTN_Q32_MINLEN;
+#define ATTN_Q32_CASE(H, O8) if (a.dh == 64 && q32) hipLaunchKernelGGL((attn16_lds_kernel<H, 64, O8, 2>), grid, dim3(256), 0, s, a); else
+#else
+#define ATTN_Q32_CASE(H, O8)
+#endif
+#define ATTN_CASE(H, O8)                                                                                          \
+    ATTN_Q32_CASE(H, O8)                                                                                          \
+    if (a.dh == 64) hipLaunchKernelGGL((attn16_lds_kernel<H, 64, O8, 1>), grid, dim3(512), 0, s, a);          \
+    else if (a.dh == 128) hipLaunchKernelGGL((attn16_lds_kernel<H, 128, O8, 1>), grid, dim3(512), 0, s, a);        \
+    else if (a.dh == 256) hipLaunchKernelGGL((attn16_lds_kernel<H, 256, O8, 1>), grid, dim3(512), 0, s, a);        \
     else abort();
     if (a.out_fp8) { ATTN_CASE(bf16_t, true) }
     else if (a.dtype == DT_F16) { ATTN_CASE(f16_t, false) } else { ATTN_CASE(bf16_t, false) }
 #undef ATTN_CASE
+#undef ATTN_Q32_CASE
 }
 
 void launch_attn_f32(const AttnArgs& a, hipStream_t s) {
