@@ -985,9 +985,9 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         // survivors per chunk (k * len / seen) whatever N is; 1 M documents = 1 + 5 launches instead of 31
         while (n256 - seen >= 256) {
             long len = half_growth ? (seen / 2 / 256 * 256 > 256 ? seen / 2 / 256 * 256 : 256) : seen * growth;
-            if (len > n256 - seen) len = n256 - seen;
             if (len > (1L << 19)) len = 1L << 19;
-            if (len >= unit) len = len / unit * unit;
+            if (len >= n256 - seen) len = n256 - seen;          // the last chunk takes what is left (no whole-wave rounding: that
+            else if (len >= unit) len = len / unit * unit;      //  left a 17 k-document sixth launch behind 1 M documents at nq = 16)
             GemmArgs g{};
             g.A = qpad; g.lda = d; g.M = nq_pad; g.m_valid = nq; g.K = d;
             g.W = (const char*)corpus + (size_t)seen * d * esz; g.ldw = d; g.N = (int)len;
@@ -1012,6 +1012,9 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             // equal scores): the merge result is incomplete -- redo THIS chunk from the pre-chunk best by materialise +
             // select.  Sync-free: predicated on the chunk's device flag.  The thresholds of the next chunk come from the
             // corrected list, so a drift costs one or two recomputed chunks, not the whole call.
+            // (Deferring the fallback to ONE predicated whole-shard recomputation per pass for short query batches saves 8 no-op
+            // launches = 2 % at nq = 16, and costs 12.9 ms instead of 0.55 when a drift does overflow: a select over 1 M columns
+            // has 16 rows of parallelism.  Measured and dropped, profiles/r03_score_defer_ab.txt.)
             if (!no_fallback) recompute(c_lo, seen, tv[cur], ti[cur], ov, oi, cflag);
             cur ^= 1;
             ++chunk_i;

@@ -406,6 +406,39 @@ def test_score_topk_filtered_large_k(ctx, k):
     assert (val[:, :-1] >= val[:, 1:]).all() and (idx >= 7).all()
 
 
+@pytest.mark.parametrize("case", ["ascending", "drift"])
+@pytest.mark.parametrize("running", [False, True], ids=["fresh", "running"])
+def test_score_topk_short_query_batches_overflow_fallback(ctx, case, running):
+    """The overflow fallback on the 64-row scorer tile (nq <= 64), with and without an incoming running list: candidate
+    lists that overflow (scores ascending with the index: every chunk; a drift inside the corpus: the chunk that holds the
+    jump) are recomputed by the predicated materialise + select and the result is the materialise-and-select answer."""
+    nq, d, k = 16, 128, 10
+    g = torch.Generator(device="cpu").manual_seed(21)
+    u = torch.randn(d, generator=g)
+    q = torch.randn(nq, d, generator=g).abs() * u.sign()
+    if case == "ascending":
+        N = 300_005
+        c = (torch.arange(1, N + 1).float() / N)[:, None] * u[None, :]
+    else:
+        N = 400_037
+        c = torch.randn(N, d, generator=g)
+        c[150_000:] += 0.5 * u[None, :]
+    q, c = q.cuda().to(torch.float16), c.cuda().to(torch.float16)
+    run, base = None, 0
+    if running:
+        prev = torch.randn(3000, d, generator=g).cuda().to(torch.float16)
+        v0, i0, n0 = ctx.score_topk(q, prev, k, idx_base=0, dtype=torch.float16)
+        run, base = (v0.clone(), i0.clone(), n0), 3000
+        val, idx, n = ctx.score_topk(q, c, k, idx_base=base, run=(v0, i0, n0), dtype=torch.float16)
+    else:
+        val, idx, n = ctx.score_topk(q, c, k, dtype=torch.float16)
+    wv, wi, wn = _sliced_classic(ctx, q, c, k, 100_000, idx_base=base, run=run)
+    assert n == wn == k
+    assert torch.equal(val, wv) and torch.equal(idx, wi), case
+    if case == "ascending" and not running:
+        assert (idx >= N - 64).all()
+
+
 @pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("nq", [1, 16, 33, 64])
 def test_score_topk_short_query_batches_use_the_64_row_tile_exactly(ctx, nq, dt16):
