@@ -81,11 +81,11 @@ __device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor
 // NQ = 16-query fragments per wave.  NQ = 1: 8 waves x 16 queries.  NQ = 2 (DH = 64): 4 waves x 32 queries -- every K / V^T
 // fragment read from LDS feeds two MFMAs, halving the LDS bytes per query; the SQ counters at S = 512 put the LDS array
 // right behind the VALU as this kernel's busiest unit (profiles/r03_attn_pmc.txt).
-template <typename H, int DH, bool OUT8, int NQ>
-__global__ __launch_bounds__(NQ == 1 ? 512 : 256, NQ == 1 ? ATTN_WAVES_PER_SIMD : SGPT_ATTN_Q32_WAVES) void attn16_lds_kernel(const AttnArgs p) {
+template <typename H, int DH, bool OUT8, int NQ, int NW = (NQ == 1 ? 8 : 4)>
+__global__ __launch_bounds__(64 * NW, NQ == 2 ? SGPT_ATTN_Q32_WAVES : ATTN_WAVES_PER_SIMD)
+void attn16_lds_kernel(const AttnArgs p) {
     constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
-    constexpr int NW = NQ == 1 ? 8 : 4;                        // waves per block
-    constexpr int NT = 64 * NW, QW = 16 * NQ, QB = 128;        // QW queries per wave, QB = NW * QW per block
+    constexpr int NT = 64 * NW, QW = 16 * NQ, QB = NW * QW;    // NW waves per block, QW queries per wave, QB per block
     constexpr int ORS = DH * 2 + 16;                           // output-transpose row stride (bytes)
     constexpr int NB = (DH <= 64 && SGPT_ATTN_STAGES == 2) ? 2 : 1;   // LDS stages of the K / V^T tiles
     __shared__ __attribute__((aligned(16))) uint4 Ks[NB][64 * CPR];
