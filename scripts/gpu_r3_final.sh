@@ -14,4 +14,6 @@ bash scripts/gpu_pmc.sh > gpurun_out/pmc.log 2>&1; tail -3 gpurun_out/pmc.log; h
 ( for nq in 1000 128 64 16; do NQ=$nq python scripts/score_bench.py; done; for dr in 0.1 0.3 0.6 0.9; do echo -n "DRIFT=$dr "; DRIFT=$dr python scripts/score_bench.py; done; for n in 500000 250000 125000; do N=$n python scripts/score_bench.py; done ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_bench.txt
 bash scripts/score_prof.sh > gpurun_out/score_prof.log 2>&1; head -8 gpurun_out/score_prof_summary.csv
 ( for ll in 0 1; do for nq in 1 16 128; do LL=$ll NQ=$nq python scripts/small_batch_profile.py 2>&1 | grep "per encode"; done; done; python scripts/query_side_breakdown.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/query_side.txt
+bash scripts/gpu_r3_small_prof.sh > gpurun_out/small_prof_run.log 2>&1; head -8 gpurun_out/small_batch_kernel_stats.csv | cut -c1-160
+bash scripts/seq_ab.sh > /dev/null 2>&1; cat gpurun_out/seq_ab.txt
 python scripts/models_table.py gpurun_out/parity.jsonl gpurun_out/models.jsonl > gpurun_out/models.log 2>&1; cut -c1-260 gpurun_out/models.jsonl
