@@ -38,6 +38,9 @@ constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
 #ifndef SGPT_SMALL_PF
 #define SGPT_SMALL_PF 2
 #endif
+#ifndef SGPT_FEW_TILES
+#define SGPT_FEW_TILES 128   // 256x256 tiles from more than half a wave of them on
+#endif
 #ifndef SGPT_DEEP_TILES
 #define SGPT_DEEP_TILES 512
 #endif
@@ -864,7 +867,7 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     const bool scorer = epi == EPI_SCORE || epi == EPI_SCORE_FILTER;
     // a.force256 (per ctx, sgpt_ctx_set_tile_policy): keep 256x256 tiles for problems the small-tile rule would hand to
     // the register-staged kernel -- kernel-level tests of single-tile shapes
-    const bool few = small_tiles && !a.force256 && !scorer && (long)(a.M / 256) * (a.N / 256) * 2 <= 256;
+    const bool few = small_tiles && !a.force256 && !scorer && (long)(a.M / 256) * (a.N / 256) <= SGPT_FEW_TILES;
     static const bool use256 = exp_env("SGPT_GEMM128") == nullptr;
     const bool shape256 = a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128;
     // short query batches: the 64-row scorer tile (M = 64 padded query rows, N % 256 == 0, K % 64 == 0, K >= 128)
