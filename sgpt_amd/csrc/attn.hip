@@ -20,6 +20,8 @@
 
 #include "common.h"
 
+// Build-time A/B switches (SGPT_LIB_TAG=x SGPT_EXTRA_FLAGS=-D... python -m sgpt_amd.build; scripts/seq_ab.sh, mid_ab.sh); the
+// defaults are what the measurements in profiles/r03_attn_pmc.txt and r03_mid_batch_ab.txt selected.
 #ifndef SGPT_ATTN_PERMLANE
 #define SGPT_ATTN_PERMLANE 1
 #endif
