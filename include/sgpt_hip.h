@@ -99,7 +99,7 @@ typedef struct {
                                 a_hi.W_lo: one GEMM over K' = 3 d on the same MFMA), i.e. to ~2^-22 instead of 2^-11 each; q / k
                                 are stored in 16 bits as before.  For GPT-Neo (attention without 1/sqrt(dh), HF:gpt_neo:110) the
                                 path LayerNorm -> Wq / Wk -> q / k carries 80 % of the 16-bit deviation at d = 2048:
-                                SGPT-1.3B shape goes from 8.7e-4 / 1.11e-3 (cosine / embedding) to well inside the 1e-3 bar, for
+                                SGPT-1.3B shape goes from 8.2e-4 / 1.09e-3 (cosine / embedding) to well inside the 1e-3 bar, for
                                 three times the FLOPs of one of the five projections.  0 (default) = off */
 } sgpt_model_desc;
 

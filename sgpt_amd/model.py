@@ -225,8 +225,8 @@ class SGPTModel:
         """precise_qk (dtype 'f16' / 'bf16'): split-precision Q / K projection -- the LayerNorm output and the Wq / Wk weights
         enter it as hi + lo pairs of 16-bit values (three K blocks on the same MFMA).  GPT-Neo has no 1/sqrt(dh) in its
         attention; at d >= 2048 the path LayerNorm -> Wq / Wk -> q / k carries 80 % of the 16-bit deviation from the fp32
-        reference: with it SGPT-1.3B shape sits inside the 1e-3 bar on embeddings and cosine scores (7.9e-4 /
-        5.1e-4 instead of 1.11e-3 / 8.7e-4), for +2x the FLOPs of the Q / K projection (-22 % throughput at that size).
+        reference: with it SGPT-1.3B shape sits inside the 1e-3 bar on embeddings and cosine scores (7.7e-4 /
+        5.0e-4 instead of 1.09e-3 / 8.2e-4), for +2x the FLOPs of the Q / K projection (-22 % throughput at that size).
         None (default) = parity first: ON for dtype 'f16' GPT-Neo models with hidden_size >= 2048 (SGPT-1.3B / 2.7B), off
         elsewhere (SGPT-125M: 3.2e-4 without it; GPT-J / BLOOM: 6e-5); True / False force it."""
         if dtype in ("fp16", "float16", "half"):
