@@ -314,7 +314,11 @@ sgpt_status sgpt_topk_merge(sgpt_ctx* ctx, const float* val, const int64_t* idx,
  * all-gathered (two ncclAllGathers in one group) and the k_out best of the world * k candidates per query are selected by
  * the library's merge kernel on the same stream -- the heapq.nlargest merge of exact_search.py:121-132 including the
  * `corpus_id != query_id` rule (:118) through exclude_idx (device int64[nq] or NULL).  Ties -> lowest index: every rank gets
- * identical results.  val device fp32[nq,k], idx device int64[nq,k] -> out_val fp32[nq,k_out], out_idx int64[nq,k_out]. */
+ * identical results.  val device fp32[nq,k], idx device int64[nq,k] -> out_val fp32[nq,k_out], out_idx int64[nq,k_out].
+ *
+ * sgpt_fold_gathered_topk is the rank-local half of that step on its own (no communicator needed): gathered_val / gathered_idx
+ * device [world][nq][k] in rank order, as an all-gather delivers them -> the same k_out best per query.  For callers that move
+ * the lists with their own transport, and for testing the fold of a many-rank world on one GPU. */
 #define SGPT_COMM_ID_BYTES 128
 sgpt_status sgpt_comm_unique_id(uint8_t* id /* [SGPT_COMM_ID_BYTES], host */);
 sgpt_status sgpt_comm_init(sgpt_ctx* ctx, const uint8_t* id, int32_t rank, int32_t world);
@@ -325,6 +329,9 @@ sgpt_status sgpt_allgather_rows(sgpt_ctx* ctx, const void* local, const int64_t*
                                 void* stream);
 sgpt_status sgpt_exchange_topk(sgpt_ctx* ctx, const float* val, const int64_t* idx, int32_t nq, int32_t k, int32_t k_out,
                                const int64_t* exclude_idx, float* out_val, int64_t* out_idx, void* stream);
+sgpt_status sgpt_fold_gathered_topk(sgpt_ctx* ctx, const float* gathered_val, const int64_t* gathered_idx, int32_t world,
+                                    int32_t nq, int32_t k, int32_t k_out, const int64_t* exclude_idx, float* out_val,
+                                    int64_t* out_idx, void* stream);
 
 /* Plain top-k over a materialised score matrix: torch.topk(scores, k, dim=1)
  * (exact_search.py:102-108; util.semantic_search util.py:241).  NaN -> -1 first (:99). */

@@ -85,6 +85,8 @@ SIGNATURES = {
     "sgpt_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "sgpt_exchange_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sgpt_fold_gathered_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgpt_ctx_set_low_latency": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sgpt_ctx_set_tile_policy": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sgpt_model_range_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]),

@@ -151,6 +151,44 @@ sgpt_status sgpt_allgather_rows(sgpt_ctx* c, const void* local, const int64_t* c
     return SGPT_OK;
 }
 
+// The rank-local half of the exchange: [world][nq][k] gathered lists -> the k_out best per query.  Needs no communicator:
+// a caller with its own transport uses it directly, and the tests drive it on one GPU with a simulated world.
+static sgpt_status fold_gathered(sgpt_ctx* c, const float* gv, const long long* gi, int world, int nq, int k, int k_out,
+                                 const int64_t* exclude_idx, float* out_val, int64_t* out_idx, float* rv, long long* ri,
+                                 hipStream_t s) {
+    const size_t nw = (size_t)nq * k * world;
+    const float* mv = gv;
+    const long long* mi = gi;
+    if (world > 1) {
+        const long total = (long)nw;
+        const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+        hipLaunchKernelGGL(gather_to_rows_kernel, dim3(grid), dim3(256), 0, s, gv, gi, rv, ri, world, nq, k);
+        mv = rv; mi = ri;
+    }
+    // the k_out best of the world * k candidates per query; idx < 0 and idx == exclude_idx[q] are skipped
+    // (exact_search.py:118, 121-132); ties -> lowest index: identical on every rank
+    const int mcand = world * k;
+    launch_topk_select(mv, mcand, 0, 0, mv, (const int64_t*)mi, mcand, mcand, nq, k_out, 0, exclude_idx, out_val, out_idx, s);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_fold_gathered_topk(sgpt_ctx* c, const float* gathered_val, const int64_t* gathered_idx, int32_t world, int32_t nq,
+                                    int32_t k, int32_t k_out, const int64_t* exclude_idx, float* out_val, int64_t* out_idx,
+                                    void* stream) {
+    if (!c) return SGPT_ERR_INVALID;
+    if (!gathered_val || !gathered_idx || !out_val || !out_idx || world <= 0 || nq <= 0 || k <= 0 || k_out <= 0)
+        return cfail(c, SGPT_ERR_INVALID, "sgpt_fold_gathered_topk: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t nw = (size_t)nq * k * world;
+    const size_t vb = (nw * 4 + 255) / 256 * 256, ib = (nw * 8 + 255) / 256 * 256;
+    sgpt_status st = ensure3(c, vb + ib);
+    if (st != SGPT_OK) return st;
+    char* base = (char*)c->ws3;
+    return fold_gathered(c, gathered_val, (const long long*)gathered_idx, world, nq, k, k_out, exclude_idx, out_val, out_idx,
+                         (float*)base, (long long*)(base + vb), (hipStream_t)stream);
+}
+
 sgpt_status sgpt_exchange_topk(sgpt_ctx* c, const float* val, const int64_t* idx, int32_t nq, int32_t k, int32_t k_out,
                                const int64_t* exclude_idx, float* out_val, int64_t* out_idx, void* stream) {
     if (!c) return SGPT_ERR_INVALID;
@@ -176,20 +214,7 @@ sgpt_status sgpt_exchange_topk(sgpt_ctx* c, const float* val, const int64_t* idx
     NCCLC(c, ncclGroupEnd());
     NCCLC(c, r1);
     NCCLC(c, r2);
-    const float* mv = gv;
-    const long long* mi = gi;
-    if (world > 1) {
-        const long total = (long)nw;
-        const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-        hipLaunchKernelGGL(gather_to_rows_kernel, dim3(grid), dim3(256), 0, s, gv, gi, rv, ri, world, nq, k);
-        mv = rv; mi = ri;
-    }
-    // the k_out best of the world * k candidates per query; idx < 0 and idx == exclude_idx[q] are skipped
-    // (exact_search.py:118, 121-132); ties -> lowest index: identical on every rank
-    const int mcand = world * k;
-    launch_topk_select(mv, mcand, 0, 0, mv, (const int64_t*)mi, mcand, mcand, nq, k_out, 0, exclude_idx, out_val, out_idx, s);
-    HIPC(c, hipGetLastError());
-    return SGPT_OK;
+    return fold_gathered(c, gv, gi, world, nq, k, k_out, exclude_idx, out_val, out_idx, rv, ri, s);
 }
 
 }  // extern "C"

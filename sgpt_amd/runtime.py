@@ -260,6 +260,20 @@ class Context:
                                            _stream_ptr(self.device)), "sgpt_topk_merge")
         return ov, oi
 
+    def fold_gathered_topk(self, gathered_val: torch.Tensor, gathered_idx: torch.Tensor, k_out: int,
+                           exclude_idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """[world, nq, k] all-gathered per-rank lists (rank order) -> the k_out best per query: the rank-local half of
+        sgpt_exchange_topk (include/sgpt_hip.h::sgpt_fold_gathered_topk), no communicator involved."""
+        gv = gathered_val.to(device=self.device, dtype=torch.float32).contiguous()
+        gi = gathered_idx.to(device=self.device, dtype=torch.int64).contiguous()
+        world, nq, k = gv.shape
+        ov = torch.empty((nq, k_out), dtype=torch.float32, device=self.device)
+        oi = torch.empty((nq, k_out), dtype=torch.int64, device=self.device)
+        ex = None if exclude_idx is None else exclude_idx.to(device=self.device, dtype=torch.int64).contiguous()
+        self._chk(self.lib.sgpt_fold_gathered_topk(self.handle, _p(gv), _p(gi), world, nq, k, k_out, _p(ex), _p(ov), _p(oi),
+                                                   _stream_ptr(self.device)), "sgpt_fold_gathered_topk")
+        return ov, oi
+
     def topk(self, scores: torch.Tensor, k: int, idx_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
         """torch.topk(scores, k, dim=1) with NaN -> -1 first (exact_search.py:99-108); sorted descending."""
         scores = scores.to(device=self.device, dtype=torch.float32)

@@ -64,6 +64,40 @@ def test_rccl_sharded_search_equals_local_search(nccl_group):
         comm.all_gather_rows(q[:3], [nq])                             # the shard plan and the local rows disagree
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_fold_of_a_simulated_world_equals_the_single_shard_search(world):
+    """The device code that only runs with more than one rank -- the [world][nq][k] -> [nq][world * k] regrouping kernel in
+    front of the merge (sgpt_amd/csrc/comm.hip) -- driven on one GPU: a corpus cut into `world` contiguous shards, one
+    sgpt_score_topk per shard with its global index base, the lists stacked in rank order exactly as ncclAllGather
+    delivers them, folded by sgpt_fold_gathered_topk (the rank-local half of sgpt_exchange_topk).  Must equal the
+    single-shard search, values and indices, including the self-id exclusion and ties across shards."""
+    from sgpt_amd import get_context
+    from sgpt_amd.dist import shard_range
+    ctx = get_context("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(100 + world)
+    nq, N, d, k = 37, 9_000, 256, 11
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).cuda().to(torch.float16)
+    c = torch.nn.functional.normalize(torch.randn(N, d, generator=g), dim=1)
+    c[5_000:5_040] = c[100:140]                                   # equal scores in different shards: ties -> lowest index
+    c = c.cuda().to(torch.float16)
+    excl = torch.full((nq,), -1, dtype=torch.int64)
+    excl[3] = 17
+    vals, idxs = [], []
+    for r in range(world):
+        lo, hi = shard_range(N, r, world)
+        v, i, n = ctx.score_topk(q, c[lo:hi].contiguous(), k, idx_base=lo, dtype=torch.float16)
+        assert n == k
+        vals.append(v); idxs.append(i)
+    fv, fi = ctx.fold_gathered_topk(torch.stack(vals), torch.stack(idxs), k, exclude_idx=excl)
+    wv, wi, _ = ctx.score_topk(q, c, k + 1, dtype=torch.float16)
+    mv, mi = ctx.topk_merge(wv, wi, k, exclude_idx=excl)
+    keep = [r for r in range(nq) if r != 3]                        # (row 3 lost a candidate to the exclusion: k of k + 1 vs k of world * k)
+    assert torch.equal(fi[keep], mi[keep]) and torch.equal(fv[keep], mv[keep])
+    assert (fi[3] != 17).all() and torch.equal(fv[3, : k - 1], mv[3, : k - 1])
+    ref_v, ref_i = torch.topk(q.float() @ c.float().T, k, dim=1)
+    assert float((fv[keep] - ref_v[keep]).abs().max()) < 1e-3
+
+
 def test_rccl_distributed_encode_equals_local_encode(nccl_group):
     from helpers import build_model
     from sgpt_amd.st import SentenceTransformerSGPT
