@@ -1240,10 +1240,6 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
     GemmArgs g{};
     g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.m_valid = M; g.N = N; g.K = K; g.out = O;
     g.ldo = epi == EPI_VT ? M : N; g.bias = bias; g.resid = epi == EPI_BIAS_RESID ? (const float*)O : nullptr;
-#ifdef SGPT_PROBE_X16
-    void* x16 = nullptr;
-    if (epi == EPI_BIAS_RESID) { HIPC(c, hipMalloc(&x16, (size_t)M * N * 2)); g.out2 = x16; }
-#endif
     hipEvent_t e0, e1;
     HIPC(c, hipEventCreate(&e0)); HIPC(c, hipEventCreate(&e1));
     long long* dbg = nullptr;
@@ -1271,9 +1267,6 @@ sgpt_status sgpt_bench_gemm(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(O); (void)hipFree(bias);
-#ifdef SGPT_PROBE_X16
-    if (x16) (void)hipFree(x16);
-#endif
     HIPC(c, hipGetLastError());
     return SGPT_OK;
 }
