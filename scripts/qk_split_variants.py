@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
-"""CPU emulation (scripts/numerics_study.py conventions) of cheaper variants of the split-precision Q / K projection at SGPT-1.3B shape:
+"""CPU emulation (the conventions of scripts/numerics_study.py, self-contained) of cheaper variants of the split-precision Q / K projection at SGPT-1.3B shape:
 plain f16, the full hi+lo split that ships (three passes), activation-only / weight-only splits and the split on one of the two
 projections (two passes).  Not a product or test path."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import sgpt_oracle as O
-import numerics_study as NS
+from types import SimpleNamespace
 torch.set_num_threads(os.cpu_count())
-cfgkw = dict(O.SGPT_125M); cfgkw.update(hidden_size=2048, num_layers=24, num_heads=16)
-cfg = O.NeoConfig(**cfgkw)
-w = {k: torch.from_numpy(v) for k, v in O.synth_weights(cfg, seed=1, std=0.02).items()}
+# GPT-Neo 1.3B shape (HF:gpt_neo config: alternating global / local-256 layers), random-init weights of std 0.02 under HF names
+cfg = SimpleNamespace(hidden_size=2048, num_layers=24, num_heads=16, window_size=256, layer_norm_epsilon=1e-5,
+                      attention_layers=["global", "local"] * 12)
+g = torch.Generator().manual_seed(1)
+def _n(*shape): return torch.randn(*shape, generator=g) * 0.02
+w = {"wte.weight": _n(50257, 2048), "wpe.weight": _n(2048, 2048), "ln_f.weight": torch.ones(2048), "ln_f.bias": torch.zeros(2048)}
+for i in range(cfg.num_layers):
+    p_ = f"h.{i}."
+    for nm in ("q", "k", "v", "out"): w[p_ + f"attn.attention.{nm}_proj.weight"] = _n(2048, 2048)
+    w[p_ + "attn.attention.out_proj.bias"] = torch.zeros(2048)
+    w[p_ + "mlp.c_fc.weight"], w[p_ + "mlp.c_fc.bias"] = _n(8192, 2048), torch.zeros(8192)
+    w[p_ + "mlp.c_proj.weight"], w[p_ + "mlp.c_proj.bias"] = _n(2048, 8192), torch.zeros(2048)
+    for ln in ("ln_1", "ln_2"): w[p_ + ln + ".weight"], w[p_ + ln + ".bias"] = torch.ones(2048), torch.zeros(2048)
 rng = np.random.default_rng(5)
 docs = torch.from_numpy(rng.integers(0, 50256, size=(24, 128)))
 qs = torch.from_numpy(rng.integers(0, 50256, size=(8, 24)))
-rnd = NS.rnd
+def rnd(x, fmt):
+    return x if fmt == "f32" else x.to(torch.float16).float()
 def split(x):
     hi = rnd(x, "f16"); lo = rnd(x - hi, "f16"); return hi, lo
 def forward(ids, variant):
