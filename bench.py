@@ -189,9 +189,14 @@ def main():
                          "MFMA; fp8 = e4m3fn weight storage (SURVEY 8d cfg5), bf16 arithmetic; fp8mfma = fp8 storage + fp8 MFMA "
                          "(v_mfma_f32_16x16x128_f8f6f4) on all four projections of a block")
     ap.add_argument("--model", default="125m", choices=sorted(MODELS), help="SGPT size (default: the BASELINE metric's 125M)")
-    ap.add_argument("--precise-qk", choices=["auto", "on", "off"], default="auto",
-                    help="split-precision Q / K projection (SGPTModel(precise_qk=...)): auto = on for f16 GPT-Neo at d >= 2048 "
-                         "(SGPT-1.3B / 2.7B: the setting that meets the 1e-3 bar there), off for the 125M headline")
+    ap.add_argument("--precise-qk", choices=["auto", "on", "off", "full", "logits", "act+logits"], default="auto",
+                    help="the structural split-precision rule (SGPTModel(precise_qk=...)): auto = the model's default for f16 "
+                         "GPT-Neo at d >= 2048 (SGPT-1.3B / 2.7B: the setting that meets the 1e-3 bar there), nothing for the "
+                         "125M headline; on / full = Q / K projection over hi + lo pairs; logits = hi + lo pairs inside the "
+                         "attention only; act+logits = plus the LayerNorm-1 output split")
+    ap.add_argument("--precision", choices=["default", "plain", "auto", "auto-class", "x3"], default="default",
+                    help="SGPTModel(precision=...): default = 'auto' for f16 (the first encode probes the checkpoint's operand "
+                         "crest factors; a clean one stays on plain 16-bit operands), 'plain' otherwise; x3 = every operand as a hi + lo pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the queries/sec @ 1M-doc scoring leg")
     ap.add_argument("--cpu-sample", type=int, default=128, help="sentences in the bounded CPU-baseline sample (a slice of the 1024 x seq probe)")
@@ -221,7 +226,8 @@ def main():
     cfg = SGPTConfig.from_hf_dict(mkw) if mkw.get("model_type") in ("gptj", "bloom") else SGPTConfig(**mkw)
     weights = synthetic_weights(cfg, seed=1) if args.model == "125m" else device_random_weights(cfg, dev)
     model = SGPTModel(cfg, weights, device=dev, dtype=args.dtype, max_tokens_per_call=args.call * args.seq,
-                      precise_qk={"auto": None, "on": True, "off": False}[args.precise_qk])
+                      precise_qk={"auto": None, "on": True, "off": False}.get(args.precise_qk, args.precise_qk),
+                      **({} if args.precision == "default" else {"precision": args.precision}))
     del weights
     torch.cuda.empty_cache()
     d, S, k1 = cfg.hidden_size, args.seq, args.topk + 1      # the reference keeps top_k+1 (exact_search.py:104)
@@ -576,13 +582,19 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": ("BASELINE configs[1]: SGPT-125M" if args.model == "125m" else f"SGPT-{args.model.upper()}") +
-                                  "-shape random-init weights, " + args.dtype + " MFMA" + (" + split-precision Q/K projection" if model.precise_qk else "") +
+                                  "-shape random-init weights, " + args.dtype + " MFMA" + (f" + precise_qk={model.precise_qk}" if model.precise_qk else "") +
                                   (" (DEVIATION from configs[1]'s bf16: IEEE-half operands -- same width and MFMA rate class, 3 more "
                                    "mantissa bits, the mode that meets the 1e-3 parity bar; --dtype bf16 times bf16)" if args.dtype == "f16" else "") + ", "
                                   f"{args.steps * args.chunk} docs/GPU x seq_len {S}, nq={args.nq}, cosine top-{args.topk} "
                                   f"(top_k+1 kept), corpus rows {'fp32' if args.dtype == 'fp32' else ('f16' if args.dtype == 'f16' else 'bf16')} in HBM",
                       "docs_per_step": args.chunk, "docs_per_encode_call": args.call, "seq_len": S, "nq": args.nq,
-                      "top_k": args.topk, "parallelism": f"corpus-shard x{world}"},
+                      "top_k": args.topk, "parallelism": f"corpus-shard x{world}",
+                      "precision": getattr(model, "precision", "plain"),
+                      "precision_probe": None if not model.precision_report else {
+                          "decided": model.precision_report["decided"], "flagged_classes": model.precision_report["flagged"],
+                          "crest_max_ln1_ctx_ln2_h": [round(float(v), 1) for v in model.precision_report["crest"].max(0)],
+                          "limits": model.precision_report["limits"]},
+                      "split_plan_entries": int((model.precision_plan() != 0).sum()) if args.dtype in ("f16", "bf16") else 0},
            "value_incl_host_pack_and_h2d": round(sent_per_s_host, 1),
            "host_leg": f"{host_steps} of the same steps with every call's ids packed from host memory and copied over PCIe inside "
                        "the clock (pinned double arena, async H2D overlapping the previous call's encode)",

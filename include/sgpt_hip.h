@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPT_ABI_VERSION 5
+#define SGPT_ABI_VERSION 6
 
 typedef int sgpt_status;
 #define SGPT_OK 0
@@ -100,7 +100,11 @@ typedef struct {
                                 are stored in 16 bits as before.  For GPT-Neo (attention without 1/sqrt(dh), HF:gpt_neo:110) the
                                 path LayerNorm -> Wq / Wk -> q / k carries 80 % of the 16-bit deviation at d = 2048:
                                 SGPT-1.3B shape goes from 8.2e-4 / 1.09e-3 (cosine / embedding) to well inside the 1e-3 bar, for
-                                three times the FLOPs of one of the five projections.  0 (default) = off */
+                                three times the FLOPs of one of the five projections.  0 (default) = off.  (= precision plan entry
+                                SGPT_PC_LN1 = 1 in every block, see sgpt_model_set_precision) */
+    int32_t split_weights;   /* SGPT_F16 / SGPT_BF16 only.  1 = also keep [W_hi | W_hi | W_lo] copies of all four matmul weights of
+                                every block (3 x the 16-bit weight bytes on top of the plain copy) so that sgpt_model_set_precision
+                                can move any operand class of any block to split precision after load.  0 (default) = off */
 } sgpt_model_desc;
 
 /* One named fp32 weight tensor under its HF state-dict name
@@ -233,13 +237,61 @@ sgpt_status sgpt_f32_to_bf16(sgpt_ctx* ctx, const float* in, int64_t numel, void
  *   than 2^40 returns SGPT_ERR_RANGE.  Bumps sgpt_ctx_generation (captured graphs carry the factors as kernel arguments).
  * sgpt_model_get/set_range_shifts: the 4 * n_layers exponents (per block: LayerNorm-1 output, q | k | v, LayerNorm-2 output,
  *   GELU output) -- to pin the shifts found on one run for reproducible embeddings on the next (a shift changes results only
- *   through f16 subnormals: |v| * 2^-k < 6.1e-5).
+ *   through f16 subnormals: |v| * 2^-k < 6.1e-5).  A LayerNorm shift below the bound sgpt_model_load derived from this
+ *   checkpoint's LayerNorm parameters is refused (the LayerNorm kernels carry no run-time tracker), and a pooled embedding
+ *   that is not finite raises bit 0 whatever produced it.
  * sgpt_range_check: the same bit 0 for the ctx-level stand-alone ops (sgpt_linear with f16 output). */
 sgpt_status sgpt_model_range_check(sgpt_model* model, int32_t* flagged, int32_t reset, void* stream);
 sgpt_status sgpt_model_range_adapt(sgpt_model* model, int32_t* n_raised, void* stream);
 sgpt_status sgpt_model_get_range_shifts(sgpt_model* model, int32_t* shifts, int32_t n);
 sgpt_status sgpt_model_set_range_shifts(sgpt_model* model, const int32_t* shifts, int32_t n);
 sgpt_status sgpt_range_check(sgpt_ctx* ctx, int32_t* flagged, int32_t reset, void* stream);
+
+/* Precision plan (ABI v6): which operand classes of which blocks enter their MFMAs as split-precision pairs.
+ * The reference runs fp32 everywhere (beir_dense_retriever.py:123,204-205; Transformer.py:38,72), so it has no checkpoint
+ * on which 11-bit operands are not enough; this path does (real GPT-Neo checkpoints carry outlier channels: a row whose
+ * energy sits in one or two entries puts their whole relative rounding error on the dot product).  A split class is stored
+ * as hi = round16(v) and lo = round16(v - hi) -- a [hi | lo | hi] row of 3 K that the UNCHANGED 16-bit GEMM contracts
+ * against [W_hi | W_hi | W_lo] (a_hi.W_hi + a_lo.W_hi + a_hi.W_lo: the product to ~2^-22 instead of 2^-11 per operand, at
+ * a third of the 16-bit MFMA rate and ~5 x the exact-fp32 MFMA mode).
+ *   plan: host int32[n_layers][SGPT_PREC_CLASSES], per block
+ *     SGPT_PC_LN1  LayerNorm-1 output -> Q / K / V projection: 0 = plain, 1 = Q and K split (V from the hi block), 2 = Q, K, V,
+ *                  3 = Q and K with the ACTIVATION alone split ([a_hi | a_lo] . [W_hi | W_hi]: K' = 2 d, half the extra FLOPs of 1)
+ *     SGPT_PC_ATT  inside the attention: q, k, V^T and the probabilities as hi + lo pairs (logits and P.V as three MFMA
+ *                  passes each; head_dim 64 / 128, GPT-Neo and BLOOM)
+ *     SGPT_PC_CTX  attention context -> out-projection
+ *     SGPT_PC_LN2  LayerNorm-2 output -> fc1 (GPT-J's parallel block reads ln_1's output: must equal LN1 != 0 there)
+ *     SGPT_PC_H    GELU output -> fc2
+ *   Every class but LN1 = 1 needs sgpt_model_desc.split_weights.  All ones (LN1 = 2) = the "f16x3" mode: embeddings within
+ *   ~1e-5 of the fp32 reference on any checkpoint the f16 RANGE guard accepts.  Changing the plan bumps sgpt_ctx_generation.
+ * sgpt_model_precision_probe_begin / _end: between the two calls every sgpt_encode on the model also records, per block and
+ *   class (LayerNorm-1 output, attention context, LayerNorm-2 output, GELU output: 4 * n_layers floats), the largest crest
+ *   factor max|v| / rms(v) over the rows of the operand -- 4-10 for a well-conditioned row, ~sqrt(K / 2) when two entries carry
+ *   the row.  The host turns them into a plan (sgpt_amd/model.py: classes above 12 / 20 are split, and with them the
+ *   attention of the block; by default any such class moves the whole model to f16x3).  The recording launches are extra
+ *   kernels: results of the probed calls are unchanged.
+ * sgpt_split16: fp32 rows [n, d] -> 16-bit rows [n, 3 d] for a split-precision SCORER on the same kernels: layout 0 =
+ *   [hi | lo | hi] (documents), layout 1 = [hi | hi | lo] (queries); sgpt_scores / sgpt_score_topk over d' = 3 d then give
+ *   q_hi.c_hi + q_hi.c_lo + q_lo.c_hi.  (Normalised embeddings that two channels dominate lose up to 4e-4 of cosine to the
+ *   16-bit corpus format alone.)
+ * sgpt_linear_split: sgpt_linear (epi 0 | 1 | 4, 16-bit output) with the split store epilogue: hi at out, lo at out + lo_delta,
+ *   a second hi at out + hi2_delta when != 0 (element offsets; ldo = leading dimension of out): kernel-level tests. */
+#define SGPT_PREC_CLASSES 5
+enum { SGPT_PC_LN1 = 0, SGPT_PC_ATT = 1, SGPT_PC_CTX = 2, SGPT_PC_LN2 = 3, SGPT_PC_H = 4 };
+sgpt_status sgpt_model_set_precision(sgpt_model* model, const int32_t* plan, int32_t n);
+sgpt_status sgpt_model_get_precision(sgpt_model* model, int32_t* plan, int32_t n);
+sgpt_status sgpt_model_precision_probe_begin(sgpt_model* model);
+sgpt_status sgpt_model_precision_probe_end(sgpt_model* model, float* crest_out /* host float[4 * n_layers] or NULL */);
+ /* sgpt_row_crest: the probe's statistic for caller-owned 16-bit rows [n, d] (leading dimension ld): max over the rows of
+ *   max|v| / rms(v), returned to the host (synchronises `stream`).  The search host uses it on the gathered query embeddings --
+ *   identical on every rank -- to decide whether a 16-bit corpus is kept as split pairs. */
+sgpt_status sgpt_row_crest(sgpt_ctx* ctx, const void* x, int32_t dtype, int64_t n, int32_t d, int64_t ld, float* crest_out,
+                           void* stream);
+sgpt_status sgpt_split16(sgpt_ctx* ctx, const float* in, int64_t n, int32_t d, int32_t layout, void* out, int32_t out_dtype,
+                         void* stream);
+sgpt_status sgpt_linear_split(sgpt_ctx* ctx, int32_t dtype, int32_t epi, const void* A, const void* W, const float* bias,
+                              void* out, int64_t ldo, int64_t lo_delta, int64_t hi2_delta, int32_t M, int32_t N, int32_t K,
+                              void* stream);
 
 /* hipGraph support.  sgpt_ctx_generation changes whenever a library-owned buffer that launched kernels point into is
  * re-allocated (workspace growth, a larger learnt-pooling table): a graph captured at generation g must be re-captured

@@ -8,7 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGPT_HIP_LIB") or os.path.join(HERE, "lib", "libsgpt_hip.so")   # env: A/B builds of the same ABI
 
 SGPT_F32, SGPT_BF16, SGPT_FP8W, SGPT_F16, SGPT_FP8M = 0, 1, 2, 3, 4
-SGPT_ABI_VERSION = 5
+SGPT_ABI_VERSION = 6
+SGPT_PREC_CLASSES = 5                      # precision-plan classes per block: LN1, ATT, CTX, LN2, H (include/sgpt_hip.h)
+PC_LN1, PC_ATT, PC_CTX, PC_LN2, PC_H = 0, 1, 2, 3, 4
 SGPT_ERR_RANGE = -5
 SGPT_ERR_COMM = -6
 SGPT_COMM_ID_BYTES = 128
@@ -20,7 +22,8 @@ class ModelDesc(C.Structure):
     _fields_ = [("arch", C.c_int32), ("n_layers", C.c_int32), ("d_model", C.c_int32), ("n_heads", C.c_int32),
                 ("d_ffn", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("window", C.c_int32),
                 ("ln_eps", C.c_float), ("attn_scale", C.c_float), ("compute_dtype", C.c_int32),
-                ("layer_is_local", C.POINTER(C.c_uint8)), ("rotary_dim", C.c_int32), ("qk_split", C.c_int32)]
+                ("layer_is_local", C.POINTER(C.c_uint8)), ("rotary_dim", C.c_int32), ("qk_split", C.c_int32),
+                ("split_weights", C.c_int32)]
 
 
 class TensorView(C.Structure):
@@ -93,6 +96,14 @@ SIGNATURES = {
     "sgpt_model_range_adapt": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "sgpt_model_get_range_shifts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "sgpt_model_set_range_shifts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "sgpt_model_set_precision": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "sgpt_model_get_precision": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "sgpt_model_precision_probe_begin": (C.c_int, [C.c_void_p]),
+    "sgpt_model_precision_probe_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sgpt_row_crest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_float), C.c_void_p]),
+    "sgpt_split16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sgpt_linear_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sgpt_bench_gemm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.POINTER(C.c_float)]),
     "sgpt_prof_enable": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -23,6 +23,7 @@ from .tokenization import TextPipeline, load_tokenizer
 
 logger = logging.getLogger(__name__)
 
+SCORE_SPLIT_CREST = 10.0      # normalised embedding rows: crest factor above which a 16-bit corpus is kept as hi + lo pairs
 SINGLE_LAYER_METHODS = ("mean", "weightedmean", "lasttoken")
 ALL_LAYER_METHODS = {"meanmean": "mean", "lasttokenmean": "lasttoken"}
 
@@ -121,8 +122,9 @@ class CustomEmbedder:
         return embeddings
 
     # device-resident variants used by DenseRetrievalExactSearch below (no D2H of embeddings)
-    def encode_queries_device(self, queries, normalize=False):
-        if os.path.exists(f"{self.base_path}_queries.pickle") or self.save_emb:
+    def encode_queries_device(self, queries, normalize=False, use_cache=True):
+        """use_cache=False: never touch `{base_path}_queries.pickle` (the sharded search encodes a slice per rank)."""
+        if use_cache and (os.path.exists(f"{self.base_path}_queries.pickle") or self.save_emb):
             emb = torch.from_numpy(self.encode_queries(queries)).to(self.model.device)
             return get_context(self.model.device).l2_normalize(emb) if normalize else emb
         return self.embed_device([q for (_, q) in queries], True, normalize=normalize)
@@ -147,7 +149,8 @@ class DenseRetrievalExactSearch:
     query, the (k+1) best of {per-chunk top-(k+1) minus corpus_id == query_id} (:102-132)."""
 
     def __init__(self, model, batch_size: int = 128, corpus_chunk_size: int = 50000, score_dtype=torch.float32,
-                 prefetch_tokenize: bool = True, ctx=None, group=None, distributed: Optional[bool] = None, **kwargs):
+                 prefetch_tokenize: bool = True, ctx=None, group=None, distributed: Optional[bool] = None,
+                 score_split: Optional[bool] = None, **kwargs):
         self.model = model
         self.prefetch_tokenize = prefetch_tokenize
         self.batch_size = batch_size
@@ -160,6 +163,12 @@ class DenseRetrievalExactSearch:
         self.group = group                      # torch.distributed process group of a multi-GPU search (default: WORLD)
         self.distributed = distributed          # None: sharded search iff the group has more than one rank; True: whenever a
                                                 # group is initialised (a world of one runs the same collectives: tests)
+        # 16-bit score_dtype only: keep query / corpus rows as split-precision (hi + lo) pairs and score over 3 d columns on
+        # the same kernels (runtime.Context.split16).  None = decided per search from the normalised query embeddings (the
+        # same on every rank): rows that a few channels dominate (crest factor above SCORE_SPLIT_CREST) lose up to 4e-4 of
+        # cosine to the 16-bit format alone; well-spread rows lose ~1e-5 and stay plain.  fp32 score_dtype is exact already.
+        self.score_split = score_split
+        self.last_score_split = False
         self.results = {}
         self.last_shard = None                  # (rank, world, first document, one-past-last document) of the last search
 
@@ -168,11 +177,11 @@ class DenseRetrievalExactSearch:
             x = torch.as_tensor(np.asarray(x))
         return x.to(device=ctx.device, dtype=torch.float32)
 
-    def _encode_queries(self, ctx, qlist):
+    def _encode_queries(self, ctx, qlist, use_cache=True):
         if not qlist:
             return None
         if hasattr(self.model, "encode_queries_device"):
-            q_emb = self.model.encode_queries_device(qlist)
+            q_emb = self.model.encode_queries_device(qlist, use_cache=use_cache)
         else:
             q_emb = self.model.encode_queries(qlist, batch_size=self.batch_size,
                                               show_progress_bar=self.show_progress_bar,
@@ -208,14 +217,22 @@ class DenseRetrievalExactSearch:
         self.results = {qid: {} for qid in query_ids}
         qlist = [(qid, queries[qid]) for qid in queries]
         if comm is not None and (nq >= 4 * world or world == 1):
-            # this rank's contiguous slice of the queries (cuts balanced on text length), then ONE all-gather
-            qcuts = balanced_cuts([len(q[1]) + 1 for q in qlist], world)
-            q_loc = self._encode_queries(ctx, qlist[qcuts[rank]: qcuts[rank + 1]])
+            # this rank's contiguous slice of the queries (cuts balanced on text length, never empty: an empty slice has no
+            # embedding width to contribute and would leave the other ranks waiting in the collective), then ONE all-gather.
+            # The `{base_path}_queries.pickle` cache of the reference holds ALL queries under one name: a sharded run neither
+            # reads nor writes it (every rank would write its partial dict to the same path).
+            qcuts = balanced_cuts([len(q[1]) + 1 for q in qlist], world, min_one=True)
+            q_loc = self._encode_queries(ctx, qlist[qcuts[rank]: qcuts[rank + 1]], use_cache=False)
             q_emb = comm.all_gather_rows(q_loc, np.diff(qcuts).tolist())
         else:
             q_emb = self._encode_queries(ctx, qlist)       # (fewer queries than a handful per rank: every rank encodes them)
         if score_function == "cos_sim":
             q_emb = ctx.l2_normalize(q_emb)                                       # util.py:41 (once, not per chunk)
+        split = False
+        if self.score_dtype in (torch.float16, torch.bfloat16) and score_function == "cos_sim" and hasattr(ctx, "split16"):
+            split = (ctx.row_crest(q_emb) > SCORE_SPLIT_CREST) if self.score_split is None else bool(self.score_split)
+        self.last_score_split = split
+        q_op = ctx.split16(q_emb, "query", self.score_dtype) if split else q_emb
 
         logger.info("Sorting Corpus by document length (Longest first)...")
         doc_len = {k: len(corpus[k].get("title", "") + corpus[k].get("text", "")) for k in corpus}
@@ -263,9 +280,10 @@ class DenseRetrievalExactSearch:
                                                    convert_to_tensor=self.convert_to_tensor, batch_num=tag(batch_num))
                 sub = self._to_dev(ctx, sub)
                 if score_function == "cos_sim":
-                    sub = ctx.l2_normalize(sub, out_dtype=self.score_dtype)           # util.py:42
+                    sub = (ctx.split16(ctx.l2_normalize(sub), "doc", self.score_dtype) if split
+                           else ctx.l2_normalize(sub, out_dtype=self.score_dtype))    # util.py:42
                 kk = min(top_k + 1, end - start)                                      # :104
-                val, idx, _ = ctx.score_topk(q_emb, sub, kk, idx_base=lo + start, dtype=self.score_dtype)   # :96-108 (NaN -> -1)
+                val, idx, _ = ctx.score_topk(q_op, sub, kk, idx_base=lo + start, dtype=self.score_dtype)   # :96-108 (NaN -> -1)
                 if run_val is None:
                     cand_v, cand_i = val, idx
                 else:

@@ -17,7 +17,9 @@
 
 struct LayerW {
     void* w_qkv = nullptr;   // [3d, d]  (q rows, k rows, v rows)
-    void* w_qk3 = nullptr;   // qk_split: [2d, 3d] = [W_hi | W_hi | W_lo] of the q and k rows
+    // split-precision copies, rows [W_hi | W_hi | W_lo] of 3 x the input width: w_qkv3 [2d or 3d, 3d] (qk_split alone: the q and k
+    // rows; split_weights: q, k and v rows), w_o3 [d, 3d], w_fc3 [ffn, 3d], w_proj3 [d, 3 ffn]
+    void *w_qkv3 = nullptr, *w_o3 = nullptr, *w_fc3 = nullptr, *w_proj3 = nullptr;
     void* w_o = nullptr;     // [d, d]
     void* w_fc = nullptr;    // [ffn, d]
     void* w_proj = nullptr;  // [d, ffn]
@@ -50,12 +52,22 @@ struct sgpt_model {
     // RANGE_LIMIT, bit 1: an e4m3 code saturated), [1 + l * RS_N + c] = fp32 bits of the largest offending magnitude.
     std::vector<int> shift;
     unsigned* range_dev = nullptr;
+    std::vector<int> ln_floor;         // [n_layers]: the LayerNorm shift sgpt_model_load derived from the parameters (set_range_shifts may not go below)
+    // Precision plan: operand class c of block l enters its consumer as a split-precision (hi + lo) pair when prec[l * PC_N + c]
+    // != 0 (classes: PC_*).  crest_dev: device fp32 bits [n_layers * RS_N] collected while `probing` (sgpt_model_precision_probe_*).
+    std::vector<int> prec;
+    bool split_all = false;            // the split copies of all four matrices exist (sgpt_model_desc.split_weights)
+    unsigned* crest_dev = nullptr;
+    bool probing = false;
     std::vector<void*> allocs;
 };
 
 // operand classes of a block: LayerNorm-1 output, q | k | v (and the attention context, a convex combination of v rows),
 // LayerNorm-2 output, GELU output
 enum { RS_LN1 = 0, RS_QKV = 1, RS_LN2 = 2, RS_H = 3, RS_N = 4 };
+// precision classes (include/sgpt_hip.h SGPT_PC_*): LayerNorm-1 output -> Q / K (/ V) projection; q | k | v | p inside the attention;
+// attention context -> out-projection; LayerNorm-2 output -> fc1; GELU output -> fc2
+enum { PC_LN1 = SGPT_PC_LN1, PC_ATT = SGPT_PC_ATT, PC_CTX = SGPT_PC_CTX, PC_LN2 = SGPT_PC_LN2, PC_H = SGPT_PC_H, PC_N = SGPT_PREC_CLASSES };
 constexpr int RS_MAX_SHIFT = 40;
 static inline float pow2f(int k) { return std::ldexp(1.0f, k); }
 
@@ -224,8 +236,8 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         return fail(c, SGPT_ERR_INVALID, "bad compute_dtype");
     if (gptj && (d->rotary_dim <= 0 || d->rotary_dim > dh || d->rotary_dim % 2))
         return fail(c, SGPT_ERR_INVALID, "GPT-J needs an even rotary_dim in (0, head_dim]");
-    if (d->qk_split != 0 && d->compute_dtype != SGPT_F16 && d->compute_dtype != SGPT_BF16)
-        return fail(c, SGPT_ERR_INVALID, "qk_split applies to SGPT_F16 / SGPT_BF16 models");
+    if ((d->qk_split != 0 || d->split_weights != 0) && d->compute_dtype != SGPT_F16 && d->compute_dtype != SGPT_BF16)
+        return fail(c, SGPT_ERR_INVALID, "qk_split / split_weights apply to SGPT_F16 / SGPT_BF16 models");
 
     std::unordered_map<std::string, const sgpt_tensor_view*> byname;
     for (size_t i = 0; i < nt; ++i) byname[tv[i].name] = &tv[i];
@@ -342,9 +354,18 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
             l.s_fc = (float*)dalloc((size_t)ffn * 4); l.s_proj = (float*)dalloc((size_t)dm * 4);
         }
         if (st != SGPT_OK) break;
-        const bool split = m->d.qk_split != 0;
-        if (split) { l.w_qk3 = dalloc((size_t)2 * dm * 3 * dm * 2); if (!l.w_qk3) break; }
+        const bool split_all = m->d.split_weights != 0;
+        const bool split = m->d.qk_split != 0 || split_all;
+        if (split) { l.w_qkv3 = dalloc((size_t)(split_all ? 3 : 2) * dm * 3 * dm * 2); if (!l.w_qkv3) break; }
+        if (split_all) {
+            l.w_o3 = dalloc((size_t)dm * 3 * dm * 2); l.w_fc3 = dalloc((size_t)ffn * 3 * dm * 2); l.w_proj3 = dalloc((size_t)dm * 3 * ffn * 2);
+            if (!l.w_o3 || !l.w_fc3 || !l.w_proj3) break;
+        }
         const int dt16 = f16 ? DT_F16 : DT_BF16;
+        auto pack3 = [&](const std::string& name, int64_t rows, int64_t cols, void* dst3) {
+            const float* src = find(name, rows * cols);
+            if (src) launch_pack_split_rows(src, rows, cols, dst3, dt16, 0);
+        };
         if (bloom) {
             const float* wq = find(p + "self_attention.query_key_value.weight", (int64_t)3 * dm * dm);
             const float* bq = find(p + "self_attention.query_key_value.bias", (int64_t)3 * dm);
@@ -353,23 +374,27 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
             launch_qkv_deinterleave(wq, stage, H, dh, dm, 0);          // rows [h,3,dh] -> [q | k | v]
             launch_qkv_deinterleave(bq, l.b_qkv, H, dh, 1, 0);
             pack_rows(stage, (int64_t)3 * dm, dm, l.w_qkv, 0, l.s_qkv);
-            if (split) launch_pack_split_rows(stage, (long)2 * dm, dm, l.w_qk3, dt16, 0);      // q and k rows
+            if (split) launch_pack_split_rows(stage, (long)(split_all ? 3 : 2) * dm, dm, l.w_qkv3, dt16, 0);      // q and k (and v) rows
             pack_w(p + "self_attention.dense.weight", dm, dm, l.w_o, 0, l.s_o);
+            if (split_all) pack3(p + "self_attention.dense.weight", dm, dm, l.w_o3);
         } else {
             if (split) {
                 const float* wq = find(p + attn + "q_proj.weight", (int64_t)dm * dm);
                 const float* wk = find(p + attn + "k_proj.weight", (int64_t)dm * dm);
                 if (!wq || !wk) break;
-                launch_pack_split_rows(wq, dm, dm, l.w_qk3, dt16, 0);
-                launch_pack_split_rows(wk, dm, dm, (bf16_t*)l.w_qk3 + (size_t)dm * 3 * dm, dt16, 0);
+                launch_pack_split_rows(wq, dm, dm, l.w_qkv3, dt16, 0);
+                launch_pack_split_rows(wk, dm, dm, (bf16_t*)l.w_qkv3 + (size_t)dm * 3 * dm, dt16, 0);
+                if (split_all) pack3(p + attn + "v_proj.weight", dm, dm, (bf16_t*)l.w_qkv3 + (size_t)2 * dm * 3 * dm);
             }
             pack_w(p + attn + "q_proj.weight", dm, dm, l.w_qkv, 0, l.s_qkv);
             pack_w(p + attn + "k_proj.weight", dm, dm, l.w_qkv, dm, l.s_qkv);
             pack_w(p + attn + "v_proj.weight", dm, dm, l.w_qkv, (int64_t)2 * dm, l.s_qkv);
             pack_w(p + attn + "out_proj.weight", dm, dm, l.w_o, 0, l.s_o);
+            if (split_all) pack3(p + attn + "out_proj.weight", dm, dm, l.w_o3);
         }
         pack_w(p + fc1 + ".weight", ffn, dm, l.w_fc, 0, l.s_fc);
         pack_w(p + fc2 + ".weight", dm, ffn, l.w_proj, 0, l.s_proj);
+        if (split_all) { pack3(p + fc1 + ".weight", ffn, dm, l.w_fc3); pack3(p + fc2 + ".weight", dm, ffn, l.w_proj3); }
     }
     if (fp8 && st == SGPT_OK) {
         m->dq[0] = dalloc((size_t)3 * dm * dm * 2); m->dq[1] = dalloc((size_t)dm * dm * 2);
@@ -381,6 +406,15 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
         if (m->h_amax && hipMemsetAsync(m->h_amax, 0, (size_t)d->n_layers * 8, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memset");
     }
     m->shift.assign((size_t)d->n_layers * RS_N, 0);
+    m->ln_floor.assign((size_t)d->n_layers, 0);
+    m->prec.assign((size_t)d->n_layers * PC_N, 0);
+    m->split_all = d->split_weights != 0;
+    if (d->qk_split != 0)              // the round-3 switch: the Q / K projection of every block contracts over hi + lo pairs
+        for (int i = 0; i < d->n_layers; ++i) m->prec[(size_t)i * PC_N + PC_LN1] = 1;
+    if (st == SGPT_OK && bf && !fp8) {
+        m->crest_dev = (unsigned*)dalloc((size_t)d->n_layers * RS_N * 4);
+        if (m->crest_dev && hipMemsetAsync(m->crest_dev, 0, (size_t)d->n_layers * RS_N * 4, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memset");
+    }
     if (st == SGPT_OK) {
         m->range_dev = (unsigned*)dalloc((size_t)(1 + d->n_layers * RS_N) * 4);
         if (m->range_dev && hipMemsetAsync(m->range_dev, 0, (size_t)(1 + d->n_layers * RS_N) * 4, 0) != hipSuccess) st = fail(c, SGPT_ERR_HIP, "memset");
@@ -404,7 +438,10 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
             int k = (int)std::ceil(std::log2(bound / 16384.f));
             k = k < 1 ? 1 : k;
             if (k > RS_MAX_SHIFT) st = fail(c, SGPT_ERR_RANGE, "SGPT_F16: LayerNorm parameters beyond any usable range shift; load with SGPT_BF16");
-            for (int i = 0; i < d->n_layers && st == SGPT_OK; ++i) m->shift[(size_t)i * RS_N + RS_LN1] = m->shift[(size_t)i * RS_N + RS_LN2] = k;
+            for (int i = 0; i < d->n_layers && st == SGPT_OK; ++i) {
+                m->shift[(size_t)i * RS_N + RS_LN1] = m->shift[(size_t)i * RS_N + RS_LN2] = k;
+                m->ln_floor[i] = k;
+            }
         }
     }
     if (st != SGPT_OK) { sgpt_model_free(m); return st; }
@@ -460,13 +497,22 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_x = carve((size_t)T * dm * 4);                        // residual stream fp32
-    // qk_split: the LayerNorm-1 output is [hi | lo | hi] rows of 3 * d (the Q / K projection contracts over all three blocks,
-    // everything else reads the first), and the attention context gets its own buffer
-    const bool split = m->d.qk_split != 0 && bf && m->d.compute_dtype != SGPT_FP8W && m->d.compute_dtype != SGPT_FP8M;
-    const size_t o_a = carve((size_t)T * dm * esz * (split ? 3 : 1));    // LN output (GPT-Neo: also attention ctx)
-    const size_t o_c = (gptj || split) ? carve((size_t)T * dm * esz) : o_a;   // GPT-J: ctx separate (ln_1 output feeds the MLP too)
-    const size_t o_qkv = carve(((size_t)T + SLACK) * 3 * dm * esz);      // bf16: [T][2d] qk + V^T [d][T]; fp32: [T][3d]
-    const size_t o_h = carve((size_t)T * ffn * esz);                     // MLP hidden (FP8M: e4m3 codes in the same region)
+    // Precision plan (prec[]): a split class is stored as [hi | lo | hi] rows of 3 x its width (the consuming GEMM contracts over
+    // all three blocks against [W_hi | W_hi | W_lo]; a consumer that is not split reads the first block alone).  Any split at
+    // all: the attention context gets its own buffer (the LayerNorm buffer has 3 d rows then).
+    const bool can_split = bf && m->d.compute_dtype != SGPT_FP8W && m->d.compute_dtype != SGPT_FP8M;
+    bool any_ln = false, any_att = false, any_ctx = false, any_h = false;
+    if (can_split)
+        for (int li = 0; li < n_layers_run; ++li) {
+            const int* pc = &m->prec[(size_t)li * PC_N];
+            any_ln |= pc[PC_LN1] != 0 || pc[PC_LN2] != 0; any_att |= pc[PC_ATT] != 0; any_ctx |= pc[PC_CTX] != 0; any_h |= pc[PC_H] != 0;
+        }
+    const bool split = any_ln || any_att || any_ctx || any_h;
+    const size_t o_a = carve((size_t)T * dm * esz * (any_ln ? 3 : 1));    // LN output (GPT-Neo: also attention ctx)
+    const size_t o_c = (gptj || split) ? carve((size_t)T * dm * esz * (any_ctx ? 3 : 1)) : o_a;   // GPT-J: ctx separate (ln_1 output feeds the MLP too)
+    const size_t qkv_bytes = ((size_t)T + SLACK) * 3 * dm * esz;
+    const size_t o_qkv = carve(qkv_bytes * (any_att ? 2 : 1));           // bf16: [T][2d] qk + V^T [d][T] (x3 attention: the lo halves behind); fp32: [T][3d]
+    const size_t o_h = carve((size_t)T * ffn * esz * (any_h ? 3 : 1));                     // MLP hidden (FP8M: e4m3 codes in the same region)
     // FP8M: fp8 MFMA on all four projections when the shapes fit the 256x256x128 kernel and the activation scales are
     // calibrated; otherwise (and while calibrating) the block runs the SGPT_FP8W arithmetic (weights de-quantised to bf16)
     const bool shapes8 = gemm_fp8_shape_ok(T, ffn, dm) && gemm_fp8_shape_ok(T, dm, ffn) && gemm_fp8_shape_ok(T, 2 * dm, dm);
@@ -493,13 +539,18 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     // (a masked key contributes p = 0, and 0 * NaN = NaN): the slack behind the q/k/v buffers, and -- when
     // the attention context has its own buffer (GPT-J) -- the filler rows past the last sequence.  The
     // workspace is reused across calls / dtypes, so stale bytes there can decode to NaN.
+    const long att_lo = (long)(qkv_bytes / 2);      // element distance of the lo halves of q | k and of V^T (x3 attention)
     if (bf) {
         HIPC(c, hipMemsetAsync((bf16_t*)qkv + (size_t)T * 2 * dm, 0, SLACK * 2 * dm * esz, s));
         HIPC(c, hipMemsetAsync((bf16_t*)vt + (size_t)T * dm, 0, SLACK * dm * esz, s));
+        if (any_att) {
+            HIPC(c, hipMemsetAsync((bf16_t*)qkv + att_lo + (size_t)T * 2 * dm, 0, SLACK * 2 * dm * esz, s));
+            HIPC(c, hipMemsetAsync((bf16_t*)vt + att_lo + (size_t)T * dm, 0, SLACK * dm * esz, s));
+        }
     } else {
         HIPC(c, hipMemsetAsync((float*)qkv + (size_t)T * 3 * dm, 0, SLACK * 3 * dm * esz, s));
     }
-    if (gptj || mlp8 || split) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz, s));   // (fp8: stale bytes would decode to NaN codes)
+    if (gptj || mlp8 || split) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz * (any_ctx ? 3 : 1), s));   // (fp8: stale bytes would decode to NaN codes)
     launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, m->d.vocab, m->d.max_pos, s);
     if (m->emb_ln_g) launch_layernorm(x, m->emb_ln_g, m->emb_ln_b, x, SGPT_F32, T, dm, m->d.ln_eps, s);   // BLOOM :499
     for (int li = 0; li < n_layers_run; ++li) {
@@ -522,6 +573,12 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         const int k_ln1 = f16m ? sh[RS_LN1] : 0, k_qkv = f16m ? sh[RS_QKV] : 0, k_h = f16m ? sh[RS_H] : 0;
         const int k_ln2 = f16m ? (gptj ? sh[RS_LN1] : sh[RS_LN2]) : 0;     // GPT-J: ln_1's output feeds the MLP too
         unsigned* slots = m->range_dev + 1 + (size_t)li * RS_N;
+        // this block's precision plan
+        const int* pc = &m->prec[(size_t)li * PC_N];
+        const int p_ln1 = can_split ? pc[PC_LN1] : 0;                  // 0 | 1 (q, k split) | 2 (q, k, v split) | 3 (q, k: activation split only)
+        const bool p_att = can_split && pc[PC_ATT] != 0, p_ctx = can_split && pc[PC_CTX] != 0, p_h = can_split && pc[PC_H] != 0;
+        const bool p_ln2 = can_split && (gptj ? p_ln1 != 0 : pc[PC_LN2] != 0);   // GPT-J: fc1 reads ln_1's output
+        unsigned* crest = (m->probing && m->crest_dev) ? m->crest_dev + (size_t)li * RS_N : nullptr;
         GemmArgs g{};
         g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
         g.range_flag = f16m ? (int*)m->range_dev : nullptr;
@@ -550,35 +607,41 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             { Prof pr(c, s, 2.0 * T * (double)dm * dm); launch_gemm_fp8(EPI_BIAS_RESID, 0, q, s); }
             q.resid = nullptr;
         } else {
-        if (split) launch_layernorm_split(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln1));
+        const long lda1 = p_ln1 ? 3 * dm : dm;                          // row stride of this block's LayerNorm-1 output
+        if (p_ln1) launch_layernorm_split(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln1));
         else launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln1));
+        if (crest && bf) launch_crest16(a, T, dm, lda1, dt, crest + RS_LN1, s);
         if (bf) {
-            // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]
+            // Q,K -> qk[T][2d] row-major ; V -> V^T[d][T]   (p_att: each also as a lo half, att_lo elements behind)
             g.W = l.w_qkv; g.out = qkv; g.ldo = 2 * dm; g.bias = l.b_qkv;                           // bias: BLOOM only
+            g.lda = lda1;
             g.in_mul = pow2f(k_ln1); g.out_mul = g.out_mul2 = pow2f(-k_qkv); g.range_amax = f16m ? slots + RS_QKV : nullptr;
-            if (split) {
-                // a_hi.W_hi + a_lo.W_hi + a_hi.W_lo as ONE contraction over K' = 3d; V from the hi block alone
-                g.lda = 3 * dm; g.K = 3 * dm; g.ldw = 3 * dm; g.k_algo = dm; g.W = l.w_qk3; g.N = 2 * dm;
-                gemm(c, dt, EPI_STORE, dt, g, s);
-                g.K = dm; g.ldw = dm; g.k_algo = 0;
-                g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; g.N = dm; g.out = vt; g.ldo = T;
-                g.bias = l.b_qkv ? l.b_qkv + 2 * dm : nullptr;
-                gemm(c, dt, EPI_VT, dt, g, s);
-                g.lda = dm;
-            } else if (gemm_qkv_one_launch(T, 2 * dm, c->force256 != 0)) {        // query-sized batch: one launch (a launch costs ~8 us there)
+            g.lo_delta = p_att ? att_lo : 0; g.lo_delta2 = p_att ? att_lo : 0;
+            if ((p_ln1 == 0 || p_ln1 == 2) && gemm_qkv_one_launch(T, 2 * dm, c->force256 != 0)) {        // query-sized batch: one launch (a launch costs ~8 us there)
+                if (p_ln1 == 2) { g.W = l.w_qkv3; g.K = 3 * dm; g.ldw = 3 * dm; g.k_algo = dm; }
                 g.N = 3 * dm; g.n_split = 2 * dm; g.out2 = vt; g.ldo2 = T;
                 gemm(c, dt, EPI_QKV, dt, g, s);
                 g.out2 = nullptr; g.n_split = 0;
             } else {
+                // split Q / K: a_hi.W_hi + a_lo.W_hi + a_hi.W_lo as ONE contraction over K' = 3d; V from the hi block alone
+                // unless the plan splits it too (p_ln1 == 2)
+                // (p_ln1 == 3: the activation alone is split -- the first TWO blocks of both layouts, [a_hi | a_lo] . [W_hi | W_hi])
+                if (p_ln1) { g.K = (p_ln1 == 3 ? 2 : 3) * dm; g.ldw = 3 * dm; g.k_algo = dm; g.W = l.w_qkv3; }
                 g.N = 2 * dm;
                 gemm(c, dt, EPI_STORE, dt, g, s);
-                g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; g.N = dm; g.out = vt; g.ldo = T;
+                if (p_ln1 == 2) g.W = (bf16_t*)l.w_qkv3 + (size_t)2 * dm * 3 * dm;
+                else { g.K = dm; g.ldw = dm; g.k_algo = 0; g.W = (bf16_t*)l.w_qkv + (size_t)2 * dm * dm; }
+                g.N = dm; g.out = vt; g.ldo = T;
                 g.bias = l.b_qkv ? l.b_qkv + 2 * dm : nullptr;
                 gemm(c, dt, EPI_VT, dt, g, s);
             }
+            g.K = dm; g.ldw = dm; g.k_algo = 0; g.lda = dm; g.lo_delta = g.lo_delta2 = 0;
             if (gptj) launch_rope(qkv, dt, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
             at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
+            at.x3 = p_att ? 1 : 0; at.qk_lo_delta = att_lo; at.v_lo_delta = att_lo;
+            at.ldo = p_ctx ? 3 * dm : dm; at.ctx_lo_delta = p_ctx ? dm : 0; at.ctx_hi2_delta = p_ctx ? 2 * dm : 0;
             launch_attn_bf16(at, s);
+            if (crest) launch_crest16(ctx, T, dm, at.ldo, dt, crest + RS_QKV, s);
             if (m->calibrating)   // FP8M calibration: range of this block's attention context
                 launch_absmax16(ctx, (long)T * dm, dt, m->h_amax + m->d.n_layers + li, s);
         } else {
@@ -588,10 +651,12 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             at.q = qkv; at.k = (float*)qkv + dm; at.v = (float*)qkv + 2 * dm; at.ldq = 3 * dm;
             launch_attn_f32(at, s);
         }
-        // x += ctx . Wo^T (+ bo)      (the context carries v's shift)
-        g.A = ctx; g.W = l.w_o; g.N = dm; g.K = dm; g.ldw = dm; g.out = x; g.ldo = dm; g.bias = l.b_o; g.resid = x;
+        // x += ctx . Wo^T (+ bo)      (the context carries v's shift; split context: K' = 3d against [Wo_hi | Wo_hi | Wo_lo])
+        g.A = ctx; g.W = l.w_o; g.N = dm; g.K = dm; g.ldw = dm; g.lda = dm; g.out = x; g.ldo = dm; g.bias = l.b_o; g.resid = x;
+        if (p_ctx) { g.W = l.w_o3; g.K = 3 * dm; g.ldw = 3 * dm; g.lda = 3 * dm; g.k_algo = dm; }
         g.in_mul = pow2f(k_qkv); g.out_mul = g.out_mul2 = 1.0f; g.range_amax = nullptr;
         gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
+        g.k_algo = 0;
         }
         // GPT-Neo: x += MLP(LN2(x));  GPT-J (parallel block, HF:gptj:400-411): x += MLP(LN1(x_old)), `a` still holds it
         if (mlp8) {
@@ -606,16 +671,29 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             q.resid = x; q.out = x; q.ldo = dm;
             { Prof pr(c, s, 2.0 * T * (double)ffn * dm); launch_gemm_fp8(EPI_BIAS_RESID, 0, q, s); }
         } else {
-            if (!gptj) launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln2));
-            g.A = a; g.lda = (gptj && split) ? 3 * dm : dm;      // GPT-J: ln_1's output again -- the hi block of a split row
-            g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ffn; g.bias = l.b_fc; g.resid = nullptr;
+            // LayerNorm-2 (GPT-J: ln_1's output again, `a` still holds it with its row stride)
+            long lda2 = gptj ? (p_ln1 ? 3 * dm : dm) : (p_ln2 ? 3 * dm : dm);
+            if (!gptj) {
+                if (p_ln2) launch_layernorm_split(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln2));
+                else launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln2));
+                if (crest && bf) launch_crest16(a, T, dm, lda2, dt, crest + RS_LN2, s);
+            }
+            const long ldh = p_h ? 3 * ffn : ffn;
+            g.A = a; g.lda = lda2;
+            g.W = l.w_fc; g.N = ffn; g.K = dm; g.ldw = dm; g.out = h; g.ldo = ldh; g.bias = l.b_fc; g.resid = nullptr;
+            if (p_ln2) { g.W = l.w_fc3; g.K = 3 * dm; g.ldw = 3 * dm; g.k_algo = dm; }
+            if (p_h) { g.lo_delta = ffn; g.hi2_delta = 2 * ffn; }       // the GELU output as a [hi | lo | hi] row for fc2
             g.in_mul = pow2f(k_ln2); g.out_mul = pow2f(-k_h); g.range_amax = f16m ? slots + RS_H : nullptr;
             gemm(c, dt, EPI_BIAS_GELU, dt, g, s);
+            g.lo_delta = g.hi2_delta = 0; g.k_algo = 0;
+            if (crest && bf) launch_crest16(h, T, ffn, ldh, dt, crest + RS_H, s);
             if (m->calibrating) launch_absmax16(h, (long)T * ffn, dt, m->h_amax + li, s);   // FP8M calibration: range of this block's GELU output
-            g.A = h; g.lda = ffn; g.W = l.w_proj; g.N = dm; g.K = ffn; g.ldw = ffn; g.out = x; g.ldo = dm;
+            g.A = h; g.lda = ldh; g.W = l.w_proj; g.N = dm; g.K = ffn; g.ldw = ffn; g.out = x; g.ldo = dm;
+            if (p_h) { g.W = l.w_proj3; g.K = 3 * ffn; g.ldw = 3 * ffn; g.k_algo = ffn; }
             g.bias = l.b_proj; g.resid = x;
             g.in_mul = pow2f(k_h); g.out_mul = 1.0f; g.range_amax = nullptr;
             gemm(c, dt, EPI_BIAS_RESID, SGPT_F32, g, s);
+            g.k_algo = 0;
         }
     }
     if (hidden_out) {
@@ -624,7 +702,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     }
     if (out)
         launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, apply_final_ln,
-                        pool_mode, normalize, m->pool_w, m->pool_w_n, out, s);
+                        pool_mode, normalize, m->pool_w, m->pool_w_n, out, s,
+                        m->d.compute_dtype == SGPT_F16 ? (int*)m->range_dev : nullptr);
     if (layer_out)
         launch_lnf_pool(x, m->lnf_g, m->lnf_b, seq_off, seq_len, pad_left, B, dm, m->d.ln_eps, apply_final_ln,
                         pool_mode, normalize, m->pool_w, m->pool_w_n, layer_out + (size_t)n_layers_run * B * dm, s);
@@ -1165,8 +1244,97 @@ sgpt_status sgpt_model_set_range_shifts(sgpt_model* m, const int32_t* shifts, in
         return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_range_shifts: SGPT_F16 models, n = 4 * n_layers");
     for (int i = 0; i < n; ++i)
         if (shifts[i] < 0 || shifts[i] > RS_MAX_SHIFT) return fail(c, SGPT_ERR_INVALID, "range shifts must lie in [0, 40]");
+    // the LayerNorm kernels have no run-time range tracker: their shifts may not go below the bound sgpt_model_load derived
+    // from THIS checkpoint's parameters (shifts pinned from another checkpoint would overflow to inf unnoticed)
+    for (int i = 0; i < n; ++i) {
+        const int cls = i % RS_N, blk = i / RS_N;
+        if ((cls == RS_LN1 || cls == RS_LN2) && shifts[i] < m->ln_floor[blk])
+            return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_range_shifts: a LayerNorm shift below the bound of this checkpoint's LayerNorm parameters (block " +
+                        std::to_string(blk) + ": at least " + std::to_string(m->ln_floor[blk]) + ")");
+    }
     for (int i = 0; i < n; ++i) m->shift[i] = shifts[i];
     c->generation++;
+    return SGPT_OK;
+}
+
+// ---- precision plan: split-precision (hi + lo) operand classes per block ----------------------------------------------
+sgpt_status sgpt_model_set_precision(sgpt_model* m, const int32_t* plan, int32_t n) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    const int cd = m->d.compute_dtype;
+    if (!plan || n != m->d.n_layers * PC_N) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: n must be 5 * n_layers");
+    const int dh = m->d.d_model / m->d.n_heads;
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        const int cls = i % PC_N, v = plan[i];
+        if (v < 0 || v > (cls == PC_LN1 ? 3 : 1)) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: entries are 0 | 1 (LayerNorm-1 class: 0 ... 3)");
+        any |= v != 0;
+        const bool legacy_ok = cls == PC_LN1 && (v == 1 || v == 3) && m->L[i / PC_N].w_qkv3 != nullptr;
+        if (v != 0 && !m->split_all && !legacy_ok)
+            return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: the model was loaded without split weight copies (sgpt_model_desc.split_weights)");
+        if (cls == PC_ATT && v != 0 && (m->d.arch == SGPT_ARCH_GPTJ || !attn_x3_supported(dh)))
+            return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: split-precision attention needs head_dim 64 or 128 and no rotary embedding (GPT-Neo / BLOOM)");
+        if (cls == PC_LN2 && m->d.arch == SGPT_ARCH_GPTJ && (v != 0) != (plan[i - PC_LN2 + PC_LN1] != 0))
+            return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: GPT-J's MLP reads ln_1's output: the LayerNorm-2 entry must follow the LayerNorm-1 entry");
+    }
+    if (any && cd != SGPT_F16 && cd != SGPT_BF16) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision applies to SGPT_F16 / SGPT_BF16 models");
+    for (int i = 0; i < n; ++i) m->prec[i] = plan[i];
+    c->generation++;                                      // captured graphs carry the old launch sequence
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_model_get_precision(sgpt_model* m, int32_t* plan, int32_t n) {
+    if (!m || !plan || n != m->d.n_layers * PC_N) return m ? fail(m->ctx, SGPT_ERR_INVALID, "sgpt_model_get_precision: n must be 5 * n_layers") : SGPT_ERR_INVALID;
+    for (int i = 0; i < n; ++i) plan[i] = m->prec[i];
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_model_precision_probe_begin(sgpt_model* m) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (!m->crest_dev) return fail(c, SGPT_ERR_INVALID, "the precision probe applies to SGPT_F16 / SGPT_BF16 models");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());
+    HIPC(c, hipMemset(m->crest_dev, 0, (size_t)m->d.n_layers * RS_N * 4));
+    m->probing = true;
+    c->generation++;                                      // a graph captured while probing must not outlive the probe
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_model_precision_probe_end(sgpt_model* m, float* crest_out) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (!m->probing) return fail(c, SGPT_ERR_INVALID, "sgpt_model_precision_probe_end without _begin");
+    m->probing = false;
+    c->generation++;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());
+    if (crest_out) HIPC(c, hipMemcpy(crest_out, m->crest_dev, (size_t)m->d.n_layers * RS_N * 4, hipMemcpyDeviceToHost));
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_row_crest(sgpt_ctx* c, const void* x, int32_t dtype, int64_t n, int32_t d, int64_t ld, float* crest_out, void* stream) {
+    if (!c || !x || !crest_out || n <= 0 || n > INT32_MAX || d <= 0 || d % 2 || ld < d || (dtype != SGPT_BF16 && dtype != SGPT_F16))
+        return fail(c, SGPT_ERR_INVALID, "sgpt_row_crest: bad arguments (16-bit rows, d % 2 == 0)");
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* slot = (unsigned*)c->range_flag + 16;          // a scratch word of the ctx's 256-byte flag block
+    HIPC(c, hipMemsetAsync(slot, 0, 4, s));
+    launch_crest16(x, (int)n, d, ld, dtype, slot, s);
+    unsigned h = 0;
+    HIPC(c, hipMemcpyAsync(&h, slot, 4, hipMemcpyDeviceToHost, s));
+    HIPC(c, hipStreamSynchronize(s));
+    memcpy(crest_out, &h, 4);
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_split16(sgpt_ctx* c, const float* in, int64_t n, int32_t d, int32_t layout, void* out, int32_t out_dtype,
+                         void* stream) {
+    if (!c || !in || !out || n <= 0 || d <= 0 || d % 4 || (layout != 0 && layout != 1) || (out_dtype != SGPT_BF16 && out_dtype != SGPT_F16))
+        return fail(c, SGPT_ERR_INVALID, "sgpt_split16: bad arguments (d % 4 == 0, layout 0 | 1, 16-bit out_dtype)");
+    HIPC(c, hipSetDevice(c->device));
+    launch_split16_rows(in, n, d, layout, out, out_dtype, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
     return SGPT_OK;
 }
 
@@ -1190,6 +1358,24 @@ sgpt_status sgpt_linear(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out_dty
     g.ldo = epi == EPI_VT ? M : N; g.bias = bias; g.resid = resid;
     g.range_flag = out_dtype == SGPT_F16 ? c->range_flag : nullptr;
     gemm(c, dtype, epi, out_dtype, g, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_linear_split(sgpt_ctx* c, int32_t dtype, int32_t epi, const void* A, const void* W, const float* bias, void* out,
+                              int64_t ldo, int64_t lo_delta, int64_t hi2_delta, int32_t M, int32_t N, int32_t K, void* stream) {
+    if (!c || !A || !W || !out || M <= 0 || N <= 0 || K <= 0 || lo_delta == 0) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_split: bad arguments");
+    if (dtype != SGPT_BF16 && dtype != SGPT_F16) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_split: 16-bit operands");
+    if (epi != EPI_STORE && epi != EPI_BIAS_GELU && epi != EPI_VT) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_split: epi 0 (store), 1 (bias+gelu) or 4 (transposed store)");
+    if (epi == EPI_BIAS_GELU && !bias) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_split: bias required");
+    if (epi == EPI_VT && (M % 128 || hi2_delta != 0)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_split: transposed store needs M % 128 == 0 and writes hi + lo only");
+    if (K % 8 || N % 4 || ldo < (epi == EPI_VT ? M : N)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_split: K % 8, N % 4, ldo >= row length");
+    HIPC(c, hipSetDevice(c->device));
+    GemmArgs g{};
+    g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.m_valid = M; g.N = N; g.K = K; g.out = out; g.ldo = ldo; g.bias = bias;
+    g.lo_delta = lo_delta; g.hi2_delta = hi2_delta;
+    g.range_flag = dtype == SGPT_F16 ? c->range_flag : nullptr;
+    gemm(c, dtype, epi, dtype, g, (hipStream_t)stream);
     HIPC(c, hipGetLastError());
     return SGPT_OK;
 }

@@ -89,15 +89,26 @@ __device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor
 // NQ = 16-query fragments per wave.  NQ = 1: 8 waves x 16 queries.  NQ = 2 (DH = 64): 4 waves x 32 queries -- every K / V^T
 // fragment read from LDS feeds two MFMAs, halving the LDS bytes per query; the SQ counters at S = 512 put the LDS array
 // right behind the VALU as this kernel's busiest unit (profiles/r03_attn_pmc.txt).
-template <typename H, int DH, bool OUT8, int NQ, int NW = (NQ == 1 ? 8 : 4)>
-__global__ __launch_bounds__(64 * NW, NQ == 2 ? SGPT_ATTN_Q32_WAVES : (NW <= 2 ? 3 : ATTN_WAVES_PER_SIMD))   // (NW = 2: 4 staging loads per thread)
+// MODE 0: the kernel as described.  MODE 1: the context additionally leaves as a split-precision pair (hi at ctx, lo = round16(v - hi)
+// at ctx + ctx_lo_delta, a second hi at ctx + ctx_hi2_delta: the [hi | lo | hi] row the split out-projection contracts over).
+// MODE 2 ("x3" attention): q, k, V^T and the probabilities ALL enter their MFMAs as hi + lo pairs of 16-bit values --
+// S = k_hi.q_hi + k_lo.q_hi + k_hi.q_lo and O += v_hi.p_hi + v_lo.p_hi + v_hi.p_lo, i.e. products to ~2^-22 on the 16-bit MFMA;
+// the lo halves of q | k and V^T sit qk_lo_delta / v_lo_delta elements behind the hi halves (written by the projections'
+// split epilogues).  Twice the LDS and three times the MFMAs of an attention that is < 2 % of a block's FLOPs; 2 waves per
+// SIMD (the second fragment set does not fit 128 VGPRs).  Context split as MODE 1 when ctx_lo_delta != 0.
+template <typename H, int DH, bool OUT8, int NQ, int NW = (NQ == 1 ? 8 : 4), int MODE = 0>
+__global__ __launch_bounds__(64 * NW, MODE == 2 ? 2 : (NQ == 2 ? SGPT_ATTN_Q32_WAVES : (NW <= 2 ? 3 : ATTN_WAVES_PER_SIMD)))   // (NW = 2: 4 staging loads per thread)
 void attn16_lds_kernel(const AttnArgs p) {
+    constexpr bool X3 = MODE == 2;
+    static_assert(!(MODE != 0 && OUT8), "split-precision modes write 16-bit contexts");
     constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
     constexpr int NT = 64 * NW, QW = 16 * NQ, QB = NW * QW;    // NW waves per block, QW queries per wave, QB per block
     constexpr int ORS = DH * 2 + 16;                           // output-transpose row stride (bytes)
     constexpr int NB = (DH <= 64 && SGPT_ATTN_STAGES == 2) ? 2 : 1;   // LDS stages of the K / V^T tiles
     __shared__ __attribute__((aligned(16))) uint4 Ks[NB][64 * CPR];
     __shared__ __attribute__((aligned(16))) uint4 Vs[NB][DH * 8];
+    __shared__ __attribute__((aligned(16))) uint4 KsL[X3 ? 64 * CPR : 1];     // lo halves of the key / V^T tile (MODE 2)
+    __shared__ __attribute__((aligned(16))) uint4 VsL[X3 ? DH * 8 : 1];
     __shared__ __attribute__((aligned(16))) char Os[NW][16 * ORS];
     const int sq = blockIdx.z, head = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -120,6 +131,14 @@ void attn16_lds_kernel(const AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             qf[f][ks] = *reinterpret_cast<const uint4*>(qb + (long)(s0 + q0 + 16 * f + fr) * p.ldq + ks * 32 + 8 * g);
+    uint4 qfl[X3 ? NQ : 1][X3 ? KS : 1];
+    if constexpr (X3) {
+#pragma unroll
+        for (int f = 0; f < NQ; ++f)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qfl[f][ks] = *reinterpret_cast<const uint4*>(qb + p.qk_lo_delta + (long)(s0 + q0 + 16 * f + fr) * p.ldq + ks * 32 + 8 * g);
+    }
 
     f32x4 o[NQ][DT];
     float m_run[NQ], l_run[NQ];
@@ -139,24 +158,33 @@ void attn16_lds_kernel(const AttnArgs p) {
     // issued before tile j is consumed from LDS, so a sequence of several key tiles (S >= 128) does not pay one
     // un-hidden global-load round trip per tile ----
     constexpr int KU = (64 * CPR + NT - 1) / NT, VU = (DH * 8 + NT - 1) / NT;
-    uint4 kreg[KU], vreg[VU];
+    uint4 kreg[KU], vreg[VU], kregl[X3 ? KU : 1], vregl[X3 ? VU : 1];
     auto tile_load = [&](int j0) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int c = t + NT * u, row = c / CPR, ch = c % CPR;
-            if (c < 64 * CPR) kreg[u] = ldg16u<ATTN_NT_LOAD>(kb + (long)(s0 + j0 + row) * p.ldq + ch * 8);
+            if (c < 64 * CPR) {
+                kreg[u] = ldg16u<ATTN_NT_LOAD>(kb + (long)(s0 + j0 + row) * p.ldq + ch * 8);
+                if constexpr (X3) kregl[u] = ldg16u<ATTN_NT_LOAD>(kb + p.qk_lo_delta + (long)(s0 + j0 + row) * p.ldq + ch * 8);
+            }
         }
 #pragma unroll
         for (int u = 0; u < VU; ++u) {
             const int c = t + NT * u, row = c >> 3, ch = c & 7;
-            if (c < DH * 8) vreg[u] = ldg16u<ATTN_NT_LOAD>(vt + (long)row * p.ldvt + s0 + j0 + ch * 8);
+            if (c < DH * 8) {
+                vreg[u] = ldg16u<ATTN_NT_LOAD>(vt + (long)row * p.ldvt + s0 + j0 + ch * 8);
+                if constexpr (X3) vregl[u] = ldg16u<ATTN_NT_LOAD>(vt + p.v_lo_delta + (long)row * p.ldvt + s0 + j0 + ch * 8);
+            }
         }
     };
     auto tile_store = [&](int b) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int c = t + NT * u, row = c / CPR, ch = c % CPR;
-            if (c < 64 * CPR) Ks[b][row * CPR + (ch ^ (row & 7))] = kreg[u];
+            if (c < 64 * CPR) {
+                Ks[b][row * CPR + (ch ^ (row & 7))] = kreg[u];
+                if constexpr (X3) KsL[row * CPR + (ch ^ (row & 7))] = kregl[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < VU; ++u) {
@@ -170,6 +198,11 @@ void attn16_lds_kernel(const AttnArgs p) {
                 char* vrow = reinterpret_cast<char*>(&Vs[b][row * 8]);
                 *reinterpret_cast<uint2*>(vrow + ((4 * blk + g0) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vreg[u].x, vreg[u].y);
                 *reinterpret_cast<uint2*>(vrow + ((4 * blk + g0 + 1) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vreg[u].z, vreg[u].w);
+                if constexpr (X3) {
+                    char* vrl = reinterpret_cast<char*>(&VsL[row * 8]);
+                    *reinterpret_cast<uint2*>(vrl + ((4 * blk + g0) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vregl[u].x, vregl[u].y);
+                    *reinterpret_cast<uint2*>(vrl + ((4 * blk + g0 + 1) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vregl[u].z, vregl[u].w);
+                }
             }
         }
     };
@@ -206,6 +239,14 @@ void attn16_lds_kernel(const AttnArgs p) {
                 const uint4 kv = Kc[row * CPR + ((ks * 4 + g) ^ (row & 7))];
 #pragma unroll
                 for (int f = 0; f < NQ; ++f) s[f][nt] = Half<H>::mfma16(kv, qf[f][ks], s[f][nt]);
+                if constexpr (X3) {
+                    const uint4 kl = KsL[row * CPR + ((ks * 4 + g) ^ (row & 7))];
+#pragma unroll
+                    for (int f = 0; f < NQ; ++f) {
+                        s[f][nt] = Half<H>::mfma16(kl, qf[f][ks], s[f][nt]);
+                        s[f][nt] = Half<H>::mfma16(kv, qfl[f][ks], s[f][nt]);
+                    }
+                }
             }
         }
         // Softmax in the log2 domain: t = s * (scale * log2 e) [+ alibi * log2 e], p = 2^(t - m).  SQ counters at S = 512
@@ -214,7 +255,7 @@ void attn16_lds_kernel(const AttnArgs p) {
         // ALiBi term).  A tile every query of the fragment sees whole (all but the diagonal tile of a fragment, and the
         // window's low edge) takes the lean path: one multiply per score.  Elsewhere the compares run against
         // compile-time offsets of one per-lane distance.
-        uint32_t pw[NQ][8];
+        uint32_t pw[NQ][8], pwl[X3 ? NQ : 1][8];
 #pragma unroll
         for (int f = 0; f < NQ; ++f) {
             const int qf0 = q0 + 16 * f, qi = qf0 + fr;
@@ -256,6 +297,10 @@ void attn16_lds_kernel(const AttnArgs p) {
                 ps += (e0 + e1) + (e2 + e3);
                 pw[f][nt * 2] = Half<H>::pack2(e0, e1);          // probabilities in [0, 1]: inside either format's range
                 pw[f][nt * 2 + 1] = Half<H>::pack2(e2, e3);
+                if constexpr (X3) {
+                    pwl[f][nt * 2] = Half<H>::pack2(e0 - Half<H>::lo(pw[f][nt * 2]), e1 - Half<H>::hi(pw[f][nt * 2]));
+                    pwl[f][nt * 2 + 1] = Half<H>::pack2(e2 - Half<H>::lo(pw[f][nt * 2 + 1]), e3 - Half<H>::hi(pw[f][nt * 2 + 1]));
+                }
             }
             l_run[f] = l_run[f] * alpha + ps;
 #pragma unroll
@@ -266,10 +311,13 @@ void attn16_lds_kernel(const AttnArgs p) {
         // ---- O^T += V^T . P^T, two 32-key steps; k-slot j <-> key 32*step + 16*(j>>2) + 4g + (j&3) ----
 #pragma unroll
         for (int step = 0; step < 2; ++step) {
-            uint4 pu[NQ];
+            uint4 pu[NQ], pul[X3 ? NQ : 1];
 #pragma unroll
             for (int f = 0; f < NQ; ++f) {
                 pu[f].x = pw[f][step * 4]; pu[f].y = pw[f][step * 4 + 1]; pu[f].z = pw[f][step * 4 + 2]; pu[f].w = pw[f][step * 4 + 3];
+                if constexpr (X3) {
+                    pul[f].x = pwl[f][step * 4]; pul[f].y = pwl[f][step * 4 + 1]; pul[f].z = pwl[f][step * 4 + 2]; pul[f].w = pwl[f][step * 4 + 3];
+                }
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -278,6 +326,14 @@ void attn16_lds_kernel(const AttnArgs p) {
                 const uint4 vu = Vc[row * 8 + ((4 * step + g) ^ (row & 7))];
 #pragma unroll
                 for (int f = 0; f < NQ; ++f) o[f][dt] = Half<H>::mfma16(vu, pu[f], o[f][dt]);
+                if constexpr (X3) {
+                    const uint4 vl = VsL[row * 8 + ((4 * step + g) ^ (row & 7))];
+#pragma unroll
+                    for (int f = 0; f < NQ; ++f) {
+                        o[f][dt] = Half<H>::mfma16(vl, pu[f], o[f][dt]);
+                        o[f][dt] = Half<H>::mfma16(vu, pul[f], o[f][dt]);
+                    }
+                }
             }
         }
         }
@@ -333,6 +389,31 @@ void attn16_lds_kernel(const AttnArgs p) {
                 const int row = h * RPI + lane / CPR, ch = lane % CPR;
                 const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
                 if (qf0 + row < alloc) gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);   // (allocations are multiples of 8 rows)
+            }
+            if constexpr (MODE != 0) {
+                if (p.ctx_lo_delta != 0) {
+                    // split-precision context: lo = round16(v - hi) through the same per-wave slice (in order behind the reads
+                    // above), then the second copy of hi -- the [hi | lo | hi] row of the split out-projection
+#pragma unroll
+                    for (int pass = 1; pass < 3; ++pass) {
+                        if (pass == 2 && p.ctx_hi2_delta == 0) break;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            const float v0 = o[f][dt][0] * inv, v1 = o[f][dt][1] * inv, v2 = o[f][dt][2] * inv, v3 = o[f][dt][3] * inv;
+                            const uint32_t h01 = Half<H>::pack2(v0, v1), h23 = Half<H>::pack2(v2, v3);
+                            *reinterpret_cast<uint2_a*>(os + fr * ORS + (dt * 16 + 4 * g) * 2) = pass == 2 ? make_uint2(h01, h23) :
+                                make_uint2(Half<H>::pack2(v0 - Half<H>::lo(h01), v1 - Half<H>::hi(h01)),
+                                           Half<H>::pack2(v2 - Half<H>::lo(h23), v3 - Half<H>::hi(h23)));
+                        }
+                        bf16_t* ob2 = obase + (pass == 1 ? p.ctx_lo_delta : p.ctx_hi2_delta);
+#pragma unroll
+                        for (int h = 0; h < 16 / RPI; ++h) {
+                            const int row = h * RPI + lane / CPR, ch = lane % CPR;
+                            const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
+                            if (qf0 + row < alloc) gstore16<ATTN_NT>(ob2 + (long)row * p.ldo + ch * 8, v);
+                        }
+                    }
+                }
             }
         }
     }
@@ -392,6 +473,25 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs p) {
 
 void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.max_alloc_len + 127) / 128, a.H, a.B);
+    if (a.x3 || a.ctx_lo_delta != 0) {
+        // split-precision variants (MODE 2: hi + lo q / k / V^T / p; MODE 1: 16-bit attention, split context).  head_dim 256
+        // has no MODE 2 (its lo tiles do not fit the LDS): the caller keeps x3 = 0 there (attn_x3_supported)
+        if (a.out_fp8 || (a.x3 && a.dh == 256)) abort();
+#define ATTN_SPLIT_CASE(H)                                                                                                      \
+        if (a.x3) {                                                                                                             \
+            if (a.dh == 64) hipLaunchKernelGGL((attn16_lds_kernel<H, 64, false, 1, 8, 2>), grid, dim3(512), 0, s, a);           \
+            else if (a.dh == 128) hipLaunchKernelGGL((attn16_lds_kernel<H, 128, false, 1, 8, 2>), grid, dim3(512), 0, s, a);    \
+            else abort();                                                                                                       \
+        } else {                                                                                                                \
+            if (a.dh == 64) hipLaunchKernelGGL((attn16_lds_kernel<H, 64, false, 1, 8, 1>), grid, dim3(512), 0, s, a);           \
+            else if (a.dh == 128) hipLaunchKernelGGL((attn16_lds_kernel<H, 128, false, 1, 8, 1>), grid, dim3(512), 0, s, a);    \
+            else if (a.dh == 256) hipLaunchKernelGGL((attn16_lds_kernel<H, 256, false, 1, 8, 1>), grid, dim3(512), 0, s, a);    \
+            else abort();                                                                                                       \
+        }
+        if (a.dtype == DT_F16) { ATTN_SPLIT_CASE(f16_t) } else { ATTN_SPLIT_CASE(bf16_t) }
+#undef ATTN_SPLIT_CASE
+        return;
+    }
     // Long sequences, head_dim 64: 16-wave blocks of 256 queries stage every K / V^T tile once per 256 queries instead of
     // once per 128 (seq 512: 118.9 -> 117.4 ms per step; 64-query blocks, the other direction: -2 ... -8 %).  Only where the
     // last block of a sequence is at least half full (seq 300 = 256 + 48 queries: -1.4 %).

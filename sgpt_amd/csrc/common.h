@@ -234,6 +234,12 @@ struct GemmArgs {
     int k_algo;         // 0, or the K of the un-split problem when K carries split-precision blocks (profiling counts 2*M*N*k_algo)
     int kgroups;        // per-ctx low-latency mode: 2 = k-groups for under-filled small-tile launches (0 / 1 = off)
     int force256;       // per-ctx tile policy: 1 = keep 256x256 tiles even where the small-tile rule would apply (kernel tests)
+    // Split-precision outputs (16-bit OutT; 0 = off).  Besides out (hi = round16(v)) the epilogue writes lo = round16(v - hi) at
+    // element offset lo_delta from the hi element and, when hi2_delta != 0, a second copy of hi at hi2_delta: an activation
+    // that enters the next GEMM as a [hi | lo | hi] row of 3 K (lo_delta = K, hi2_delta = 2 K, ldo = 3 K), or q | k / V^T
+    // kept as separate hi and lo buffers for the split-precision attention (lo_delta = the buffers' distance).
+    // lo_delta2: the same for out2 (EPI_QKV's V^T part).
+    long lo_delta, hi2_delta, lo_delta2;
     // EPI_QKV
     void* out2;         // V^T [N - n_split][ldo2]
     long ldo2;
@@ -276,7 +282,13 @@ struct AttnArgs {
     int out_fp8;
     float out_scale;
     int* range_flag;
+    // split precision (attn.hip, MODE 1 / 2): x3 = 1: q | k, V^T and the probabilities as hi + lo pairs (lo halves qk_lo_delta /
+    // v_lo_delta elements behind the hi halves); ctx_lo_delta != 0: the context leaves as hi (ctx), lo (ctx + ctx_lo_delta) and,
+    // when ctx_hi2_delta != 0, a second hi (ctx + ctx_hi2_delta)
+    int x3;
+    long qk_lo_delta, v_lo_delta, ctx_lo_delta, ctx_hi2_delta;
 };
+inline bool attn_x3_supported(int dh) { return dh == 64 || dh == 128; }
 void launch_attn_bf16(const AttnArgs& a, hipStream_t s);   // 16-bit MFMA path (bf16 or f16 by a.dtype)
 void launch_attn_f32(const AttnArgs& a, hipStream_t s);
 
@@ -289,13 +301,18 @@ void launch_layernorm(const float* x, const float* g, const float* b, void* out,
 void launch_layernorm_split(const float* x, const float* g, const float* b, void* out, int out_dtype, int T, int d,
                             float eps, hipStream_t s, float out_mul);
 void launch_pack_split_rows(const float* src, long rows, long cols, void* dst, int out_dtype, hipStream_t s);
+// precision probe: max over rows of max|v| / rms(v) of a 16-bit operand [T][cols] (leading dim ld) folded into *out_bits
+void launch_crest16(const void* in, int T, int cols, long ld, int dtype, unsigned* out_bits, hipStream_t s);
+// fp32 [n][d] -> 16-bit [n][3 d]: layout 0 = [hi | lo | hi] (documents / activations), 1 = [hi | hi | lo] (queries / weights)
+void launch_split16_rows(const float* in, long n, int d, int layout, void* out, int out_dtype, hipStream_t s);
 // LayerNorm -> e4m3fn codes q[T,d] + one power-of-two scale per row (+ optionally the same rows in a 16-bit format)
 void launch_layernorm_q8(const float* x, const float* g, const float* b, void* q, float* scale, void* out16, int out16_dtype,
                          int T, int d, float eps, hipStream_t s);
 void launch_absmax16(const void* in, long numel, int dtype, unsigned* out_bits, hipStream_t s);   // max|x| of a bf16 / f16 array
 void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,
                      const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize,
-                     const float* pos_weights, int pos_weights_n, float* out, hipStream_t s);
+                     const float* pos_weights, int pos_weights_n, float* out, hipStream_t s,
+                     int* nonfinite_flag = nullptr);   // f16 models: raised (bit 0) when a pooled row is not finite
 void launch_pool(const void* hidden, int dtype, const int* mask, int B, int S, int d, int mode,
                  const float* pos_weights, float* out, hipStream_t s);
 // fp8 e4m3fn weight storage, one power-of-two scale per row (output channel)

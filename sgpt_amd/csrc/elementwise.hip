@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void lnf_pool_kernel(const float* __restrict__
                                                        const int* __restrict__ seq_len,
                                                        const int* __restrict__ pad_left, int d, float eps,
                                                        int apply_ln, int mode, int normalize,
-                                                       const float* __restrict__ pw, int pw_n, float* __restrict__ out) {
+                                                       const float* __restrict__ pw, int pw_n, float* __restrict__ out,
+                                                       int* __restrict__ nonfinite_flag) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][d] + 8
     const int sq = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -254,6 +255,9 @@ __global__ __launch_bounds__(256) void lnf_pool_kernel(const float* __restrict__
         sm[c] = e;
         ss += e * e;
     }
+    // f16 models: a NaN / inf that reached the pooled embedding (an under-shifted LayerNorm output overflowing to inf gives
+    // inf - inf in the next GEMM, and the per-launch range trackers' fmaxf drops NaN) raises the model's guard word: never silent
+    if (nonfinite_flag != nullptr && !(ss < INFINITY)) atomicOr(nonfinite_flag, 1);
     if (normalize) {  // F.normalize(p=2, dim=1), SentenceTransformer.py:248-249
         ss = wave_sum(ss);
         __syncthreads();
@@ -540,6 +544,55 @@ __global__ __launch_bounds__(256) void absmax16_kernel(const uint32_t* __restric
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __float_as_uint(m));
 }
 
+// Precision probe (sgpt_model_precision_probe_begin / _end): the crest factor max|v| / rms(v) of every row of a 16-bit
+// operand [T][cols] (leading dimension ld), its maximum over the rows folded into *out_bits (fp32 bits, atomicMax).  A row of
+// 11-bit values whose energy sits in one or two entries (outlier channels / hidden units of real GPT-Neo checkpoints: crest
+// ~ sqrt(cols / 2); a well-conditioned row: 4-9) puts the whole relative rounding error of those entries on the dot product.
+// One wave per row.
+template <typename H>
+__global__ __launch_bounds__(256) void crest16_kernel(const uint16_t* __restrict__ in, int T, int cols, long ld,
+                                                      unsigned* __restrict__ out_bits) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t* r = reinterpret_cast<const uint32_t*>(in + (long)row * ld);
+    float mx = 0.f, ss = 0.f;
+    for (int c = lane; c < cols / 2; c += 64) {
+        const uint32_t u = r[c];
+        const float a = Half<H>::lo(u), b = Half<H>::hi(u);
+        mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
+        ss += a * a + b * b;
+    }
+    mx = wave_max(mx);
+    ss = wave_sum(ss);
+    if (lane == 0 && ss > 0.f && mx < INFINITY) {
+        const float crest = mx / sqrtf(ss / (float)cols);
+        atomicMax(out_bits, __float_as_uint(crest));
+    }
+}
+
+// fp32 rows [n][d] -> split-precision 16-bit rows [n][3 d]: layout 0 = [hi | lo | hi] (the streamed operand: activations,
+// documents), layout 1 = [hi | hi | lo] (the resident operand: weights, queries); hi = round16(v), lo = round16(v - hi).
+// One contraction over 3 d of a layout-0 row with a layout-1 row is hi.hi + lo.hi + hi.lo: the product to ~2^-22.
+template <typename H>
+__global__ __launch_bounds__(256) void split16_rows_kernel(const float* __restrict__ in, long n, int d, int layout,
+                                                           uint16_t* __restrict__ out) {
+    const long total = n * (long)(d / 4), stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const long r = e / (d / 4);
+        const int c = (int)(e - r * (d / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(in + r * d + c);
+        const uint32_t h01 = Half<H>::pack2(v.x, v.y), h23 = Half<H>::pack2(v.z, v.w);
+        const uint2 hi = make_uint2(h01, h23);
+        const uint2 lo = make_uint2(Half<H>::pack2(v.x - Half<H>::lo(h01), v.y - Half<H>::hi(h01)),
+                                    Half<H>::pack2(v.z - Half<H>::lo(h23), v.w - Half<H>::hi(h23)));
+        uint16_t* o = out + r * 3 * d + c;
+        *reinterpret_cast<uint2*>(o) = hi;
+        *reinterpret_cast<uint2*>(o + d) = layout == 0 ? lo : hi;
+        *reinterpret_cast<uint2*>(o + 2 * d) = layout == 0 ? hi : lo;
+    }
+}
+
 inline int cap_grid(long blocks) { return (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks)); }
 
 }  // namespace
@@ -584,6 +637,17 @@ void launch_layernorm_split(const float* x, const float* g, const float* b, void
 #undef LS_CASE
 }
 
+void launch_crest16(const void* in, int T, int cols, long ld, int dtype, unsigned* out_bits, hipStream_t s) {
+    if (dtype == DT_F16) hipLaunchKernelGGL(crest16_kernel<f16_t>, dim3((T + 3) / 4), dim3(256), 0, s, (const uint16_t*)in, T, cols, ld, out_bits);
+    else hipLaunchKernelGGL(crest16_kernel<bf16_t>, dim3((T + 3) / 4), dim3(256), 0, s, (const uint16_t*)in, T, cols, ld, out_bits);
+}
+
+void launch_split16_rows(const float* in, long n, int d, int layout, void* out, int out_dtype, hipStream_t s) {
+    const int grid = cap_grid((n * (d / 4) + 255) / 256);
+    if (out_dtype == DT_F16) hipLaunchKernelGGL(split16_rows_kernel<f16_t>, dim3(grid), dim3(256), 0, s, in, n, d, layout, (uint16_t*)out);
+    else hipLaunchKernelGGL(split16_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, in, n, d, layout, (uint16_t*)out);
+}
+
 void launch_pack_split_rows(const float* src, long rows, long cols, void* dst, int out_dtype, hipStream_t s) {
     const int grid = cap_grid((rows * cols + 255) / 256);
     if (out_dtype == DT_F16) hipLaunchKernelGGL(pack_split_rows_kernel<f16_t>, dim3(grid), dim3(256), 0, s, src, rows, cols, (uint16_t*)dst);
@@ -614,11 +678,11 @@ void launch_absmax16(const void* in, long numel, int dtype, unsigned* out_bits, 
 
 void launch_lnf_pool(const float* x, const float* g, const float* b, const int* seq_off, const int* seq_len,
                      const int* pad_left, int B, int d, float eps, int apply_ln, int mode, int normalize,
-                     const float* pos_weights, int pos_weights_n, float* out, hipStream_t s) {
+                     const float* pos_weights, int pos_weights_n, float* out, hipStream_t s, int* nonfinite_flag) {
     const size_t sm = (size_t)(4 * d + 8) * sizeof(float);
 #define LP_CASE(NV)                                                                                              \
     hipLaunchKernelGGL((lnf_pool_kernel<NV>), dim3(B), dim3(256), sm, s, x, g, b, seq_off, seq_len, pad_left, d, \
-                       eps, apply_ln, mode, normalize, pos_weights, pos_weights_n, out);
+                       eps, apply_ln, mode, normalize, pos_weights, pos_weights_n, out, nonfinite_flag);
     const int nv = (d + 255) / 256;
     if (nv <= 1) { LP_CASE(1) } else if (nv <= 2) { LP_CASE(2) } else if (nv <= 3) { LP_CASE(3) }
     else if (nv <= 4) { LP_CASE(4) } else if (nv <= 8) { LP_CASE(8) } else if (nv <= 10) { LP_CASE(10) }

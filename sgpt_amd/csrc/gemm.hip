@@ -372,12 +372,27 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
                         OutT* vt = static_cast<OutT*>(p.out2) + (long)(n - p.n_split) * p.ldo2 + m;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) store1<OutT>(vt + (long)r * p.ldo2, v[r]);
+                        if constexpr (sizeof(OutT) == 2 && sizeof(T) == 2) {
+                            if (p.lo_delta2 != 0) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    store1<OutT>(vt + (long)r * p.ldo2 + p.lo_delta2, v[r] - Half<OutT>::lo(Half<OutT>::pack2(v[r], 0.f)));
+                            }
+                        }
                         continue;
                     }
                 }
                 OutT* dst = out + (long)m * p.ldo + n;
                 if (full) {
                     store4<OutT>(dst, v[0], v[1], v[2], v[3]);
+                    if constexpr (sizeof(OutT) == 2 && sizeof(T) == 2) {
+                        if (p.lo_delta != 0) {    // split-precision output: lo = round16(v - hi) (+ a second copy of hi), see GemmArgs
+                            const uint32_t h01 = Half<OutT>::pack2(v[0], v[1]), h23 = Half<OutT>::pack2(v[2], v[3]);
+                            store4<OutT>(dst + p.lo_delta, v[0] - Half<OutT>::lo(h01), v[1] - Half<OutT>::hi(h01),
+                                         v[2] - Half<OutT>::lo(h23), v[3] - Half<OutT>::hi(h23));
+                            if (p.hi2_delta != 0) store4<OutT>(dst + p.hi2_delta, v[0], v[1], v[2], v[3]);
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -402,6 +417,13 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
                 const float v2 = __builtin_fmaf(acc[i][j][2], csv, bn), v3 = __builtin_fmaf(acc[i][j][3], csv, bn);
                 range.note(v0, v1); range.note(v2, v3);
                 store4<OutT>(out + (long)n * p.ldo + m, v0, v1, v2, v3);
+                if constexpr (sizeof(OutT) == 2 && sizeof(T) == 2) {
+                    if (p.lo_delta != 0) {
+                        const uint32_t h01 = Half<OutT>::pack2(v0, v1), h23 = Half<OutT>::pack2(v2, v3);
+                        store4<OutT>(out + (long)n * p.ldo + m + p.lo_delta, v0 - Half<OutT>::lo(h01), v1 - Half<OutT>::hi(h01),
+                                     v2 - Half<OutT>::lo(h23), v3 - Half<OutT>::hi(h23));
+                    }
+                }
             }
         }
     }
@@ -421,7 +443,9 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
 // deep(s+1) have landed while deep(s+2) stays in flight.  The barrier sits in front of the step's last row pair and
 // the next step's first fragments are read behind it (see the loop): 2 615 instead of 2 700 cycles per k-step.  Epilogue scratch: after a tile's last step one deep and one
 // shallow slot are free (32 KiB each): waves 0-3 transpose through the first, waves 4-7 through the second.
-template <typename T, int EPI, typename OutT, bool SWAP, bool DEEP_A>
+// LO: the 16-bit store epilogues also write lo = round16(v - hi) (GemmArgs.lo_delta / hi2_delta) -- split-precision operands
+// for the next GEMM or the attention kernel; a template parameter so that the default kernels keep their exact code.
+template <typename T, int EPI, typename OutT, bool SWAP, bool DEEP_A, bool LO = false>
 __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     if (p.pred != nullptr && *p.pred == 0) return;
     typedef __attribute__((address_space(3))) char* lds_cptr_t;
@@ -624,7 +648,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
 #undef STAMP
 }
 
-template <typename T, int EPI, typename OutT, bool SWAP>
+template <typename T, int EPI, typename OutT, bool SWAP, bool LO = false>
 void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
     const int MT = a.M / 256, NT = a.N / 256;
     const int AT = MT >= NT ? MT : NT, BT = MT >= NT ? NT : MT;
@@ -648,8 +672,8 @@ void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
 #else
     b.skew = 0;
 #endif
-    if (deep_a) hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, true>), dim3(grid), dim3(512), 0, s, b);
-    else hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, false>), dim3(grid), dim3(512), 0, s, b);
+    if (deep_a) hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, true, LO>), dim3(grid), dim3(512), 0, s, b);
+    else hipLaunchKernelGGL((gemm256d_kernel<T, EPI, OutT, SWAP, false, LO>), dim3(grid), dim3(512), 0, s, b);
 }
 
 
@@ -884,6 +908,12 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
         if (g_use_w && (epi != EPI_STORE || o16))
             return launch_gemm256w(Half<H>::is_f16 ? DT_F16 : DT_BF16, epi, a, s, deep_a);
 #endif
+        if (a.lo_delta != 0) {                   // split-precision (hi + lo) outputs: 16-bit store epilogues only
+            if (epi == EPI_STORE && o16) return launch256d<H, EPI_STORE, H, true, true>(a, s, deep_a);
+            if (epi == EPI_VT) return launch256d<H, EPI_VT, H, false, true>(a, s, deep_a);
+            if (epi == EPI_BIAS_GELU) return launch256d<H, EPI_BIAS_GELU, H, true, true>(a, s, deep_a);
+            abort();
+        }
         if (epi == EPI_SCORE) return launch256d<H, EPI_SCORE, float, true>(a, s, deep_a);
         if (epi == EPI_SCORE_FILTER) return launch256d<H, EPI_SCORE_FILTER, float, true>(a, s, deep_a);
         if (epi == EPI_STORE && o16) return launch256d<H, EPI_STORE, H, true>(a, s, deep_a);

@@ -250,6 +250,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(const GemmArgs p) {
                 }
                 OutT* out = static_cast<OutT*>(p.out);
                 typename OutRange<OutT>::type range;
+                constexpr bool LO = false;                 // (split-precision outputs: 16-bit operand kernels only)
 #include "gemm256_epilogue.inc"
                 range.finish(p.range_flag);
             } else {

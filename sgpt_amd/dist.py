@@ -36,13 +36,16 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + sizes[rank]
 
 
-def balanced_cuts(weights: Sequence[int], world: int) -> np.ndarray:
+def balanced_cuts(weights: Sequence[int], world: int, min_one: bool = False) -> np.ndarray:
     """Cut points c[0] = 0 <= c[1] <= ... <= c[world] = n of a list into `world` CONTIGUOUS ranges of (nearly) equal total
     weight: rank r owns items [c[r], c[r+1]).  The weights are per-item costs (token rows of the packed layout, or
     character counts as their proxy); contiguity keeps the length-sorted order inside a shard ("balance by
     tokens, not by sentences" -- with equal counts of a longest-first list, rank 0 of 8 carries ~1.7x the mean token load).
     Every cut lies within one item of its ideal position: max load <= mean + the heaviest item.  Pure function of
-    (weights, world): every rank computes the same cuts without communication."""
+    (weights, world): every rank computes the same cuts without communication.
+    min_one: with n >= world items no range is left empty (one dominant item otherwise pulls several cuts onto the same
+    position: 32 queries, the first one 400 characters long, on 8 ranks gave [0 8 17 20 20 21 21 24 32]) -- for callers
+    whose per-rank step cannot run on zero items.  Balance degrades by at most one item per rank."""
     w = np.asarray(weights, dtype=np.int64)
     n = int(w.shape[0])
     cuts = np.zeros(world + 1, dtype=np.int64)
@@ -57,6 +60,11 @@ def balanced_cuts(weights: Sequence[int], world: int) -> np.ndarray:
         if i > 0 and target - cum[i - 1] < cum[i] - target:  # nearer cut
             i -= 1
         cuts[r] = min(max(i, int(cuts[r - 1])), n)
+    if min_one and n >= world:
+        for r in range(1, world):                            # forward: every range starts after its predecessor's first item
+            cuts[r] = max(int(cuts[r]), int(cuts[r - 1]) + 1)
+        for r in range(world - 1, 0, -1):                    # backward: ... and leaves one item for every successor
+            cuts[r] = min(int(cuts[r]), int(cuts[r + 1]) - 1)
     return cuts
 
 
@@ -71,9 +79,15 @@ class RcclComm:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         lib = ctx.lib
         have = int(lib.sgpt_comm_world(ctx.handle))
-        if have:                                   # this context already carries a communicator (one per process / GPU)
-            if have != self.world or int(lib.sgpt_comm_rank(ctx.handle)) != self.rank:
-                raise _lib.SgptHipError("the context's RCCL communicator belongs to a different process group")
+        owner = ctx.__dict__.get("_comm_group_key", "unset")
+        key = id(group) if group is not None else None
+        if have:                                   # this context already carries a communicator (one per ctx)
+            # world and rank matching is not enough: two different groups of the same size would silently share one
+            # communicator (collectives of one group paired with another group's ranks)
+            if have != self.world or int(lib.sgpt_comm_rank(ctx.handle)) != self.rank or owner not in ("unset", key):
+                raise _lib.SgptHipError("the context's RCCL communicator belongs to a different process group "
+                                        "(one communicator per context: use a second Context for a second group)")
+            ctx.__dict__["_comm_group_key"] = key
             return
         # bootstrap: rank 0's unique id travels over whatever backend torch.distributed was initialised with
         on_dev = dist.get_backend(group) == "nccl"
@@ -88,6 +102,7 @@ class RcclComm:
         dist.broadcast(buf, src=src, group=group)
         ident = (C.c_uint8 * _lib.SGPT_COMM_ID_BYTES)(*buf.cpu().tolist())
         _lib.check(ctx.handle, lib.sgpt_comm_init(ctx.handle, ident, self.rank, self.world), "sgpt_comm_init")
+        ctx.__dict__["_comm_group_key"] = key
 
     def all_gather_rows(self, local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
         """Rank r contributes counts[r] rows; everyone gets the concatenation in rank order (one ncclAllGather)."""

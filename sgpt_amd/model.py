@@ -15,8 +15,17 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F16, SGPT_F32, SGPT_FP8M, SGPT_FP8W, SgptRangeError
+from ._lib import (ModelDesc, TensorView, POOL_MODES, SGPT_BF16, SGPT_F16, SGPT_F32, SGPT_FP8M, SGPT_FP8W, SgptRangeError,
+                   SGPT_PREC_CLASSES, PC_LN1, PC_ATT, PC_CTX, PC_LN2, PC_H)
 from .runtime import Context, get_context, _p, _stream_ptr
+
+# Precision probe thresholds: crest factor max|v| / rms(v) of an operand row above which 11-bit operands are not trusted.
+# Well-conditioned rows measure 5-7 (LayerNorm outputs, attention context) and 8-10 (GELU outputs: half the entries near
+# zero) at any depth / width (seeded SGPT-125M and 1.3B shapes); a row that two outlier channels carry measures ~sqrt(K / 2)
+# (K = 768: 20-28 on the engineered-outlier fixture, GELU outputs 55): twice the clean level separates the two.
+CREST_LIMIT_LN = 12.0
+CREST_LIMIT_H = 20.0
+PROBE_MAX_ROWS = 8192   # token rows of the probe forward (a bounded sample of the first call's sequences)
 
 ALIGN = 8          # sequence starts on the packed token axis: multiples of 8 rows (16-byte V^T tile loads in attention)
 TOKEN_TILE = 256   # GEMM M tile (256x256 LDS-DMA kernel)
@@ -216,23 +225,49 @@ class _Staging:
         self.events[i] = ev
 
 
+# precise_qk=None on dtype-'f16' GPT-Neo models with hidden_size >= 2048: the cheapest variant that holds the SGPT-1.3B
+# reference fixture inside the bar with margin (profiles/r04_precise_qk.txt)
+PRECISE_QK_DEFAULT = "full"
+
+
 class SGPTModel:
     """GPT-Neo weights resident on one GPU behind an `sgpt_model*` handle."""
 
     def __init__(self, cfg: SGPTConfig, weights: Dict[str, "np.ndarray | torch.Tensor"], device=None,
                  dtype: str = "f16", ctx: Optional[Context] = None, max_tokens_per_call: int = 131072,
-                 calibrate: bool = True, precise_qk: Optional[bool] = None):
-        """precise_qk (dtype 'f16' / 'bf16'): split-precision Q / K projection -- the LayerNorm output and the Wq / Wk weights
-        enter it as hi + lo pairs of 16-bit values (three K blocks on the same MFMA).  GPT-Neo has no 1/sqrt(dh) in its
-        attention; at d >= 2048 the path LayerNorm -> Wq / Wk -> q / k carries 80 % of the 16-bit deviation from the fp32
-        reference: with it SGPT-1.3B shape sits inside the 1e-3 bar on embeddings and cosine scores (7.7e-4 /
-        5.0e-4 instead of 1.09e-3 / 8.2e-4), for +2x the FLOPs of the Q / K projection (-22 % throughput at that size).
-        None (default) = parity first: ON for dtype 'f16' GPT-Neo models with hidden_size >= 2048 (SGPT-1.3B / 2.7B), off
-        elsewhere (SGPT-125M: 3.2e-4 without it; GPT-J / BLOOM: 6e-5); True / False force it."""
+                 calibrate: bool = True, precise_qk=None, precision: Optional[str] = None):
+        """precision (dtype 'f16' / 'bf16'): how operands enter the MFMAs (include/sgpt_hip.h::sgpt_model_set_precision).
+          'plain'  16-bit operands everywhere (plus the structural rule below);
+          'x3'     every operand class of every block as a hi + lo pair of 16-bit values (the "f16x3" mode: embeddings within
+                   ~1e-5 of the fp32 reference on ANY checkpoint the f16 range guard accepts, a third of the 16-bit MFMA
+                   rate, ~5x the exact-fp32 mode);
+          'auto'   (the default for dtype 'f16': parity first) the split weight copies are kept, and the FIRST encode call
+                   probes a bounded sample of its own sequences: the crest factor max|v| / rms(v) of every operand class of
+                   every block.  A class above the limits (CREST_LIMIT_*) means an ill-conditioned checkpoint -- outlier
+                   channels / hidden units, as real GPT-Neo checkpoints have -- and moves the WHOLE model to 'x3'; a clean
+                   checkpoint stays 'plain' (same kernels, same bits, same speed).  The choice is sticky and readable
+                   (precision_plan(), precision_report); set_precision_plan() pins it across processes;
+          'auto-class'  as 'auto' but only the flagged classes are split (LayerNorm-1 brings the block's attention along).
+        precise_qk: the structural rule for GPT-Neo -- no 1/sqrt(dh) in its attention, so at d >= 2048 the path LayerNorm ->
+        Wq / Wk -> q / k -> logits carries 80 % of the 16-bit deviation from the fp32 reference.  None (default)
+        = ON for dtype 'f16' GPT-Neo models with hidden_size >= 2048 (SGPT-1.3B / 2.7B) as PRECISE_QK_DEFAULT, off
+        elsewhere; False = off; True / 'full' = the Q / K projection over hi + lo pairs of both operands (+33 % FLOPs);
+        'logits' = q / k / v / p as hi + lo pairs inside the attention only (no extra GEMM FLOPs); 'act+logits' = that plus the
+        LayerNorm-1 output split against plain weights (+17 % FLOPs)."""
         if dtype in ("fp16", "float16", "half"):
             dtype = "f16"
+        if precision is None:
+            precision = "auto" if dtype == "f16" else "plain"
+        if precision not in ("plain", "x3", "auto", "auto-class"):
+            raise ValueError("precision must be 'plain', 'x3', 'auto' or 'auto-class'")
+        if precision != "plain" and dtype not in ("f16", "bf16"):
+            raise ValueError("precision applies to dtype 'f16' / 'bf16'")
         if precise_qk is None:
-            precise_qk = dtype == "f16" and cfg.model_type == "gpt_neo" and cfg.hidden_size >= 2048
+            precise_qk = PRECISE_QK_DEFAULT if (dtype == "f16" and cfg.model_type == "gpt_neo" and cfg.hidden_size >= 2048) else False
+        if precise_qk is True:
+            precise_qk = "full"
+        if precise_qk not in (False, "full", "logits", "act+logits"):
+            raise ValueError("precise_qk must be None, False, True / 'full', 'logits' or 'act+logits'")
         if precise_qk and dtype not in ("f16", "bf16"):
             raise ValueError("precise_qk applies to dtype 'f16' / 'bf16'")
         if dtype not in ("f16", "bf16", "fp32", "fp8", "fp8mfma"):
@@ -260,8 +295,13 @@ class SGPTModel:
                          compute_dtype={"f16": SGPT_F16, "bf16": SGPT_BF16, "fp32": SGPT_F32, "fp8": SGPT_FP8W,
                                         "fp8mfma": SGPT_FP8M}[dtype],
                          layer_is_local=C.cast(local, C.POINTER(C.c_uint8)), rotary_dim=cfg.rotary_dim if gptj else 0,
-                         qk_split=1 if precise_qk else 0)
-        self.precise_qk = bool(precise_qk)
+                         qk_split=1 if precise_qk == "full" else 0,
+                         split_weights=1 if (precision != "plain" or precise_qk == "act+logits") else 0)
+        self.precise_qk = precise_qk
+        self.precision = precision
+        self.precision_report = None      # filled by the probe: crest factors [num_layers, 4] and what was decided
+        self._att_ok = (not gptj) and dh in (64, 128)          # split-precision attention: head_dim 64 / 128, no rotary
+        self._plan_pending = precision in ("auto", "auto-class")
         if gptj:
             weights = dict(weights)
             weights["rotary.sin"], weights["rotary.cos"] = rotary_tables(cfg.max_position_embeddings, cfg.rotary_dim)
@@ -296,6 +336,95 @@ class SGPTModel:
         self.position_weights = None
         if "position_weights" in weights:
             self.set_position_weights(weights["position_weights"])
+        if dtype in ("f16", "bf16"):
+            base = self._base_plan()
+            if precision == "x3":
+                base = self._x3_plan()
+            if base.any():
+                self.set_precision_plan(base, _keep_pending=True)
+
+    # ---- precision plan (split-precision operand classes per block) ----
+    def _base_plan(self) -> np.ndarray:
+        """The structural part of the plan: precise_qk."""
+        plan = np.zeros((self.cfg.num_layers, SGPT_PREC_CLASSES), dtype=np.int32)
+        if self.precise_qk == "full":
+            plan[:, PC_LN1] = 1
+        elif self.precise_qk in ("logits", "act+logits"):
+            if not self._att_ok:
+                raise ValueError("precise_qk='logits' needs head_dim 64 / 128 and no rotary embedding")
+            plan[:, PC_ATT] = 1
+            if self.precise_qk == "act+logits":
+                plan[:, PC_LN1] = 3
+        return plan
+
+    def _x3_plan(self) -> np.ndarray:
+        plan = np.ones((self.cfg.num_layers, SGPT_PREC_CLASSES), dtype=np.int32)
+        plan[:, PC_LN1] = 2
+        if not self._att_ok:
+            plan[:, PC_ATT] = 0        # GPT-J (rotary in place on 16-bit q / k; head_dim 256): q / k / v / p stay 16-bit
+        return plan
+
+    def precision_plan(self) -> np.ndarray:
+        """int32[num_layers, 5]: per block (LayerNorm-1 -> Q/K/V: 0 | 1 q,k | 2 q,k,v | 3 q,k activation-only; attention; context ->
+        out-projection; LayerNorm-2 -> fc1; GELU output -> fc2); non-zero = that operand class enters its MFMAs as hi + lo pairs."""
+        out = np.zeros(self.cfg.num_layers * SGPT_PREC_CLASSES, dtype=np.int32)
+        _lib.check(self.ctx.handle, self.ctx.lib.sgpt_model_get_precision(self.handle, out.ctypes.data_as(C.c_void_p), out.size),
+                   "sgpt_model_get_precision")
+        return out.reshape(self.cfg.num_layers, SGPT_PREC_CLASSES)
+
+    def set_precision_plan(self, plan, _keep_pending: bool = False) -> None:
+        """Install a plan (e.g. the one an earlier run's probe chose: reproducible embeddings across processes).  Ends the
+        'auto' probe: the plan is the caller's now."""
+        a = np.ascontiguousarray(np.asarray(plan, dtype=np.int32).reshape(-1))
+        _lib.check(self.ctx.handle, self.ctx.lib.sgpt_model_set_precision(self.handle, a.ctypes.data_as(C.c_void_p), a.size),
+                   "sgpt_model_set_precision")
+        if not _keep_pending:
+            self._plan_pending = False
+
+    def probe_precision(self, seqs, pad_left=None) -> np.ndarray:
+        """Crest factors float32[num_layers, 4] (LayerNorm-1 output, attention context, LayerNorm-2 output, GELU output) of a
+        forward over `seqs` (at most PROBE_MAX_ROWS token rows are used)."""
+        if self.dtype not in ("f16", "bf16"):
+            raise ValueError("probe_precision applies to dtype 'f16' / 'bf16'")
+        lens = np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs))
+        alloc = np.cumsum((lens + ALIGN - 1) // ALIGN * ALIGN)
+        n = max(1, int(np.searchsorted(alloc, PROBE_MAX_ROWS, side="right")))
+        sub = [seqs[i][:PROBE_MAX_ROWS] for i in range(n)]
+        pl = None if pad_left is None else [pad_left[i] for i in range(n)]
+        lib = self.ctx.lib
+        out = (C.c_float * (4 * self.cfg.num_layers))()
+
+        def once():
+            _lib.check(self.ctx.handle, lib.sgpt_model_precision_probe_begin(self.handle), "sgpt_model_precision_probe_begin")
+            try:
+                self.encode_packed(self.pack(sub, pl))
+            finally:
+                _lib.check(self.ctx.handle, lib.sgpt_model_precision_probe_end(self.handle, out), "sgpt_model_precision_probe_end")
+        self.guarded(once)          # (an f16 range overflow inside the probe forward: shifts raised, probed again)
+        return np.array(list(out), dtype=np.float32).reshape(self.cfg.num_layers, 4)
+
+    def _auto_precision(self, seqs, pad_left) -> None:
+        """precision 'auto' / 'auto-class', first encode call: probe, decide, install."""
+        self._plan_pending = False
+        crest = self.probe_precision(seqs, pad_left)
+        lim = np.array([CREST_LIMIT_LN, CREST_LIMIT_LN, CREST_LIMIT_LN, CREST_LIMIT_H], dtype=np.float32)
+        hot = crest > lim[None, :]                        # [L, 4]: LN1, CTX, LN2, H
+        plan = self._base_plan()
+        if hot.any():
+            if self.precision == "auto":
+                plan = self._x3_plan()
+            else:
+                plan[hot[:, 0], PC_LN1] = 2
+                if self._att_ok:
+                    plan[hot[:, 0], PC_ATT] = 1
+                plan[hot[:, 1], PC_CTX] = 1
+                plan[hot[:, 2], PC_LN2] = 1
+                plan[hot[:, 3], PC_H] = 1
+                if self.cfg.model_type == "gptj":
+                    plan[:, PC_LN2] = (plan[:, PC_LN1] != 0).astype(np.int32)
+            self.set_precision_plan(plan)
+        self.precision_report = dict(crest=crest, limits=lim.tolist(), flagged=int(hot.sum()),
+                                     decided="x3" if (hot.any() and self.precision == "auto") else ("classes" if hot.any() else "plain"))
 
     def calibrate(self, seqs: Optional[Sequence[Sequence[int]]] = None, margin: float = 2.0) -> np.ndarray:
         """dtype='fp8mfma': fix the per-block power-of-two scales of the e4m3 codes of the GELU output and of the attention
@@ -535,6 +664,8 @@ class SGPTModel:
         lens = np.fromiter(map(len, seqs), dtype=np.int64, count=n)
         if (lens <= 0).any():
             raise ValueError("Empty items should be cleaned prior to running")
+        if self._plan_pending:
+            self._auto_precision(seqs, pad_left)
         return self.guarded(lambda: self._batched_once(seqs, pad_left, run, lens))
 
     def _batched_once(self, seqs, pad_left, run, lens) -> torch.Tensor:

@@ -110,6 +110,32 @@ class Context:
                                           _stream_ptr(self.device)), "sgpt_f32_to_16")
         return out
 
+    def row_crest(self, x: torch.Tensor) -> float:
+        """max over the rows of max|v| / rms(v) (include/sgpt_hip.h::sgpt_row_crest; fp32 rows are rounded to f16 first).
+        ~3.5-5 for well-spread embedding rows, ~sqrt(d / 2) when two channels carry the row.  Syncs the stream."""
+        if x.dtype not in (torch.float16, torch.bfloat16):
+            x = self.to_16(self._dev_f32(x), torch.float16)
+        x = x.to(self.device).contiguous()
+        n, d = x.shape
+        out = C.c_float(0)
+        self._chk(self.lib.sgpt_row_crest(self.handle, _p(x), DT_CODE[x.dtype], n, d, d, C.byref(out),
+                                          _stream_ptr(self.device)), "sgpt_row_crest")
+        return float(out.value)
+
+    def split16(self, x: torch.Tensor, role: str, dtype=torch.float16) -> torch.Tensor:
+        """fp32 rows [n, d] -> split-precision 16-bit rows [n, 3 d] for the scorer (include/sgpt_hip.h::sgpt_split16):
+        role 'doc' = [hi | lo | hi], role 'query' = [hi | hi | lo]; `scores` / `score_topk` over the 3 d columns then give
+        q_hi.c_hi + q_hi.c_lo + q_lo.c_hi -- cosine scores to ~1e-6 on the 16-bit scorer kernels, for embeddings that a few
+        channels dominate (the plain 16-bit corpus format alone costs those up to 4e-4)."""
+        if role not in ("doc", "query"):
+            raise ValueError("role must be 'doc' or 'query'")
+        x = self._dev_f32(x)
+        n, d = x.shape
+        out = torch.empty((n, 3 * d), dtype=dtype, device=self.device)
+        self._chk(self.lib.sgpt_split16(self.handle, _p(x), n, d, 0 if role == "doc" else 1, _p(out), DT_CODE[dtype],
+                                        _stream_ptr(self.device)), "sgpt_split16")
+        return out
+
     def to_bf16(self, x: torch.Tensor) -> torch.Tensor:
         return self.to_16(x, torch.bfloat16)
 
@@ -180,6 +206,25 @@ class Context:
         self._chk(self.lib.sgpt_linear(self.handle, DT_CODE[a.dtype], code, DT_CODE[out_dtype], _p(a.contiguous()),
                                        _p(w.contiguous()), _p(b), _p(r), _p(out), M, N, K, _stream_ptr(self.device)),
                   "sgpt_linear")
+        return out
+
+    def linear_split(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: str = "store",
+                     triple: bool = False) -> torch.Tensor:
+        """The split store epilogues (include/sgpt_hip.h::sgpt_linear_split): epi 'store' | 'gelu' -> [M, 2 N] = [hi | lo], or
+        with triple=True [M, 3 N] = [hi | lo | hi] (the row layout a split consumer contracts over); 'vt' -> [2, N, M]
+        (hi, lo transposed)."""
+        code = {"store": 0, "gelu": 1, "vt": 4}[epi]
+        M, K = a.shape
+        N = w.shape[0]
+        b = None if bias is None else bias.to(device=self.device, dtype=torch.float32).contiguous()
+        if epi == "vt":
+            out = torch.zeros((2, N, M), dtype=a.dtype, device=self.device)
+            ldo, lo, hi2 = M, N * M, 0
+        else:
+            out = torch.zeros((M, (3 if triple else 2) * N), dtype=a.dtype, device=self.device)
+            ldo, lo, hi2 = out.shape[1], N, (2 * N if triple else 0)
+        self._chk(self.lib.sgpt_linear_split(self.handle, DT_CODE[a.dtype], code, _p(a.contiguous()), _p(w.contiguous()), _p(b),
+                                             _p(out), ldo, lo, hi2, M, N, K, _stream_ptr(self.device)), "sgpt_linear_split")
         return out
 
     # ---- fp8-MFMA building blocks (dtype='fp8mfma'): quantising LayerNorm, e4m3 x e4m3 projection ----

@@ -35,10 +35,11 @@ def oracle_cfg_weights(cfg_kw, seed, std, bf16_linear=False):
     return cfg, O.synth_weights(cfg, seed=seed, std=std, bf16_linear=bf16_linear)
 
 
-def build_model(cfg_kw, seed, std, dtype, precise_qk=False):
-    """SGPTModel on cuda:0 with the oracle's seeded synthetic weights (cached per test session)."""
+def build_model(cfg_kw, seed, std, dtype, precise_qk=False, precision="plain"):
+    """SGPTModel on cuda:0 with the oracle's seeded synthetic weights (cached per test session).  precision='plain' unless a
+    test asks otherwise: the kernel-level tests pin the 16-bit path itself, not what the 'auto' probe would choose."""
     from sgpt_amd import SGPTConfig, SGPTModel
-    key = (repr(sorted(cfg_kw.items())), seed, std, dtype, precise_qk)
+    key = (repr(sorted(cfg_kw.items())), seed, std, dtype, precise_qk, precision)
     if key not in _models:
         _, w = oracle_cfg_weights(cfg_kw, seed, std)
         if "n_embd" in cfg_kw:
@@ -47,7 +48,8 @@ def build_model(cfg_kw, seed, std, dtype, precise_qk=False):
             scfg = SGPTConfig.from_hf_dict(dict(cfg_kw, model_type="bloom"))
         else:
             scfg = SGPTConfig(**cfg_kw)
-        _models[key] = SGPTModel(scfg, w, device="cuda:0", dtype=dtype, precise_qk=precise_qk)
+        kw = dict(precision=precision) if dtype in ("f16", "bf16") else {}
+        _models[key] = SGPTModel(scfg, w, device="cuda:0", dtype=dtype, precise_qk=precise_qk, **kw)
     return _models[key]
 
 

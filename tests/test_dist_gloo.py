@@ -215,11 +215,13 @@ def _text_data(n_docs, n_queries):
     return corpus, queries
 
 
-def _text_search_worker(rank, world, port, out, n_docs, n_queries, chunk, top_k, fn):
+def _text_search_worker(rank, world, port, out, n_docs, n_queries, chunk, top_k, fn, long_query=False):
     _init(rank, world, port)
     try:
         from sgpt_amd.beir import DenseRetrievalExactSearch
         corpus, queries = _text_data(n_docs, n_queries)
+        if long_query:
+            queries = dict([("qlong", "alpha " * 400)] + list(queries.items()))
         dres = DenseRetrievalExactSearch(TextModel(), corpus_chunk_size=chunk, ctx=StubCtx())
         got = dres.search(corpus, queries, top_k, fn)                         # distributed branch (world 2)
         out.put((rank, got, dres.last_shard))
@@ -255,6 +257,30 @@ def test_two_rank_text_search_equals_single_process(n_docs, n_queries, chunk, fn
         assert ranges[0][1] - ranges[0][0] == 0 or ranges[1][1] - ranges[1][0] == 0          # one rank had nothing to score
 
 
+@pytest.mark.timeout(240)
+def test_three_rank_text_search_with_one_dominant_query():
+    """ADVICE r03 (medium): one query longer than total / world pulled several length-balanced cuts onto the same position;
+    the rank with the empty query slice crashed in `all_gather_rows(None)` and the others hung in the collective.  The query
+    cuts now leave no rank empty (balanced_cuts(min_one=True)); three ranks, the first query 400 words long."""
+    from sgpt_amd.beir import DenseRetrievalExactSearch
+    from sgpt_amd.dist import balanced_cuts
+    n_docs, n_queries, chunk, top_k, fn = 97, 12, 40, 4, "cos_sim"
+    corpus, queries = _text_data(n_docs, n_queries)
+    queries = dict([("qlong", "alpha " * 400)] + list(queries.items()))
+    lens = [len(q) + 1 for q in queries.values()]
+    assert (np.diff(balanced_cuts(lens, 3)) == 0).any()                 # the plain cuts DO leave a rank empty here
+    assert (np.diff(balanced_cuts(lens, 3, min_one=True)) > 0).all()
+    single = DenseRetrievalExactSearch(TextModel(), corpus_chunk_size=chunk, ctx=StubCtx()).search(corpus, queries, top_k, fn)
+    res = _run(_text_search_worker, 3, n_docs, n_queries, chunk, top_k, fn, True)
+    assert len(res) == 3
+    for rank, got, shard in res:
+        assert set(got) == set(single)
+        for qid in single:
+            assert set(got[qid]) == set(single[qid]), (rank, qid)
+            for cid, sc in single[qid].items():
+                assert abs(got[qid][cid] - sc) <= 1e-6
+
+
 def test_balanced_cuts_properties():
     """Property test: the cuts are a monotone partition, a pure function of (weights, world), and no rank is heavier than the
     mean by more than the heaviest item."""
@@ -271,4 +297,8 @@ def test_balanced_cuts_properties():
             w = np.asarray(weights)
             load = np.array([w[c[r]: c[r + 1]].sum() for r in range(world)], dtype=np.float64)
             assert load.sum() == w.sum() and load.max() <= w.sum() / world + w.max()
+            m = balanced_cuts(weights, world, min_one=True)
+            assert m[0] == 0 and m[-1] == len(weights) and (np.diff(m) >= 0).all()
+            if len(weights) >= world:
+                assert (np.diff(m) >= 1).all()                      # no rank is left without an item
     check()

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     m = re.search(r"#define SGPT_ABI_VERSION (\d+)", hdr)
     assert lib.sgpt_abi_version() == int(m.group(1)) == _lib.SGPT_ABI_VERSION
     # struct layout mirrors the header
-    assert ctypes.sizeof(_lib.ModelDesc) == 64 and ctypes.sizeof(_lib.TensorView) == 24
+    assert ctypes.sizeof(_lib.ModelDesc) == 72 and ctypes.sizeof(_lib.TensorView) == 24
 
 
 def test_no_gpu_means_loud_failure():
