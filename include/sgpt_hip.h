@@ -260,9 +260,9 @@ sgpt_status sgpt_range_check(sgpt_ctx* ctx, int32_t* flagged, int32_t reset, voi
  *     SGPT_PC_ATT  inside the attention: q, k, V^T and the probabilities as hi + lo pairs (logits and P.V as three MFMA
  *                  passes each; head_dim 64 / 128, GPT-Neo and BLOOM)
  *     SGPT_PC_CTX  attention context -> out-projection
- *     SGPT_PC_LN2  LayerNorm-2 output -> fc1 (GPT-J's parallel block reads ln_1's output: must equal LN1 != 0 there)
+ *     SGPT_PC_LN2  LayerNorm-2 output -> fc1 (GPT-J's parallel block reads ln_1's output: needs LN1 != 0 there)
  *     SGPT_PC_H    GELU output -> fc2
- *   Every class but LN1 = 1 needs sgpt_model_desc.split_weights.  All ones (LN1 = 2) = the "f16x3" mode: embeddings within
+ *   Every class but LN1 = 1 / 3 (qk_split is enough) and ATT (activations only) needs sgpt_model_desc.split_weights.  All ones (LN1 = 2) = the "f16x3" mode: embeddings within
  *   ~1e-5 of the fp32 reference on any checkpoint the f16 RANGE guard accepts.  Changing the plan bumps sgpt_ctx_generation.
  * sgpt_model_precision_probe_begin / _end: between the two calls every sgpt_encode on the model also records, per block and
  *   class (LayerNorm-1 output, attention context, LayerNorm-2 output, GELU output: 4 * n_layers floats), the largest crest

@@ -12,7 +12,9 @@ LIBDIR = os.path.join(HERE, "lib")
 # the slower 32x32x16-MFMA re-tiling (gemm256w.hip) compiled in.  The product library has none of them.
 EXPERIMENTS = os.environ.get("SGPT_EXPERIMENTS") == "1"
 LIB = os.path.join(LIBDIR, "libsgpt_hip_exp.so" if EXPERIMENTS else "libsgpt_hip.so")
-SOURCES = ["gemm.hip", "gemm256q.hip", "attn.hip", "elementwise.hip", "topk.hip", "comm.hip", "api.hip"] + (["gemm256w.hip"] if EXPERIMENTS else [])
+SOURCES = ["gemm.hip", "gemm256q.hip", "attn.hip", "elementwise.hip", "topk.hip", "comm.hip", "api.hip"]
+# the slower 32x32x16-MFMA re-tiling lives with the measurement scripts (scripts/micro/gemm256w.hip): experiment build only
+EXTRA_SOURCES = [os.path.join(HERE, "..", "scripts", "micro", "gemm256w.hip")] if EXPERIMENTS else []
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result"] + (["-DSGPT_EXPERIMENTS"] if EXPERIMENTS else []) + os.environ.get("SGPT_EXTRA_FLAGS", "").split()
 OBJ_SUFFIX = ".exp.o" if EXPERIMENTS else ".o"
@@ -24,10 +26,27 @@ if os.environ.get("SGPT_LIB_TAG"):
 
 
 def _hipcc():
-    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+    rocm = os.environ.get("ROCM_PATH") or os.environ.get("ROCM_HOME")
+    for c in (os.environ.get("HIPCC"), os.path.join(rocm, "bin", "hipcc") if rocm else None, "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.sep not in c or os.path.exists(c)):
             return c
     raise RuntimeError("hipcc not found")
+
+
+def _rocm_libdir(hipcc):
+    """Where librccl lives: $ROCM_PATH/lib, else next to the hipcc that compiles the sources (versioned prefixes such as
+    /opt/rocm-7.2.0 work), else /opt/rocm/lib."""
+    import shutil
+    rocm = os.environ.get("ROCM_PATH") or os.environ.get("ROCM_HOME")
+    cands = [os.path.join(rocm, "lib")] if rocm else []
+    exe = hipcc if os.path.sep in hipcc else shutil.which(hipcc)
+    if exe:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(exe))), "lib"))
+    cands.append("/opt/rocm/lib")
+    for d in cands:
+        if os.path.exists(os.path.join(d, "librccl.so")):
+            return d
+    return cands[-1]
 
 
 def _stale(target, deps):
@@ -43,12 +62,12 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers += [os.path.join(HERE, "..", "include", "sgpt_hip.h"), os.path.abspath(__file__)]
     objs, jobs = [], []
-    for src in SOURCES:
-        sp = os.path.join(CSRC, src)
-        op = os.path.join(LIBDIR, src.replace(".hip", OBJ_SUFFIX))
+    for src in SOURCES + EXTRA_SOURCES:
+        sp = src if os.path.isabs(src) or os.path.sep in src else os.path.join(CSRC, src)
+        op = os.path.join(LIBDIR, os.path.basename(src).replace(".hip", OBJ_SUFFIX))
         objs.append(op)
         if force or _stale(op, [sp] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", sp, "-o", op])
+            jobs.append([hipcc] + FLAGS + ["-I", CSRC, "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -63,8 +82,10 @@ def build(force=False, verbose=False):
     if force or jobs or _stale(LIB, objs):
         # librccl: the exchange steps of the multi-GPU search (comm.hip).  torch ships its own copy under the same soname
         # (librccl.so.1): in a process that imported torch first, the loader resolves to that one -- a single RCCL per process.
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
-            ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+        # (A process that loads this library BEFORE torch would bind ROCm's copy and torch then its own: import torch first,
+        # as sgpt_amd/runtime.py does.)
+        rl = _rocm_libdir(hipcc)
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [f"-L{rl}", "-lrccl", f"-Wl,-rpath,{rl}"])
     return LIB
 
 

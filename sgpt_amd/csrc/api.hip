@@ -577,7 +577,7 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         const int* pc = &m->prec[(size_t)li * PC_N];
         const int p_ln1 = can_split ? pc[PC_LN1] : 0;                  // 0 | 1 (q, k split) | 2 (q, k, v split) | 3 (q, k: activation split only)
         const bool p_att = can_split && pc[PC_ATT] != 0, p_ctx = can_split && pc[PC_CTX] != 0, p_h = can_split && pc[PC_H] != 0;
-        const bool p_ln2 = can_split && (gptj ? p_ln1 != 0 : pc[PC_LN2] != 0);   // GPT-J: fc1 reads ln_1's output
+        const bool p_ln2 = can_split && pc[PC_LN2] != 0 && (!gptj || p_ln1 != 0);   // GPT-J: fc1 reads ln_1's output (its [hi | lo | hi] rows)
         unsigned* crest = (m->probing && m->crest_dev) ? m->crest_dev + (size_t)li * RS_N : nullptr;
         GemmArgs g{};
         g.A = a; g.lda = dm; g.M = T; g.m_valid = T; g.K = dm; g.ldw = dm;
@@ -939,17 +939,41 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     static const bool classic_only = exp_env("SGPT_SCORE_CLASSIC") != nullptr;
     // Capacity and growth: a filtered chunk of len = growth * seen documents expects ~k * growth survivors per query
     // (the threshold is the k-th best of `seen` documents); the merge sorts the candidates in 2048 LDS slots.
-    const int cap = k <= 64 ? 256 : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
+    // k <= 64 ("sampled" schedule, round 4): the first thresholds come from a STRIDED SAMPLE of the whole shard instead of its
+    // first documents, so (a) nothing is materialised but the sample's own score tile, (b) the expected number of survivors of
+    // a chunk, k * len / S, holds whatever the document order does to the score distribution (the reference sorts the corpus
+    // by length: a drift along the index used to overflow the lists and pay the materialised recomputation of the chunk), and
+    // (c) chunks can therefore be as long as the lists allow instead of doubling: a 125 k-document shard is ONE filtered
+    // launch, 1 M documents three (1 + 6 before).  The rank of a sample's k-th best in the population is Gamma(k)-distributed
+    // (relative spread 1 / sqrt(k)): lists of `cap` entries take R = cap / (k (1 + 6 / sqrt(k))) times the documents the
+    // thresholds were drawn from with ~6 sigma of head-room.
+    const bool sampled_k = k <= 64;
+    const int cap = sampled_k ? (k <= 32 ? 512 : 1024) : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
     const bool half_growth = 2 * cap < 5 * k;          // k > ~340: cap < 2.5 k -> grow by half, expect ~k/2 per chunk
-    // Chunks grow by doubling even where the lists could hold more.  Two schedules were measured against it and rejected:
-    //   round 2: 4x growth with 256-entry lists -- overflowed on corpora whose score distribution drifts along the index (the
-    //            reference sorts documents by length, exact_search.py:66-71) and paid the materialised recomputation;
-    //   round 3: 2048-entry lists with growth cap / 6k (k = 11: first chunk + two filtered chunks per 1 M documents, 6x
-    //            head-room) -- fewer launches, but ~330 survivors per query and chunk instead of ~11 go through the
-    //            epilogue's append path: the filtered GEMM went from 1.45 to 1.58 ms per pass (nq = 1000), nq = 64 from 0.47
-    //            to 0.52 ms, and a drift at 10 % of the corpus from 2.2 to 3.5 ms (profiles/r03_score_schedule.txt).
+    // k > 64 keeps the first-chunk + doubling schedule.  Two other schedules were measured against doubling and rejected:
+    //   round 2: 4x growth with 256-entry lists -- overflowed on corpora whose score distribution drifts along the index and
+    //            paid the materialised recomputation;
+    //   round 3: 2048-entry lists with growth cap / 6k (k = 11: first chunk + two filtered chunks per 1 M documents) -- ~330
+    //            survivors per query and chunk through the epilogue's append path: the filtered GEMM went from 1.45 to 1.58 ms
+    //            per pass (nq = 1000), and a drift at 10 % of the corpus from 2.2 to 3.5 ms (profiles/r03_score_schedule.txt).
     const int growth = 1;
     const bool filt = fast && !classic_only && k <= 1024 && chunk % 256 == 0 && N >= 2 * chunk;
+    const bool sampled = filt && sampled_k;
+    const double ratio = (double)cap / ((double)k * (1.0 + 6.0 / std::sqrt((double)k)));   // documents per threshold document
+    const long n256_all = N / 256 * 256;
+    long S = 0, s_stride = 1;                           // sample size (documents) and row stride
+    if (sampled) {
+        // S = N / ratio: the survivors of the WHOLE shard fit the lists even if no chunk ever raises the thresholds (a corpus
+        // whose best documents all come last).  Bounded by a 512 MiB score tile (131 072 documents at nq = 1000; 1 M documents
+        // need 60 k): behind that the schedule relies on the merges raising the thresholds, like the doubling one did.
+        S = ((long)((double)N / ratio) + 255) / 256 * 256;     // rounded UP: ratio * S covers the shard
+        if (S < 2048) S = 2048;
+        const long s_max = (long)(((size_t)512 << 20) / ((size_t)nq * 4)) / 256 * 256;
+        if (S > s_max) S = s_max > 2048 ? s_max : 2048;
+        if (S > n256_all / 2) S = n256_all / 2 / 256 * 256;
+        s_stride = n256_all / S;
+        if (s_stride < 1) s_stride = 1;
+    }
 
     // A filtered chunk whose candidate lists overflow is recomputed by materialise + select in pieces whose fp32 score tile
     // stays in the Infinity Cache (measured: 1 GiB tiles made the recomputation 6x slower than the plain materialised
@@ -957,16 +981,21 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // chunk (nq = 16: 2.6 M documents per 160 MiB tile), so a pass carries 2 predicated launches per chunk, not 2 per 131 072
     // documents.
     long fchunk = (long)(budget / ((size_t)nq * 4)) / 256 * 256;
+    // sampled schedule: an overflow needs an adversarial mass of near-equal scores now, so the fallback is sized for few
+    // no-op launches (a predicated 256x256 launch that exits at once still costs ~4.4 us, two per piece: ~60 of them were
+    // 0.05-0.08 ms of a 1 M-document pass) rather than for the cache: pieces of up to 131 072 documents
+    if (sampled && fchunk < 131072) fchunk = 131072;
     if (fchunk > (long)align_up((size_t)N, 256)) fchunk = (long)align_up((size_t)N, 256);
     if (fchunk < chunk) fchunk = chunk;
     const long n_flags = 64 + N / (1L << 19) + 1;      // one overflow flag per filtered chunk
-    const size_t sc_bytes = align_up((size_t)nq * fchunk * 4, 256);
+    const size_t sc_bytes = align_up((size_t)nq * (fchunk > S ? fchunk : S) * 4, 256);
     const size_t tv_bytes = align_up((size_t)nq * k * 4, 256), ti_bytes = align_up((size_t)nq * k * 8, 256);
     const size_t qp_bytes = fast ? align_up((size_t)nq_pad * d * 2, 256) : 0;
     const size_t cv_bytes = filt ? align_up((size_t)nq * cap * 4, 256) : 0, ci_bytes = filt ? align_up((size_t)nq * cap * 8, 256) : 0;
     const size_t cc_bytes = filt ? align_up((size_t)(nq_pad + n_flags) * 4, 256) : 0;  // counters + per-chunk overflow flags
+    const size_t th_bytes = sampled ? tv_bytes + ti_bytes + align_up((size_t)nq * 4, 256) : 0;   // sample's list + dense thresholds
     st = ensure(c, &c->ws2, &c->ws2_bytes,
-                sc_bytes + 3 * (tv_bytes + ti_bytes) + qp_bytes + cv_bytes + ci_bytes + cc_bytes);
+                sc_bytes + 3 * (tv_bytes + ti_bytes) + qp_bytes + cv_bytes + ci_bytes + cc_bytes + th_bytes);
     if (st != SGPT_OK) return st;
     char* base = (char*)c->ws2;
     size_t off = 0;
@@ -981,6 +1010,9 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     long long* cand_i = filt ? (long long*)take(ci_bytes) : nullptr;
     int* cand_cnt = filt ? (int*)take(cc_bytes) : nullptr;
     int* flag = filt ? cand_cnt + nq_pad : nullptr;
+    float* th_v = sampled ? (float*)take(tv_bytes) : nullptr;
+    int64_t* th_i = sampled ? (int64_t*)take(ti_bytes) : nullptr;
+    float* thr_dense = sampled ? (float*)take(align_up((size_t)nq * 4, 256)) : nullptr;
     if (fast) {
         HIPC(c, hipMemsetAsync(qpad, 0, (size_t)nq_pad * d * 2, s));
         HIPC(c, hipMemcpyAsync(qpad, q, (size_t)nq * d * 2, hipMemcpyDeviceToDevice, s));
@@ -988,10 +1020,10 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     const size_t esz = dtype == SGPT_F32 ? 4 : 2;
 
     // fp32 scores of documents [c0, c0 + nc) for every query -> sc[nq][ld]
-    auto score_tile = [&](long c0, long nc, long ld, const int* pred) {
+    auto score_tile = [&](long c0, long nc, long ld, const int* pred, long row_stride = 1) {
         GemmArgs g{};
         g.A = q; g.lda = d; g.M = nq; g.m_valid = nq; g.K = d; g.pred = pred;
-        g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = d; g.N = (int)nc;
+        g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = (long)d * row_stride; g.N = (int)nc;   // row_stride > 1: a strided sample
         g.out = sc; g.ldo = ld;
         const long na = fast ? nc / 256 * 256 : 0;      // documents the 256-document tile kernels take
         if (na > 0) {
@@ -1052,29 +1084,55 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     } else {
         HIPC(c, hipMemsetAsync(cand_cnt, 0, (size_t)(nq_pad + n_flags) * 4, s));
         static const bool no_fallback = exp_env("SGPT_SCORE_NOFALLBACK") != nullptr;   // timing experiments ONLY: unsafe
-        // first chunk: materialise + select -> the initial thresholds.  One whole wave of tiles is enough (the
-        // doubling schedule takes over from there): 16 384 documents for nq = 1000 instead of 32 768
-        const long first = unit < chunk ? unit : chunk;
-        st = classic(0, first, pv0, pi0, n_run, tv[0], ti[0], nullptr, chunk);
-        if (st != SGPT_OK) return st;
         int cur = 0, chunk_i = 0;
-        long seen = first;
-        const long n256 = N / 256 * 256;
-        // doubling schedule: a filtered chunk is as long as everything seen before it, so a query expects ~k
-        // survivors per chunk (k * len / seen) whatever N is; 1 M documents = 1 + 5 launches instead of 31
+        long seen = 0;                 // documents behind which the filtered chunks continue
+        long eff = 0;                  // documents the current thresholds are the k-th best of
+        const long n256 = n256_all;
+        if (sampled) {
+            // running best going in: tv[0] / ti[0] = the caller's list padded to k columns, or empty (idx -1 everywhere)
+            if (n_run > 0) {
+                launch_topk_select(run_val, k, 0, 0, run_val, run_idx, n_run, k, nq, k, 0, nullptr, tv[0], ti[0], s);
+            } else {
+                HIPC(c, hipMemsetAsync(tv[0], 0, (size_t)nq * k * 4, s));
+                HIPC(c, hipMemsetAsync(ti[0], 0xff, (size_t)nq * k * 8, s));
+            }
+            // thresholds: the k-th best of {running best} U {S documents at stride s_stride across the shard}; only the VALUES
+            // of this selection are used (its indices are sample positions) -- the filtered chunks below re-score the sampled
+            // documents like any other and find them again
+            score_tile(0, S, S, nullptr, s_stride);
+            launch_topk_select(sc, S, S, 0, tv[0], ti[0], k, k, nq, k, 0, nullptr, th_v, th_i, s);
+            launch_thr_below(th_v, k, nq, thr_dense, s);
+            eff = S;
+        } else {
+            // first chunk: materialise + select -> the initial thresholds.  One whole wave of tiles is enough (the
+            // doubling schedule takes over from there): 16 384 documents for nq = 1000 instead of 32 768
+            const long first = unit < chunk ? unit : chunk;
+            st = classic(0, first, pv0, pi0, n_run, tv[0], ti[0], nullptr, chunk);
+            if (st != SGPT_OK) return st;
+            seen = first; eff = first;
+        }
+        // k > 64, doubling schedule: a filtered chunk is as long as everything seen before it, so a query expects ~k
+        // survivors per chunk (k * len / seen) whatever N is; 1 M documents = 1 + 5 launches instead of 31.
+        // k <= 64, sampled schedule: `ratio` times the documents the thresholds stand for (see above).
         while (n256 - seen >= 256) {
-            long len = half_growth ? (seen / 2 / 256 * 256 > 256 ? seen / 2 / 256 * 256 : 256) : seen * growth;
+            long len;
+            if (sampled) len = (long)((double)eff * ratio) / 256 * 256;
+            else len = half_growth ? (eff / 2 / 256 * 256 > 256 ? eff / 2 / 256 * 256 : 256) : eff * growth;
+            if (len < 256) len = 256;
             if (len > (1L << 19)) len = 1L << 19;
             if (len >= n256 - seen) len = n256 - seen;          // the last chunk takes what is left (no whole-wave rounding: that
             else if (len >= unit) len = len / unit * unit;      //  left a 17 k-document sixth launch behind 1 M documents at nq = 16)
             GemmArgs g{};
             g.A = qpad; g.lda = d; g.M = nq_pad; g.m_valid = nq; g.K = d;
             g.W = (const char*)corpus + (size_t)seen * d * esz; g.ldw = d; g.N = (int)len;
-            g.thr = tv[cur] + (k - 1); g.thr_ld = k;
+            // sampled schedule: the dense thresholds -- the sample's k-th best, raised by every merge to the running k-th best
+            if (sampled) { g.thr = thr_dense; g.thr_ld = 1; }
+            else { g.thr = tv[cur] + (k - 1); g.thr_ld = k; }
             g.cand_val = cand_v; g.cand_idx = cand_i; g.cand_cnt = cand_cnt; g.cand_cap = cap; g.idx_base = idx_base + seen;
             gemm(c, dtype, EPI_SCORE_FILTER, SGPT_F32, g, s);
             const long c_lo = seen;
             seen += len;
+            eff = seen;                                         // the thresholds now stand for every document of [0, seen)
             if (seen == n256 && seen < N) {
                 // ragged tail (< 256 documents): filtered against the same thresholds by the small-tile kernel, its
                 // survivors join this chunk's candidate lists -- one merge, no materialise + select round for 72 documents
@@ -1086,7 +1144,8 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             int* cflag = flag + (chunk_i < n_flags ? chunk_i : n_flags - 1);
             float* ov = fin ? run_val : tv[cur ^ 1];
             int64_t* oi = fin ? run_idx : ti[cur ^ 1];
-            launch_cand_merge(tv[cur], ti[cur], cand_v, (const int64_t*)cand_i, cand_cnt, cap, nq, k, ov, oi, cflag, s);
+            launch_cand_merge(tv[cur], ti[cur], cand_v, (const int64_t*)cand_i, cand_cnt, cap, nq, k, ov, oi, cflag, s,
+                              sampled ? thr_dense : nullptr);
             // A candidate list of this chunk overflowed (document order with a drifting score distribution, a mass of
             // equal scores): the merge result is incomplete -- redo THIS chunk from the pre-chunk best by materialise +
             // select.  Sync-free: predicated on the chunk's device flag.  The thresholds of the next chunk come from the
@@ -1270,12 +1329,12 @@ sgpt_status sgpt_model_set_precision(sgpt_model* m, const int32_t* plan, int32_t
         if (v < 0 || v > (cls == PC_LN1 ? 3 : 1)) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: entries are 0 | 1 (LayerNorm-1 class: 0 ... 3)");
         any |= v != 0;
         const bool legacy_ok = cls == PC_LN1 && (v == 1 || v == 3) && m->L[i / PC_N].w_qkv3 != nullptr;
-        if (v != 0 && !m->split_all && !legacy_ok)
+        if (v != 0 && cls != PC_ATT && !m->split_all && !legacy_ok)      // (the attention class splits activations only)
             return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: the model was loaded without split weight copies (sgpt_model_desc.split_weights)");
         if (cls == PC_ATT && v != 0 && (m->d.arch == SGPT_ARCH_GPTJ || !attn_x3_supported(dh)))
             return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: split-precision attention needs head_dim 64 or 128 and no rotary embedding (GPT-Neo / BLOOM)");
-        if (cls == PC_LN2 && m->d.arch == SGPT_ARCH_GPTJ && (v != 0) != (plan[i - PC_LN2 + PC_LN1] != 0))
-            return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: GPT-J's MLP reads ln_1's output: the LayerNorm-2 entry must follow the LayerNorm-1 entry");
+        if (cls == PC_LN2 && m->d.arch == SGPT_ARCH_GPTJ && v != 0 && plan[i - PC_LN2 + PC_LN1] == 0)
+            return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: GPT-J's MLP reads ln_1's output: a split fc1 needs a split LayerNorm-1 entry");
     }
     if (any && cd != SGPT_F16 && cd != SGPT_BF16) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision applies to SGPT_F16 / SGPT_BF16 models");
     for (int i = 0; i < n; ++i) m->prec[i] = plan[i];

@@ -343,8 +343,10 @@ void launch_topk_select(const float* scores, long ld, long n, long idx_base, con
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
                         const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s,
                         const int* pred = nullptr);
+// thr[q] = nextafter(list[q][k-1], -inf): the inclusive form of a sampled threshold for the strict `>` filter (topk.hip)
+void launch_thr_below(const float* list, int k, int nq, float* thr, hipStream_t s);
 // k best of {running top-k} U {candidate list of the filtered score GEMM}; resets cnt[q], raises *overflow when a
 // list was longer than cap (candidates were dropped: the caller's predicated fallback recomputes)
 void launch_cand_merge(const float* run_val, const int64_t* run_idx, const float* cand_val, const int64_t* cand_idx,
                        int* cand_cnt, int cap, int nq, int k, float* out_val, int64_t* out_idx, int* overflow,
-                       hipStream_t s);
+                       hipStream_t s, float* thr_io = nullptr);   // thr_io: dense per-query threshold, raised to the new k-th best

@@ -770,17 +770,22 @@ __global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
         }
         // ---- epilogue, straight from the registers: lane = query row i*16 + fr, documents n0 + 32 w + 16 j + 4 g .. + 3 ----
         const long n0 = (long)tile * 256 + wave * 32;
+        if constexpr (EPI == EPI_SCORE_FILTER) {
+            // count -> all atomics in flight together -> store (see gemm256_epilogue.inc)
+            float thv[4];
+            int cntv[4], slotv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = i * 16 + fr;
-            if constexpr (EPI == EPI_SCORE_FILTER) {
+            for (int i = 0; i < 4; ++i) {
+                const int m = i * 16 + fr;
                 const float th = m < p.m_valid ? p.thr[(long)m * p.thr_ld] : INFINITY;
+                thv[i] = th;
                 float mx = -INFINITY;                                // fast reject on the raw accumulators (see gemm256_epilogue.inc)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
-                if ((mx > th || th < -1.0f) && cand_room(p.cand_cnt + m, p.cand_cap)) {   // (over capacity: recomputed anyway)
+                int c = 0;
+                if (mx > th || th < -1.0f) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -788,18 +793,30 @@ __global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
                             const float v = acc[i][j][r];
                             acc[i][j][r] = v != v ? -1.0f : v;       // cos_scores[isnan] = -1 (exact_search.py:99)
                         }
-                    int c = 0;
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) c += acc[i][j][r] > th ? 1 : 0;
-                    int slot = atomicAdd(p.cand_cnt + m, c);
+                }
+                cntv[i] = c;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = i * 16 + fr;
+                slotv[i] = p.cand_cap;
+                if (cntv[i] > 0 && cand_room(p.cand_cnt + m, p.cand_cap)) slotv[i] = atomicAdd(p.cand_cnt + m, cntv[i]);   // (over capacity: recomputed anyway)
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (cntv[i] > 0) {
+                    const int m = i * 16 + fr;
+                    int slot = slotv[i];
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float v = acc[i][j][r];
-                            if (v > th) {
+                            if (v > thv[i]) {
                                 if (slot < p.cand_cap) {
                                     p.cand_val[(long)m * p.cand_cap + slot] = v;
                                     p.cand_idx[(long)m * p.cand_cap + slot] = p.idx_base + n0 + j * 16 + 4 * g + r;
@@ -808,7 +825,13 @@ __global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
                             }
                         }
                 }
-            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = i * 16 + fr;
                 if (m < p.m_valid) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -818,9 +841,9 @@ __global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
                         *reinterpret_cast<float4*>(static_cast<float*>(p.out) + (long)m * p.ldo + n0 + j * 16 + 4 * g) = v;
                     }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         if (!has_next) break;
         tile = ntile; dsrc = ndsrc;

@@ -356,7 +356,11 @@ __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __r
                                                                const int64_t* __restrict__ cand_idx,
                                                                int* __restrict__ cand_cnt, int cap, int k,
                                                                float* __restrict__ out_val, int64_t* __restrict__ out_idx,
-                                                               int* __restrict__ overflow) {
+                                                               int* __restrict__ overflow, float* __restrict__ thr_io) {
+    // thr_io (optional, sampled scorer schedule): the query's dense filter threshold; raised to the merged list's k-th best
+    // when that is higher.  It starts as the (inclusive) k-th best of a strided sample of the whole shard and never drops
+    // below it: a first chunk whose documents all score under the sample's k-th best leaves fewer than k entries in the
+    // running list, and a threshold read from that list would be -inf -- every document of the next chunk a survivor.
     __shared__ float s_val[TK_SORT_MAX];      // candidates
     __shared__ int64_t s_idx[TK_SORT_MAX];
     __shared__ float r_val[TK_MERGE_KMAX];    // running top-k
@@ -388,15 +392,38 @@ __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __r
     for (int i = t; i < nrun; i += TK_THREADS) {
         const int pos = i + count_before(s_val, s_idx, cnt, r_val[i], r_idx[i]);
         if (pos < k) { out_val[(long)q * k + pos] = r_val[i]; out_idx[(long)q * k + pos] = r_idx[i]; }
+        if (pos == k - 1 && thr_io != nullptr && r_val[i] > thr_io[q]) thr_io[q] = r_val[i];     // (exactly one element lands on k - 1)
     }
     for (int j = t; j < cnt; j += TK_THREADS) {
         const int pos = j + count_before(r_val, r_idx, nrun, s_val[j], s_idx[j]);
         if (pos < k) { out_val[(long)q * k + pos] = s_val[j]; out_idx[(long)q * k + pos] = s_idx[j]; }
+        if (pos == k - 1 && thr_io != nullptr && s_val[j] > thr_io[q]) thr_io[q] = s_val[j];
     }
     for (int i = total + t; i < k; i += TK_THREADS) { out_val[(long)q * k + i] = -INFINITY; out_idx[(long)q * k + i] = -1; }
 }
 
+// thr[q] = the largest float strictly below list[q][k - 1] (the k-th best of a SAMPLE of the shard): the filtered scorer keeps
+// scores STRICTLY above its threshold, which is right when the threshold comes from earlier documents (a later document never
+// displaces an equal score) but not when it comes from a sample that also holds LATER documents -- an equal score with a lower
+// index must survive.  `v > nextdown(t)` is `v >= t`.  -inf (fewer than k real scores) stays -inf: everything survives.
+__global__ __launch_bounds__(256) void thr_below_kernel(const float* __restrict__ list, int k, int nq, float* __restrict__ thr) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float t = list[(long)q * k + (k - 1)];
+    float r = t;
+    if (t == t && t > -INFINITY) {
+        const uint32_t u = __float_as_uint(t);
+        if (t == 0.0f) r = -__uint_as_float(1u);                       // below +-0: the smallest negative subnormal
+        else r = __uint_as_float((u & 0x80000000u) ? u + 1 : u - 1);  // one ulp towards -inf
+    }
+    thr[q] = r;
+}
+
 }  // namespace
+
+void launch_thr_below(const float* list, int k, int nq, float* thr, hipStream_t s) {
+    hipLaunchKernelGGL(thr_below_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, list, k, nq, thr);
+}
 
 void launch_topk_select(const float* scores, long ld, long n, long idx_base, const float* prev_val,
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
@@ -407,7 +434,7 @@ void launch_topk_select(const float* scores, long ld, long n, long idx_base, con
 
 void launch_cand_merge(const float* run_val, const int64_t* run_idx, const float* cand_val, const int64_t* cand_idx,
                        int* cand_cnt, int cap, int nq, int k, float* out_val, int64_t* out_idx, int* overflow,
-                       hipStream_t s) {
+                       hipStream_t s, float* thr_io) {
     hipLaunchKernelGGL(cand_merge_kernel, dim3(nq), dim3(TK_THREADS), 0, s, run_val, run_idx, cand_val, cand_idx, cand_cnt,
-                       cap, k, out_val, out_idx, overflow);
+                       cap, k, out_val, out_idx, overflow, thr_io);
 }

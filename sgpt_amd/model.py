@@ -225,9 +225,24 @@ class _Staging:
         self.events[i] = ev
 
 
-# precise_qk=None on dtype-'f16' GPT-Neo models with hidden_size >= 2048: the cheapest variant that holds the SGPT-1.3B
-# reference fixture inside the bar with margin (profiles/r04_precise_qk.txt)
-PRECISE_QK_DEFAULT = "full"
+# precise_qk -> (LayerNorm-1 class level, attention class, context class) in every block
+PRECISE_QK_PLANS = {"full": (1, 0, 0), "logits": (0, 1, 0), "act+logits": (3, 1, 0), "full+logits": (1, 1, 0),
+                    "qkv+logits": (2, 1, 0), "attn": (2, 1, 1)}
+
+
+
+def default_precise_qk(cfg: "SGPTConfig", dtype: str):
+    """precise_qk=None: the cheapest variant that holds the reference fixture of the model's shape inside the 1e-3 bar with
+    margin, measured on MI355X (profiles/r04_precise_qk.txt; max |cos - ref| / max |normalised emb - ref| and sentences/s):
+      SGPT-1.3B shape (24 layers, d 2048)   plain 8.2e-4 / 1.09e-3 @ 3590   'logits' 6.7e-4 / 8.3e-4 @ 3428   <- default
+                                            'full' (round 3's default) 5.0e-4 / 7.7e-4 @ 2800, 'full+logits' 3.3e-4 / 4.3e-4 @ 2706
+      SGPT-2.7B shape (32 layers, d 2560)   plain 1.11e-3 / 2.21e-3 @ 1788  'logits' 1.07e-3 / 1.74e-3, 'full' 9.0e-4 / 1.25e-3
+                                            'full+logits' 5.1e-4 / 8.0e-4 @ 1337   <- default ('qkv+logits' 4.6e-4 / 6.9e-4 @ 1214)
+    GPT-Neo only (no 1/sqrt(dh) in its attention, HF:gpt_neo:110: the logits grow with the width); GPT-J / BLOOM sit at 6e-5
+    and SGPT-125M at 3.2e-4 without any of it."""
+    if dtype != "f16" or cfg.model_type != "gpt_neo" or cfg.hidden_size < 2048:
+        return False
+    return "logits" if cfg.hidden_size < 2560 else "full+logits"
 
 
 class SGPTModel:
@@ -250,10 +265,11 @@ class SGPTModel:
           'auto-class'  as 'auto' but only the flagged classes are split (LayerNorm-1 brings the block's attention along).
         precise_qk: the structural rule for GPT-Neo -- no 1/sqrt(dh) in its attention, so at d >= 2048 the path LayerNorm ->
         Wq / Wk -> q / k -> logits carries 80 % of the 16-bit deviation from the fp32 reference.  None (default)
-        = ON for dtype 'f16' GPT-Neo models with hidden_size >= 2048 (SGPT-1.3B / 2.7B) as PRECISE_QK_DEFAULT, off
-        elsewhere; False = off; True / 'full' = the Q / K projection over hi + lo pairs of both operands (+33 % FLOPs);
+        = default_precise_qk(): ON for dtype 'f16' GPT-Neo models with hidden_size >= 2048 ('logits' at SGPT-1.3B shape,
+        'full+logits' from SGPT-2.7B shape on), off elsewhere; False = off; True / 'full' = the Q / K projection over hi + lo pairs of both operands (+33 % FLOPs);
         'logits' = q / k / v / p as hi + lo pairs inside the attention only (no extra GEMM FLOPs); 'act+logits' = that plus the
-        LayerNorm-1 output split against plain weights (+17 % FLOPs)."""
+        LayerNorm-1 output split against plain weights (+17 % FLOPs); 'full+logits'; 'qkv+logits' (the V projection split as
+        well); 'attn' (the whole attention sub-block: Q / K / V projection, attention, out-projection)."""
         if dtype in ("fp16", "float16", "half"):
             dtype = "f16"
         if precision is None:
@@ -263,11 +279,11 @@ class SGPTModel:
         if precision != "plain" and dtype not in ("f16", "bf16"):
             raise ValueError("precision applies to dtype 'f16' / 'bf16'")
         if precise_qk is None:
-            precise_qk = PRECISE_QK_DEFAULT if (dtype == "f16" and cfg.model_type == "gpt_neo" and cfg.hidden_size >= 2048) else False
+            precise_qk = default_precise_qk(cfg, dtype)
         if precise_qk is True:
             precise_qk = "full"
-        if precise_qk not in (False, "full", "logits", "act+logits"):
-            raise ValueError("precise_qk must be None, False, True / 'full', 'logits' or 'act+logits'")
+        if precise_qk not in (False,) + tuple(PRECISE_QK_PLANS):
+            raise ValueError(f"precise_qk must be None, False, True or one of {sorted(PRECISE_QK_PLANS)}")
         if precise_qk and dtype not in ("f16", "bf16"):
             raise ValueError("precise_qk applies to dtype 'f16' / 'bf16'")
         if dtype not in ("f16", "bf16", "fp32", "fp8", "fp8mfma"):
@@ -295,8 +311,9 @@ class SGPTModel:
                          compute_dtype={"f16": SGPT_F16, "bf16": SGPT_BF16, "fp32": SGPT_F32, "fp8": SGPT_FP8W,
                                         "fp8mfma": SGPT_FP8M}[dtype],
                          layer_is_local=C.cast(local, C.POINTER(C.c_uint8)), rotary_dim=cfg.rotary_dim if gptj else 0,
-                         qk_split=1 if precise_qk == "full" else 0,
-                         split_weights=1 if (precision != "plain" or precise_qk == "act+logits") else 0)
+                         qk_split=1 if (precise_qk and PRECISE_QK_PLANS[precise_qk][0] in (1, 3)) else 0,
+                         split_weights=1 if (precision != "plain" or (precise_qk and (PRECISE_QK_PLANS[precise_qk][0] == 2 or
+                                                                                        PRECISE_QK_PLANS[precise_qk][2]))) else 0)
         self.precise_qk = precise_qk
         self.precision = precision
         self.precision_report = None      # filled by the probe: crest factors [num_layers, 4] and what was decided
@@ -347,14 +364,11 @@ class SGPTModel:
     def _base_plan(self) -> np.ndarray:
         """The structural part of the plan: precise_qk."""
         plan = np.zeros((self.cfg.num_layers, SGPT_PREC_CLASSES), dtype=np.int32)
-        if self.precise_qk == "full":
-            plan[:, PC_LN1] = 1
-        elif self.precise_qk in ("logits", "act+logits"):
-            if not self._att_ok:
-                raise ValueError("precise_qk='logits' needs head_dim 64 / 128 and no rotary embedding")
-            plan[:, PC_ATT] = 1
-            if self.precise_qk == "act+logits":
-                plan[:, PC_LN1] = 3
+        if self.precise_qk:
+            ln1, att, ctx = PRECISE_QK_PLANS[self.precise_qk]
+            if att and not self._att_ok:
+                raise ValueError(f"precise_qk={self.precise_qk!r} needs head_dim 64 / 128 and no rotary embedding")
+            plan[:, PC_LN1], plan[:, PC_ATT], plan[:, PC_CTX] = ln1, att, ctx
         return plan
 
     def _x3_plan(self) -> np.ndarray:
