@@ -379,6 +379,10 @@ int32_t sgpt_comm_world(const sgpt_ctx* ctx);     /* 0 = no communicator */
 int32_t sgpt_comm_rank(const sgpt_ctx* ctx);
 sgpt_status sgpt_allgather_rows(sgpt_ctx* ctx, const void* local, const int64_t* counts, int64_t row_bytes, void* out,
                                 void* stream);
+/* The same result through the RAGGED branch whatever the counts are (pad to the largest block, gather into the exchange
+ * workspace, compact in rank order): lets a world of one -- or equal shards -- exercise the code path unequal shards take. */
+sgpt_status sgpt_allgather_rows_padded(sgpt_ctx* ctx, const void* local, const int64_t* counts, int64_t row_bytes, void* out,
+                                       void* stream);
 sgpt_status sgpt_exchange_topk(sgpt_ctx* ctx, const float* val, const int64_t* idx, int32_t nq, int32_t k, int32_t k_out,
                                const int64_t* exclude_idx, float* out_val, int64_t* out_idx, void* stream);
 sgpt_status sgpt_fold_gathered_topk(sgpt_ctx* ctx, const float* gathered_val, const int64_t* gathered_idx, int32_t world,

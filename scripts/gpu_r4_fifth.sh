@@ -1,0 +1,8 @@
+#!/bin/bash
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd $R; mkdir -p gpurun_out
+( timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_search.py -q --timeout=600 ) > gpurun_out/r4e_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r4e_tests.log | cut -c1-300
+( for n in 125000 250000 500000 1000000; do N=$n python scripts/score_bench.py; done; for nq in 128 64 16; do NQ=$nq python scripts/score_bench.py; done; NQ=16 N=125000 python scripts/score_bench.py; NQ=128 N=125000 python scripts/score_bench.py; for dr in 0.1 0.5 0.9; do echo -n "DRIFT=$dr "; DRIFT=$dr python scripts/score_bench.py; done; echo -n "K=101 "; K=101 python scripts/score_bench.py;  echo -n "K=1001 "; K=1001 python scripts/score_bench.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4e_score_bench.txt
+( timeout 900 python bench.py --steps 10 --no-cpu-baseline --no-varlen ) 2>/dev/null | grep '^{' > gpurun_out/r4e_bench.json; python -c "
+import json; d=json.load(open('gpurun_out/r4e_bench.json')); print(d['value'], d['queries_per_sec_at_1M_corpus'], json.dumps(d['projected_8gpu']), json.dumps(d['queries_per_sec_at_1M_corpus_k1001']), d['queries_per_sec_at_1M_corpus_incl_query_encode_by_nq'])"

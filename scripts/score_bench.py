@@ -12,6 +12,12 @@ base = torch.randn(1, d, device="cuda", generator=g) * 3          # anisotropic:
 cf = base + torch.randn(N, d, device="cuda", generator=g)
 if os.environ.get("DRIFT"):      # score distribution jumps at this fraction of the corpus (documents behind it score higher)
     cf[int(float(os.environ["DRIFT"]) * N):] += 2.0 * base
+if os.environ.get("DUP"):        # bench.py's 1 M shard: perturbed copies of a block of DUP documents
+    D = int(os.environ["DUP"])
+    blk = torch.nn.functional.normalize(cf[:D], dim=1).to(DT).float()
+    for s0 in range(0, N, D):
+        e0 = min(N, s0 + D)
+        cf[s0:e0] = blk[: e0 - s0] + 0.02 * torch.randn((e0 - s0, d), device="cuda", generator=g)
 c = torch.nn.functional.normalize(cf, dim=1).to(DT)
 del cf
 q = torch.nn.functional.normalize(base + torch.randn(nq, d, device="cuda", generator=g), dim=1).to(DT)

@@ -86,6 +86,7 @@ SIGNATURES = {
     "sgpt_comm_world": (C.c_int32, [C.c_void_p]),
     "sgpt_comm_rank": (C.c_int32, [C.c_void_p]),
     "sgpt_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sgpt_allgather_rows_padded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "sgpt_exchange_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgpt_fold_gathered_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -948,7 +948,15 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // (relative spread 1 / sqrt(k)): lists of `cap` entries take R = cap / (k (1 + 6 / sqrt(k))) times the documents the
     // thresholds were drawn from with ~6 sigma of head-room.
     const bool sampled_k = k <= 64;
-    const int cap = sampled_k ? (k <= 32 ? 512 : 1024) : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
+    // list capacity of the sampled schedule: the sample is N / ratio documents and ratio grows with cap, so long shards take
+    // long lists (1 M documents, k = 11: 2048 entries -> a 15 k-document sample instead of 60 k); short shards keep short
+    // ones, because the expected survivors per row and 256-document tile, cap / (2.8 N / 256), is what the filtered GEMM's
+    // append path pays for (0.37 at 125 k documents with 512 entries: 236 us per launch against ~190 without appends)
+    // (nq <= 64: the 64-row scorer tile is HBM-bound -- ~1 us per tile -- and an append flush costs it a global round trip, so
+    // short query batches keep the survivors rare: 512 entries, a sample of N / 16)
+    const int cap_n = nq <= 64 ? 512 : (N >= 800000 ? 2048 : (N >= 400000 ? 1024 : 512));
+    const int cap_s = cap_n * (k <= 32 ? 1 : 2) > 2048 ? 2048 : cap_n * (k <= 32 ? 1 : 2);
+    const int cap = sampled_k ? cap_s : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
     const bool half_growth = 2 * cap < 5 * k;          // k > ~340: cap < 2.5 k -> grow by half, expect ~k/2 per chunk
     // k > 64 keeps the first-chunk + doubling schedule.  Two other schedules were measured against doubling and rejected:
     //   round 2: 4x growth with 256-entry lists -- overflowed on corpora whose score distribution drifts along the index and
@@ -973,6 +981,14 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         if (S > n256_all / 2) S = n256_all / 2 / 256 * 256;
         s_stride = n256_all / S;
         if (s_stride < 1) s_stride = 1;
+        // an ODD stride: a corpus with a power-of-two period (bench.py's 1 M shard is perturbed copies of a 40 960-document
+        // block: stride 16 met the SAME source documents in every copy -- a third of the effective sample, and lists that
+        // overflowed for a few queries in a thousand) is the structure a sample must not resonate with
+        if (s_stride > 1 && s_stride % 2 == 0) s_stride -= 1;
+        // equally spaced rows have an integer stride: stretch the sample to the END of the shard at that stride (a tail the
+        // sample never visits is invisible to the thresholds -- 33 k of 1 M documents at stride 16: a corpus whose best
+        // documents sit at the end overflowed the lists of ~3 queries in 1000)
+        S = n256_all / s_stride / 256 * 256;
     }
 
     // A filtered chunk whose candidate lists overflow is recomputed by materialise + select in pieces whose fp32 score tile
@@ -1014,7 +1030,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     int64_t* th_i = sampled ? (int64_t*)take(ti_bytes) : nullptr;
     float* thr_dense = sampled ? (float*)take(align_up((size_t)nq * 4, 256)) : nullptr;
     if (fast) {
-        HIPC(c, hipMemsetAsync(qpad, 0, (size_t)nq_pad * d * 2, s));
+        if (nq_pad > nq) HIPC(c, hipMemsetAsync((char*)qpad + (size_t)nq * d * 2, 0, (size_t)(nq_pad - nq) * d * 2, s));   // the pad rows only
         HIPC(c, hipMemcpyAsync(qpad, q, (size_t)nq * d * 2, hipMemcpyDeviceToDevice, s));
     }
     const size_t esz = dtype == SGPT_F32 ? 4 : 2;
@@ -1093,8 +1109,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             if (n_run > 0) {
                 launch_topk_select(run_val, k, 0, 0, run_val, run_idx, n_run, k, nq, k, 0, nullptr, tv[0], ti[0], s);
             } else {
-                HIPC(c, hipMemsetAsync(tv[0], 0, (size_t)nq * k * 4, s));
-                HIPC(c, hipMemsetAsync(ti[0], 0xff, (size_t)nq * k * 8, s));
+                HIPC(c, hipMemsetAsync(ti[0], 0xff, (size_t)nq * k * 8, s));     // idx -1: an empty slot whatever its value says
             }
             // thresholds: the k-th best of {running best} U {S documents at stride s_stride across the shard}; only the VALUES
             // of this selection are used (its indices are sample positions) -- the filtered chunks below re-score the sampled

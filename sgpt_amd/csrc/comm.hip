@@ -110,8 +110,8 @@ sgpt_status sgpt_comm_destroy(sgpt_ctx* c) {
 int32_t sgpt_comm_world(const sgpt_ctx* c) { return c && c->comm ? c->comm_world : 0; }
 int32_t sgpt_comm_rank(const sgpt_ctx* c) { return c && c->comm ? c->comm_rank : -1; }
 
-sgpt_status sgpt_allgather_rows(sgpt_ctx* c, const void* local, const int64_t* counts, int64_t row_bytes, void* out,
-                                void* stream) {
+static sgpt_status allgather_rows_impl(sgpt_ctx* c, const void* local, const int64_t* counts, int64_t row_bytes, void* out,
+                                       void* stream, bool force_padded) {
     if (!c) return SGPT_ERR_INVALID;
     if (!c->comm) return cfail(c, SGPT_ERR_INVALID, "sgpt_allgather_rows: no communicator (sgpt_comm_init)");
     if (!counts || !out || row_bytes <= 0) return cfail(c, SGPT_ERR_INVALID, "sgpt_allgather_rows: bad arguments");
@@ -129,7 +129,7 @@ sgpt_status sgpt_allgather_rows(sgpt_ctx* c, const void* local, const int64_t* c
     HIPC(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const size_t blk = (size_t)mx * row_bytes;
-    if (equal) {            // the common case (shard sizes differ by at most one row only when n % world != 0)
+    if (equal && !force_padded) {            // the common case (shard sizes differ by at most one row only when n % world != 0)
         NCCLC(c, ncclAllGather(local, out, blk, ncclInt8, (ncclComm_t)c->comm, s));
         return SGPT_OK;
     }
@@ -149,6 +149,16 @@ sgpt_status sgpt_allgather_rows(sgpt_ctx* c, const void* local, const int64_t* c
         o += b;
     }
     return SGPT_OK;
+}
+
+sgpt_status sgpt_allgather_rows(sgpt_ctx* c, const void* local, const int64_t* counts, int64_t row_bytes, void* out,
+                                void* stream) {
+    return allgather_rows_impl(c, local, counts, row_bytes, out, stream, false);
+}
+
+sgpt_status sgpt_allgather_rows_padded(sgpt_ctx* c, const void* local, const int64_t* counts, int64_t row_bytes, void* out,
+                                       void* stream) {
+    return allgather_rows_impl(c, local, counts, row_bytes, out, stream, true);
 }
 
 // The rank-local half of the exchange: [world][nq][k] gathered lists -> the k_out best per query.  Needs no communicator:

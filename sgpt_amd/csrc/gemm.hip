@@ -692,6 +692,7 @@ __global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
     typedef __attribute__((address_space(3))) char* lds_cptr_t;
     constexpr int DSLOT = 256 * CH, QSLOT = 64 * CH;                           // uint4 per slot
     __shared__ __attribute__((aligned(16))) uint4 lds[3 * DSLOT + 2 * QSLOT];  // 96 + 16 KiB
+    __shared__ __attribute__((aligned(16))) uint2 stage_all[EPI == EPI_SCORE_FILTER ? 8 * 256 : 1];   // filtered epilogue: 256 staged survivors per wave
     const int K = p.K, nk = K / 64, NT = p.N / 256;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, g = lane >> 4;
@@ -771,62 +772,82 @@ __global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
         // ---- epilogue, straight from the registers: lane = query row i*16 + fr, documents n0 + 32 w + 16 j + 4 g .. + 3 ----
         const long n0 = (long)tile * 256 + wave * 32;
         if constexpr (EPI == EPI_SCORE_FILTER) {
-            // count -> all atomics in flight together -> store (see gemm256_epilogue.inc)
-            float thv[4];
-            int cntv[4], slotv[4];
+            // survivors staged in LDS by ballot positions, one flush per tile (see gemm256_epilogue.inc)
+            uint2_a* stage = reinterpret_cast<uint2_a*>(&stage_all[wave * 256]);
+            int staged = 0;                                                // wave-uniform
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = i * 16 + fr;
                 const float th = m < p.m_valid ? p.thr[(long)m * p.thr_ld] : INFINITY;
-                thv[i] = th;
-                float mx = -INFINITY;                                // fast reject on the raw accumulators (see gemm256_epilogue.inc)
+                float mx = -INFINITY;                                // fast reject on the raw accumulators
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
-                int c = 0;
-                if (mx > th || th < -1.0f) {
+                if (__ballot(th < -1.0f) != 0) {                      // thresholds below -1 (dot scores): the per-lane path, NaN -> -1 may survive
+                    if ((mx > th || th < -1.0f) && cand_room(p.cand_cnt + m, p.cand_cap)) {
+                        int c = 0;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = acc[i][j][r];
-                            acc[i][j][r] = v != v ? -1.0f : v;       // cos_scores[isnan] = -1 (exact_search.py:99)
-                        }
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = acc[i][j][r];
+                                acc[i][j][r] = v != v ? -1.0f : v;       // cos_scores[isnan] = -1 (exact_search.py:99)
+                                c += acc[i][j][r] > th ? 1 : 0;
+                            }
+                        int slot = atomicAdd(p.cand_cnt + m, c);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) c += acc[i][j][r] > th ? 1 : 0;
-                }
-                cntv[i] = c;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = i * 16 + fr;
-                slotv[i] = p.cand_cap;
-                if (cntv[i] > 0 && cand_room(p.cand_cnt + m, p.cand_cap)) slotv[i] = atomicAdd(p.cand_cnt + m, cntv[i]);   // (over capacity: recomputed anyway)
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (cntv[i] > 0) {
-                    const int m = i * 16 + fr;
-                    int slot = slotv[i];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = acc[i][j][r];
-                            if (v > thv[i]) {
-                                if (slot < p.cand_cap) {
-                                    p.cand_val[(long)m * p.cand_cap + slot] = v;
-                                    p.cand_idx[(long)m * p.cand_cap + slot] = p.idx_base + n0 + j * 16 + 4 * g + r;
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = acc[i][j][r];
+                                if (v > th) {
+                                    if (slot < p.cand_cap) {
+                                        p.cand_val[(long)m * p.cand_cap + slot] = v;
+                                        p.cand_idx[(long)m * p.cand_cap + slot] = p.idx_base + n0 + j * 16 + 4 * g + r;
+                                    }
+                                    ++slot;
                                 }
-                                ++slot;
+                            }
+                    }
+                } else if (__ballot(mx > th) != 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[i][j][r];
+                            const bool sv = v > th;
+                            const unsigned long long mask = __ballot(sv);
+                            if (mask != 0) {
+                                if (sv) {
+                                    const int pos = staged + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                    if (pos < 256) stage[pos] = make_uint2((unsigned)(m << 16) | (unsigned)(j * 16 + 4 * g + r), __float_as_uint(v));
+                                }
+                                staged += __builtin_popcountll(mask);
                             }
                         }
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (staged > 0) {
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int ne = staged < 256 ? staged : 256;
+                for (int e = lane; e < ne; e += 64) {
+                    const uint2 ent = stage[e];
+                    const int m = (int)(ent.x >> 16);
+                    if (cand_room(p.cand_cnt + m, p.cand_cap)) {
+                        const int slot = atomicAdd(p.cand_cnt + m, 1);
+                        if (slot < p.cand_cap) {
+                            p.cand_val[(long)m * p.cand_cap + slot] = __uint_as_float(ent.y);
+                            p.cand_idx[(long)m * p.cand_cap + slot] = p.idx_base + n0 + (int)(ent.x & 0xffffu);
+                        }
+                    }
+                }
+                if (staged > 256 && lane == 0) atomicAdd(p.cand_cnt + (int)(stage[0].x >> 16), p.cand_cap + 1);   // force the fallback
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else {
 #pragma unroll

@@ -134,6 +134,36 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
             if (in_lds) { s_val[i] = v; s_idx[i] = id; } else { ov[i] = v; oi[i] = id; }
         }
         done = true;
+    } else if (k <= TK_FAST_KMAX && total <= 1024 && in_lds) {
+        // ---------------- short rows (cross-chunk / cross-rank merges: 2 k ... world * k candidates): everything into LDS,
+        // the k best by k rounds of a wave-wide arg-max -- ~2 us where the radix path below (4 histogram passes + tie
+        // handling, built for rows of 10^4 ... 10^6 scores) took ~25: the fold of 8 ranks' lists, the chunk-loop merge ----
+        for (long i = t; i < total; i += TK_THREADS) { s_val[i] = r.val(i); s_idx[i] = r.idx(i); }
+        __syncthreads();
+        if (t < 64) {
+            const int cnt = (int)total;
+            for (int round = 0; round < kk; ++round) {
+                float bv = -INFINITY; int64_t bi = 0x7fffffffffffffffLL; int bp = -1;
+                for (int c0 = lane; c0 < cnt; c0 += 64) {
+                    const float v = s_val[c0]; const int64_t id = s_idx[c0];
+                    if (id >= 0 && (bp < 0 || sorts_before(v, id, bv, bi))) { bv = v; bi = id; bp = c0; }
+                }
+#pragma unroll
+                for (int sd = 32; sd > 0; sd >>= 1) {
+                    const float ov_ = __shfl_xor(bv, sd, 64);
+                    const long long oi_ = __shfl_xor((long long)bi, sd, 64);
+                    const int op_ = __shfl_xor(bp, sd, 64);
+                    if (op_ >= 0 && (bp < 0 || sorts_before(ov_, (int64_t)oi_, bv, bi))) { bv = ov_; bi = (int64_t)oi_; bp = op_; }
+                }
+                if (lane == 0) {
+                    const bool ok = bp >= 0 && bv > -INFINITY;          // (-inf: an empty / excluded slot -> (-inf, -1) like every path)
+                    ov[round] = ok ? bv : -INFINITY; oi[round] = ok ? bi : -1;
+                    if (bp >= 0) s_idx[bp] = -1;
+                }
+            }
+            for (int i = kk + lane; i < k; i += 64) { ov[i] = -INFINITY; oi[i] = -1; }
+        }
+        return;                                    // block-uniform exit: output written
     } else if (k <= TK_FAST_KMAX && total >= TK_FAST_MIN_ROW) {
         // ---------------- fast path: sampled threshold + one pass ----------------
         // Threshold: every thread takes the max of 16 strided samples; each wave sorts its 64 thread-maxima
@@ -386,18 +416,48 @@ __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __r
         cand_cnt[q] = 0;                       // ready for the next filtered chunk
         if (raw > cap) atomicOr(overflow, 1);
     }
-    if (cnt > 1) bitonic_desc<true>(s_val, s_idx, np2, t);
+    // the candidates, sorted: small k with many candidates (the sampled schedule: ~180 of them for k = 11) -> the k best by k
+    // rounds of a wave-wide arg-max (wave 0; ~1 us) instead of a bitonic sort of all of them (36 barrier stages for 256
+    // entries: 29 us per launch at nq = 1000, profiles/r04_shard_profile.txt); everything else is sorted whole
+    const float* cv = s_val;
+    const int64_t* ci = s_idx;
+    int ccnt = cnt;
+    if (k <= TK_FAST_KMAX && cnt > 2 * k) {
+        float* tv_ = r_val + TK_MERGE_KMAX / 2;          // (k <= 64: the upper half of the running-list arrays is free)
+        int64_t* ti_ = r_idx + TK_MERGE_KMAX / 2;
+        if (t < 64) {
+            for (int round = 0; round < k; ++round) {
+                float bv = -INFINITY; int64_t bi = 0x7fffffffffffffffLL; int bp = -1;
+                for (int c0 = t; c0 < cnt; c0 += 64) {
+                    const float v = s_val[c0]; const int64_t id = s_idx[c0];
+                    if (sorts_before(v, id, bv, bi)) { bv = v; bi = id; bp = c0; }
+                }
+#pragma unroll
+                for (int sd = 32; sd > 0; sd >>= 1) {
+                    const float ov_ = __shfl_xor(bv, sd, 64);
+                    const long long oi_ = __shfl_xor((long long)bi, sd, 64);
+                    const int op_ = __shfl_xor(bp, sd, 64);
+                    if (sorts_before(ov_, (int64_t)oi_, bv, bi)) { bv = ov_; bi = (int64_t)oi_; bp = op_; }
+                }
+                if (t == 0) { tv_[round] = bv; ti_[round] = bi; if (bp >= 0) { s_val[bp] = -INFINITY; s_idx[bp] = 0x7fffffffffffffffLL; } }
+            }
+        }
+        __syncthreads();
+        cv = tv_; ci = ti_; ccnt = k;
+    } else if (cnt > 1) {
+        bitonic_desc<true>(s_val, s_idx, np2, t);
+    }
     nrun = count_before(r_val, r_idx, k, -INFINITY, 0x7fffffffffffffffLL);   // sentinels sort last
-    const int total = nrun + cnt;
+    const int total = nrun + ccnt;
     for (int i = t; i < nrun; i += TK_THREADS) {
-        const int pos = i + count_before(s_val, s_idx, cnt, r_val[i], r_idx[i]);
+        const int pos = i + count_before(cv, ci, ccnt, r_val[i], r_idx[i]);
         if (pos < k) { out_val[(long)q * k + pos] = r_val[i]; out_idx[(long)q * k + pos] = r_idx[i]; }
         if (pos == k - 1 && thr_io != nullptr && r_val[i] > thr_io[q]) thr_io[q] = r_val[i];     // (exactly one element lands on k - 1)
     }
-    for (int j = t; j < cnt; j += TK_THREADS) {
-        const int pos = j + count_before(r_val, r_idx, nrun, s_val[j], s_idx[j]);
-        if (pos < k) { out_val[(long)q * k + pos] = s_val[j]; out_idx[(long)q * k + pos] = s_idx[j]; }
-        if (pos == k - 1 && thr_io != nullptr && s_val[j] > thr_io[q]) thr_io[q] = s_val[j];
+    for (int j = t; j < ccnt; j += TK_THREADS) {
+        const int pos = j + count_before(r_val, r_idx, nrun, cv[j], ci[j]);
+        if (pos < k) { out_val[(long)q * k + pos] = cv[j]; out_idx[(long)q * k + pos] = ci[j]; }
+        if (pos == k - 1 && thr_io != nullptr && cv[j] > thr_io[q]) thr_io[q] = cv[j];
     }
     for (int i = total + t; i < k; i += TK_THREADS) { out_val[(long)q * k + i] = -INFINITY; out_idx[(long)q * k + i] = -1; }
 }

@@ -104,8 +104,9 @@ class RcclComm:
         _lib.check(ctx.handle, lib.sgpt_comm_init(ctx.handle, ident, self.rank, self.world), "sgpt_comm_init")
         ctx.__dict__["_comm_group_key"] = key
 
-    def all_gather_rows(self, local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
-        """Rank r contributes counts[r] rows; everyone gets the concatenation in rank order (one ncclAllGather)."""
+    def all_gather_rows(self, local: torch.Tensor, counts: Sequence[int], padded: bool = False) -> torch.Tensor:
+        """Rank r contributes counts[r] rows; everyone gets the concatenation in rank order (one ncclAllGather).
+        padded=True: through the ragged branch (pad, gather, compact) whatever the counts are -- tests of that path."""
         from . import _lib
         from .runtime import _p, _stream_ptr
         ctx = self.ctx
@@ -116,8 +117,8 @@ class RcclComm:
         row_bytes = int(np.prod(tail, dtype=np.int64)) * local.element_size()
         out = torch.empty((int(sum(counts)),) + tail, dtype=local.dtype, device=ctx.device)
         cnt = (C.c_int64 * self.world)(*[int(c) for c in counts])
-        _lib.check(ctx.handle, ctx.lib.sgpt_allgather_rows(ctx.handle, _p(local), cnt, row_bytes, _p(out),
-                                                           _stream_ptr(ctx.device)), "sgpt_allgather_rows")
+        fn = ctx.lib.sgpt_allgather_rows_padded if padded else ctx.lib.sgpt_allgather_rows
+        _lib.check(ctx.handle, fn(ctx.handle, _p(local), cnt, row_bytes, _p(out), _stream_ptr(ctx.device)), "sgpt_allgather_rows")
         return out
 
     def exchange_topk(self, val: torch.Tensor, idx: torch.Tensor, k_out: int,

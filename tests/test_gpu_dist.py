@@ -62,6 +62,12 @@ def test_rccl_sharded_search_equals_local_search(nccl_group):
     assert torch.equal(cv, mv[:, :5]) and torch.equal(ci, mi[:, :5])
     with pytest.raises(ValueError):
         comm.all_gather_rows(q[:3], [nq])                             # the shard plan and the local rows disagree
+    # the RAGGED branch of sgpt_allgather_rows (pad to the largest block, gather into the exchange workspace, compact in
+    # rank order) -- unequal shards take it; a world of one reaches it through the padded entry point
+    assert torch.equal(comm.all_gather_rows(q, [nq], padded=True), q)
+    assert torch.equal(comm.all_gather_rows(i64, [7], padded=True), i64)
+    big = torch.randn(5000, 96, device="cuda")                         # workspace growth inside the padded path
+    assert torch.equal(comm.all_gather_rows(big, [5000], padded=True), big)
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
@@ -167,6 +173,37 @@ def test_bench_distributed_path_on_rccl_world_one():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["shard_check"]["identical_to_single_rank"] is True
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices (runs by default on the first multi-GPU box)")
+def test_two_process_rccl_world():
+    """N = 2 on hardware: `torchrun --nproc-per-node 2 tests/dist_worker.py` -- ragged all-gather, sharded search, exchange --
+    and the bench line with --gpus 2."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), "tests/dist_worker.py"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0 and r.stdout.count("DIST_WORKER_OK") == 2, r.stdout[-2000:] + r.stderr[-3000:]
+    r = _run_bench(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--chunk", "1024", "--nq", "64",
+                    "--no-cpu-baseline", "--no-1m", "--no-varlen"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["shard_check"]["identical_to_single_rank"] is True
+
+
+def test_dist_worker_on_a_world_of_one():
+    """The same worker under torchrun with one rank (this box): every step it takes on N ranks, degenerate collectives."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), "tests/dist_worker.py"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0 and "DIST_WORKER_OK rank=0 world=1" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_bench_gpus_more_than_visible_fails_loudly():

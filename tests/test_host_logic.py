@@ -365,3 +365,33 @@ def test_fp8_gemm_swizzle_is_conflict_free():
     spec.loader.exec_module(mod)
     q8 = mod.check_q8()
     assert q8["rotl3(row&7)"] == 1 and q8["row&7"] == 2
+
+
+def test_one_rccl_per_process_and_it_exports_what_comm_hip_calls():
+    """libsgpt_hip.so is compiled against /opt/rocm's rccl.h and, in a process that imported torch first,
+    binds torch's librccl through the shared soname.  Host-only check of that assumption: exactly one librccl is mapped after
+    both are loaded, it exports every nccl* entry point csrc/comm.hip calls, and its version is the major version of the
+    header the library was compiled against (same collective ABI)."""
+    import ctypes
+    import torch  # noqa: F401  (first: the loader then resolves libsgpt_hip.so's librccl.so.1 to torch's copy)
+    from sgpt_amd import _lib
+    _lib.load()
+    with open("/proc/self/maps") as f:
+        paths = sorted({ln.split()[-1] for ln in f if "librccl" in ln})
+    assert len(paths) == 1, f"more than one RCCL in the process: {paths}"
+    src = open(os.path.join(ROOT, "sgpt_amd", "csrc", "comm.hip")).read()
+    called = sorted(set(re.findall(r"\b(nccl[A-Z][A-Za-z]+)\s*\(", src)))
+    assert {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclGroupStart", "ncclGroupEnd"} <= set(called)
+    rccl = ctypes.CDLL(paths[0])
+    for name in called:
+        assert hasattr(rccl, name), f"{paths[0]} does not export {name}"
+    v = ctypes.c_int(0)
+    assert rccl.ncclGetVersion(ctypes.byref(v)) == 0 and v.value >= 20000
+    hdr = None
+    for cand in ("/opt/rocm/include/rccl/rccl.h", os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include", "rccl", "rccl.h")):
+        if os.path.exists(cand):
+            hdr = open(cand).read()
+            break
+    if hdr is not None:
+        m = re.search(r"#define\s+NCCL_MAJOR\s+(\d+)", hdr)
+        assert m and int(m.group(1)) == v.value // 10000, (m.group(1) if m else None, v.value)
