@@ -442,6 +442,11 @@ sgpt_status sgpt_prof_read(sgpt_ctx* ctx, int64_t* launches, double* ms, double*
  * sgpt_ctx_set_tile_policy: 0 (default) = problems with less than half a wave of 256x256 tiles take the 128x128 / 64x64
  *   register-staged kernel; 1 = keep the 256x256 LDS-DMA kernel wherever the shape allows (kernel-level tests of
  *   single-tile shapes; identical bits either way).  Returns the previous policy. */
+ /* sgpt_ctx_set_gemm_cu_cap: n > 0 = the persistent 256x256 projection kernel launches at most n workgroups (rounded down to
+ *   a multiple of 8; 0 = one per CU, the default) -- for two contexts that run their calls half a block out of phase on two
+ *   streams, so that one pipeline's LayerNorm / attention / embed kernels find free CUs while the other is in its k-loops
+ *   (scripts/dual_stream_probe.py).  Results do not depend on it.  Returns the previous value. */
+int32_t sgpt_ctx_set_gemm_cu_cap(sgpt_ctx* ctx, int32_t n);
 int32_t sgpt_ctx_set_low_latency(sgpt_ctx* ctx, int32_t on);
 int32_t sgpt_ctx_set_tile_policy(sgpt_ctx* ctx, int32_t policy);
 

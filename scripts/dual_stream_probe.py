@@ -3,7 +3,10 @@
 encode call (LayerNorm, attention, embed, pool) hide under the MFMA-bound GEMMs of ANOTHER call?  Two contexts (each with
 its own activation workspace) and two copies of the SGPT-125M weights on one GPU, two HIP streams; the same 1024 x 128
 token calls issued (a) all on one stream, (b) alternating between the two streams.  The persistent 256x256 GEMM occupies
-every CU's LDS, so two GEMMs never co-reside; LayerNorm needs no LDS and may."""
+every CU's LDS, so two GEMMs never co-reside; LayerNorm needs no LDS and may.
+Round 4: CAP=n caps the persistent GEMM grid at n workgroups per launch (Context.set_gemm_cu_cap), so
+that 256 - n CUs stay free for the other pipeline's HBM-bound kernels; CALL=512 halves the call so the two pipelines are
+half a call out of phase."""
 import os
 import sys
 import time
@@ -21,6 +24,9 @@ dev = torch.device("cuda", 0)
 ctxs = [Context(0), Context(0)]
 models = [SGPTModel(cfg, w, device=dev, dtype=os.environ.get("DT", "f16"), ctx=c) for c in ctxs]
 streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+CAP = int(os.environ.get("CAP", 0))
+for c in ctxs:
+    c.set_gemm_cu_cap(CAP)
 CALL = int(os.environ.get("CALL", 1024))
 rng = np.random.default_rng(0)
 ncalls = int(os.environ.get("CALLS", 16))
@@ -44,5 +50,5 @@ for rnd in range(3):
         t = time.perf_counter()
         run(mode)
         dt = time.perf_counter() - t
-        print(f"round {rnd}: {'two streams (alternating calls)' if mode else 'one stream                     '}: "
+        print(f"cap {CAP or 256}: round {rnd}: {'two streams (alternating calls)' if mode else 'one stream                     '}: "
               f"{dt / ncalls * 1e3:.3f} ms per {CALL}-sentence call -> {ncalls * CALL / dt:,.0f} sentences/s", flush=True)

@@ -10,10 +10,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FIXTURE = {"125m": "cfg2_125m_1024x128", "1.3b": "cfg3_neo13b_specb", "2.7b": None, "5.8b": "cfg4_gptj6b", "bloom-7b1": "cfg5_bloom7b1"}
-# (1.3b / 2.7b f16: the model default there is the split-precision Q / K projection; "f16-qk" rows time the plain projection)
-SPECS = ["125m f16", "125m bf16", "125m fp8mfma", "1.3b f16", "1.3b f16-qk", "1.3b bf16", "2.7b f16", "2.7b f16-qk", "5.8b f16", "5.8b bf16", "5.8b fp8mfma",
-         "bloom-7b1 f16", "bloom-7b1 bf16", "bloom-7b1 fp8", "bloom-7b1 fp8mfma"]
+FIXTURE = {"125m": "cfg2_125m_1024x128", "1.3b": "cfg3_neo13b_specb", "2.7b": "cfg_neo27b", "5.8b": "cfg4_gptj6b", "bloom-7b1": "cfg5_bloom7b1"}
+# (1.3b / 2.7b f16: the model default there is the structural precise_qk rule; "f16-qk" rows time the plain projection,
+#  "f16-x3" rows every operand as a hi + lo pair)
+SPECS = ["125m f16", "125m bf16", "125m fp8mfma", "125m f16-x3", "1.3b f16", "1.3b f16-qk", "1.3b f16-x3", "1.3b bf16", "2.7b f16", "2.7b f16-qk",
+         "2.7b f16-x3", "5.8b f16", "5.8b bf16", "5.8b fp8mfma", "bloom-7b1 f16", "bloom-7b1 bf16", "bloom-7b1 fp8", "bloom-7b1 fp8mfma"]
 parity = {}
 for ln in open(sys.argv[1]):
     d = json.loads(ln)
@@ -23,7 +24,9 @@ with open(sys.argv[2], "w") as out:
         model, dtype = spec.split()
         ch = "4096" if model == "125m" else "1024"
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", model, "--dtype", dtype.split("-")[0],
-                            "--precise-qk", "off" if dtype.endswith("-qk") else "auto", "--steps", "3", "--warmup", "1",
+                            "--precise-qk", "off" if dtype.endswith("-qk") else "auto",
+                            "--precision", "x3" if dtype.endswith("-x3") else ("plain" if dtype.endswith("-qk") else "default"),
+                            "--steps", "3", "--warmup", "1",
                             "--chunk", ch, "--no-cpu-baseline", "--no-1m", "--no-varlen"], capture_output=True, text=True, timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if not line:
@@ -37,6 +40,7 @@ with open(sys.argv[2], "w") as out:
                "parity_fixture": fx,
                "parity_max_abs_cos": None if p is None else p["max_abs_cos"],
                "parity_max_abs_normalised_emb": None if p is None else p["max_abs_norm_emb"],
-               "parity_note": None if fx else "no fixture at this size: the 1.3B fixture pins the GPT-Neo family at depth"}
+               "precise_qk": b["config"]["workload"].split("precise_qk=")[1].split(" ")[0].rstrip(",") if "precise_qk=" in b["config"]["workload"] else None,
+               "parity_note": None if p is not None else "no parity-log line for this mode"}
         out.write(json.dumps(row) + "\n")
         print(json.dumps(row))

@@ -93,6 +93,7 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgpt_ctx_set_low_latency": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sgpt_ctx_set_tile_policy": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "sgpt_ctx_set_gemm_cu_cap": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sgpt_model_range_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]),
     "sgpt_model_range_adapt": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "sgpt_model_get_range_shifts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

@@ -127,7 +127,7 @@ struct Prof {  // brackets one GEMM launch with events when profiling is on
 void gemm(sgpt_ctx* c, int dtype, int epi, int out_dtype, const GemmArgs& a0, hipStream_t s) {
     Prof p(c, s, 2.0 * (double)a0.m_valid * a0.N * (a0.k_algo > 0 ? a0.k_algo : a0.K));   // algorithmic FLOPs (split blocks not counted)
     GemmArgs a = a0;
-    a.kgroups = c->kgroups; a.force256 = c->force256;     // per-ctx policies (no process-global state)
+    a.kgroups = c->kgroups; a.force256 = c->force256; a.cu_cap = c->cu_cap;     // per-ctx policies (no process-global state)
     launch_gemm(dtype, epi, out_dtype, a, s);
 }
 
@@ -1242,6 +1242,12 @@ int32_t sgpt_ctx_set_low_latency(sgpt_ctx* c, int32_t on) {
     if (!c) return 0;
     const int old = c->kgroups > 1 ? 1 : 0;
     c->kgroups = on ? 2 : 1;
+    return old;
+}
+int32_t sgpt_ctx_set_gemm_cu_cap(sgpt_ctx* c, int32_t n) {
+    if (!c) return 0;
+    const int old = c->cu_cap;
+    c->cu_cap = n > 0 ? n : 0;
     return old;
 }
 int32_t sgpt_ctx_set_tile_policy(sgpt_ctx* c, int32_t policy) {

@@ -234,6 +234,7 @@ struct GemmArgs {
     int k_algo;         // 0, or the K of the un-split problem when K carries split-precision blocks (profiling counts 2*M*N*k_algo)
     int kgroups;        // per-ctx low-latency mode: 2 = k-groups for under-filled small-tile launches (0 / 1 = off)
     int force256;       // per-ctx tile policy: 1 = keep 256x256 tiles even where the small-tile rule would apply (kernel tests)
+    int cu_cap;         // per-ctx: the persistent 256x256 kernel launches at most this many workgroups (0 = one per CU)
     // Split-precision outputs (16-bit OutT; 0 = off).  Besides out (hi = round16(v)) the epilogue writes lo = round16(v - hi) at
     // element offset lo_delta from the hi element and, when hi2_delta != 0, a second copy of hi at hi2_delta: an activation
     // that enters the next GEMM as a [hi | lo | hi] row of 3 K (lo_delta = K, hi2_delta = 2 K, ldo = 3 K), or q | k / V^T

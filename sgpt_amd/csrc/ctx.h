@@ -21,6 +21,7 @@ struct sgpt_ctx {
     int* range_flag = nullptr;                      // device int: an f16 activation left the representable range (ctx-level ops: sgpt_linear*)
     int kgroups = 1;                                // low-latency mode: 2 = k-groups for query-sized launches (sgpt_ctx_set_low_latency)
     int force256 = 0;                               // tile policy: 1 = 256x256 tiles even for small problems (sgpt_ctx_set_tile_policy)
+    int cu_cap = 0;                                 // persistent 256x256 GEMM: workgroups per launch at most (0 = one per CU; sgpt_ctx_set_gemm_cu_cap)
     // GEMM profiling (bench.py roofline)
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;

@@ -666,7 +666,10 @@ void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
 #endif
     const int gm = b.gm > 0 ? b.gm : 4;
     const int tiles_pad = ((AT + 7) / 8 + gm - 1) / gm * gm * 8 * BT;
-    const int grid = tiles_pad < ncu ? tiles_pad : ncu;
+    // a.cu_cap (per ctx): leave CUs to a second pipeline on another stream (its LayerNorm / attention / embed kernels run on
+    // the free CUs while this launch is in its k-loops); multiples of 8 keep the XCD interleave of the tile order
+    const int cus = (a.cu_cap >= 8 && a.cu_cap < ncu) ? a.cu_cap / 8 * 8 : ncu;
+    const int grid = tiles_pad < cus ? tiles_pad : cus;
 #ifdef SGPT_EXPERIMENTS
     b.skew = tiles_pad >= 4 * grid ? g_skew : 0;       // fewer than ~4 tiles per workgroup: the delay is not amortised
 #else

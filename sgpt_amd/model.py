@@ -449,6 +449,10 @@ class SGPTModel:
         if self.dtype != "fp8mfma":
             raise ValueError("calibrate() applies to dtype='fp8mfma'")
         if seqs is None:
+            import warnings
+            warnings.warn("dtype='fp8mfma': activation scales calibrated on 64 synthetic random-token sequences; pass representative "
+                          "token lists to SGPTModel.calibrate() (a later batch that saturates the e4m3 range raises SgptRangeError)",
+                          stacklevel=2)
             S = min(64, self.cfg.max_position_embeddings)
             seqs = np.random.default_rng(1234).integers(0, self.cfg.vocab_size, size=(64, S), dtype=np.int64)
         lib = self.ctx.lib

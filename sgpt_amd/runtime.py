@@ -156,6 +156,11 @@ class Context:
         16-query encode since round 3 (16 % before), at the price of bit-identical embeddings across batch sizes.  Returns the previous setting."""
         return bool(self.lib.sgpt_ctx_set_low_latency(self.handle, 1 if on else 0))
 
+    def set_gemm_cu_cap(self, n: int) -> int:
+        """Per context: at most n workgroups per launch of the persistent 256x256 projection kernel (0 = one per CU), for two
+        contexts pipelined on two streams (include/sgpt_hip.h::sgpt_ctx_set_gemm_cu_cap).  Returns the previous value."""
+        return int(self.lib.sgpt_ctx_set_gemm_cu_cap(self.handle, int(n)))
+
     def set_tile_policy(self, force_256: bool) -> bool:
         """Per context: keep the 256x256 LDS-DMA GEMM tiles even where the small-tile rule would apply (kernel tests of
         single-tile shapes; identical bits either way).  Returns the previous policy."""

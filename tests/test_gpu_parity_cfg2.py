@@ -21,8 +21,9 @@ from oracle import sgpt_oracle as O
 pytestmark = pytest.mark.gpu
 
 BAR = 1e-3                                   # north_star tolerance
-BUDGET = {"f16": BAR, "f16+qk": BAR, "bf16": 2.5e-3}        # max |cos - cos_ref| allowed per operand format ("+qk": precise_qk)
-TORCH_DT = {"f16": torch.float16, "f16+qk": torch.float16, "bf16": torch.bfloat16}
+# max |cos - cos_ref| allowed per operand format ("+qk": precise_qk; "-x3": every operand as a hi + lo pair, f16 scorer rows)
+BUDGET = {"f16": BAR, "f16+qk": BAR, "bf16": 2.5e-3, "f16-x3": 1e-4}
+TORCH_DT = {"f16": torch.float16, "f16+qk": torch.float16, "bf16": torch.bfloat16, "f16-x3": torch.float16}
 
 
 @pytest.fixture(scope="module")
@@ -30,12 +31,13 @@ def fx():
     return np.load(os.path.join(GOLDEN, "cfg2_125m_1024x128.npz"))
 
 
-@pytest.mark.parametrize("dtype", ["f16", "f16+qk", "bf16"])
+@pytest.mark.parametrize("dtype", ["f16", "f16+qk", "bf16", "f16-x3"])
 def test_cfg2_cosine_and_ranked_top10_vs_reference(fx, dtype):
     from helpers import build_model
     from sgpt_amd import get_context
     ctx = get_context("cuda:0")
-    m = build_model(dict(O.SGPT_125M), 1, 0.02, dtype.split("+")[0], precise_qk=dtype.endswith("+qk"))
+    m = build_model(dict(O.SGPT_125M), 1, 0.02, dtype.split("+")[0].split("-")[0], precise_qk=dtype.endswith("+qk"),
+                    precision="x3" if dtype.endswith("-x3") else "plain")
     m.max_tokens_per_call = 1024 * 128
     docs = fx["doc_ids"].astype(np.int64)                              # [1024, 128]
     qlens = fx["query_lens"].tolist()
@@ -49,7 +51,10 @@ def test_cfg2_cosine_and_ranked_top10_vs_reference(fx, dtype):
     dn, qn = ctx.l2_normalize(d_emb), ctx.l2_normalize(q_emb)
     e_dev = maxabs(dn.cpu().numpy(), O.normalize(ref_d))
     sdt = TORCH_DT[dtype]
-    cos = ctx.scores(ctx._operand(qn, sdt), ctx._operand(dn, sdt), dtype=sdt).cpu().numpy()
+    x3 = dtype.endswith("-x3")              # its scores through split-precision scorer rows too: the whole path at ~fp32 accuracy
+    q_op = ctx.split16(qn, "query", sdt) if x3 else ctx._operand(qn, sdt)
+    d_op = ctx.split16(dn, "doc", sdt) if x3 else ctx._operand(dn, sdt)
+    cos = ctx.scores(q_op, d_op, dtype=sdt).cpu().numpy()
     c_dev = maxabs(cos, fx["cos"])
     print(f"cfg2 {dtype}: max|emb-ref|/||ref|| = {rel:.2e}, normalised max|emb-ref| = {e_dev:.2e}, "
           f"max|cos-ref| = {c_dev:.2e} over {cos.size} pairs")
@@ -63,7 +68,7 @@ def test_cfg2_cosine_and_ranked_top10_vs_reference(fx, dtype):
     # ranked top-10 through the fused scorer: every returned score within the budget of the reference score of that
     # pair; rank-for-rank scores within the budget of the reference's ranked scores; a document outside the reference
     # top-10 may only appear when the reference itself separates it from its 10th hit by less than 2 x budget
-    val, idx, n = ctx.score_topk(ctx._operand(qn, sdt), ctx._operand(dn, sdt), 10, dtype=sdt)
+    val, idx, n = ctx.score_topk(q_op, d_op, 10, dtype=sdt)
     val, idx = val.cpu().numpy(), idx.cpu().numpy()
     ref_cos, ref_top = fx["cos"], fx["top10"]
     ref_sorted = np.take_along_axis(ref_cos, ref_top, 1)

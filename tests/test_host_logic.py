@@ -323,7 +323,10 @@ def _device_asm(name):
     import sys
     from sgpt_amd import build as b
     src = os.path.join(ROOT, "sgpt_amd", "csrc", name)
-    out = subprocess.run([b._hipcc()] + b.FLAGS + ["--cuda-device-only", "-S", src, "-o", "-"], capture_output=True, text=True)
+    if not os.path.exists(src):                                    # (the experiment-build-only re-tiling lives under scripts/micro)
+        src = os.path.join(ROOT, "scripts", "micro", name)
+    out = subprocess.run([b._hipcc()] + b.FLAGS + ["-I", os.path.join(ROOT, "sgpt_amd", "csrc"), "--cuda-device-only", "-S", src, "-o", "-"],
+                         capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     return out.stdout
 
