@@ -116,7 +116,7 @@ def cpu_threads():
     return max(1, min(64, info["physical_cores"] or info["logical_cpus"] or 1))
 
 
-def hf_cpu_baseline(ocfg, ow, sample, repeats=3, mask=None, hf=None):
+def hf_cpu_baseline(ocfg, ow, sample, repeats=3, mask=None, hf=None, slice_note=""):
     """The code the reference itself runs on a CPU: HF GPTNeoModel (fp32, eager attention, eval -- the
     un-vendored dependency behind beir_dense_retriever.py:204-205) + the raw weighted-mean pooling of :258-270 +
     F.normalize, on the host cores over a bounded sample; 1 warm-up + `repeats` timed passes, median."""
@@ -150,7 +150,7 @@ def hf_cpu_baseline(ocfg, ow, sample, repeats=3, mask=None, hf=None):
         times.append(time.perf_counter() - t)
     dt = float(np.median(times))
     return emb.numpy(), {"value": round(len(sample) / dt, 2), "unit": "sentences/s", "cores": threads, "kind": "reference",
-                         "sample": f"{len(sample)} sentences x {ids.shape[1]} tokens: HF GPTNeoModel fp32 eager + raw weighted-mean "
+                         "sample": f"{len(sample)} sentences x {ids.shape[1]} tokens{slice_note}: HF GPTNeoModel fp32 eager + raw weighted-mean "
                                    f"pooling + normalise (the reference's CPU path), torch CPU, median of {repeats} passes "
                                    f"({', '.join(f'{x:.1f}' for x in times)} s)"}, hf
 
@@ -550,7 +550,7 @@ def main():
     # HBM bytes per launch from the committed PMC passes of this same command (profiles/, rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 corrections applied there); null if not collected
     traffic, traffic_source = None, None
-    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if args.dtype in ("bf16", "f16") and args.call * S == 131072 and os.path.exists(tpath):
             with open(tpath) as f:
@@ -597,7 +597,8 @@ def main():
                   "gpu_vs_oracle_max_abs_emb_diff": float(np.abs(got - ce).max()),
                   "gpu_vs_oracle_max_abs_cos_diff": float(np.abs(gcos - ce @ ce.T).max())}
         try:
-            hf_emb, cpu, hf = hf_cpu_baseline(ocfg, ow, sample)
+            hf_emb, cpu, hf = hf_cpu_baseline(ocfg, ow, sample, slice_note=f" (every {stride}th row of SURVEY 8(d)'s 1024 x {S} slice: "
+                                              "three passes over all of it would be minutes of CPU work)")
             parity["gpu_vs_hf_max_abs_emb_diff"] = float(np.abs(got - hf_emb).max())
             parity["gpu_vs_hf_max_abs_cos_diff"] = float(np.abs(gcos - hf_emb @ hf_emb.T).max())
             parity["oracle_vs_hf_max_abs_emb_diff"] = float(np.abs(ce - hf_emb).max())
