@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--no-1m", action="store_true", help="skip the queries/sec @ 1M-doc scoring leg")
     ap.add_argument("--cpu-sample", type=int, default=128, help="sentences in the bounded CPU-baseline sample (a slice of the 1024 x seq probe)")
     ap.add_argument("--no-varlen", action="store_true", help="skip the lengths ~U{16..128} leg")
+    ap.add_argument("--no-modes", action="store_true", help="skip the precision-mode leg (f16x3 and exact-fp32 encode rates beside the headline)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -538,6 +539,29 @@ def main():
                   "end_to_end_frac_of_mfma_roofline": round(v_steps * per_step_flops / vdt / (PEAK_BF16_TFLOPS * 1e12), 4)}
         del vpacked
 
+    # ---- the precision modes beside the headline: every operand as a hi + lo pair of halves ("f16x3": what the probe selects
+    # for an ill-conditioned checkpoint) and the exact-fp32 MFMA mode, the same 1024 x seq encode calls ----
+    modes = None
+    if world == 1 and args.model == "125m" and args.dtype == "f16" and not args.no_modes:
+        modes = {"f16_sentences_per_s": round(sent_per_s, 1)}
+        w2 = synthetic_weights(cfg, seed=1)
+        for tag, kw, calls in (("f16x3", dict(dtype="f16", precision="x3"), 4), ("fp32", dict(dtype="fp32"), 1)):
+            m2 = SGPTModel(cfg, w2, device=dev, max_tokens_per_call=args.call * args.seq, **kw)
+            pbs = [m2.pack(np.random.default_rng(77 + j).integers(0, 50256, size=(args.call, S), dtype=np.int64)) for j in range(calls)]
+            m2.encode_packed(pbs[0], mode="weightedmean", normalize=True, out=emb32[: args.call])
+            sync()
+            t = time.perf_counter()
+            for pb in pbs:
+                m2.encode_packed(pb, mode="weightedmean", normalize=True, out=emb32[: args.call])
+            sync()
+            modes[f"{tag}_sentences_per_s"] = round(calls * args.call / (time.perf_counter() - t), 1)
+            m2.close()
+        del w2
+        torch.cuda.empty_cache()
+        modes["f16x3_over_fp32"] = round(modes["f16x3_sentences_per_s"] / modes["fp32_sentences_per_s"], 2)
+        modes["note"] = ("encode + pool only (no scoring), 1024-sentence calls; f16x3 = SGPTModel(precision='x3'): embeddings within ~1e-5 of "
+                         "the fp32 reference on the engineered-outlier fixtures (tests/test_gpu_parity_large.py), selected by precision='auto'")
+
     if rank != 0:
         if dist_on:
             dist.destroy_process_group()
@@ -668,7 +692,7 @@ def main():
            "queries_per_sec_at_1M_corpus_incl_query_encode": None if qps_1m_enc is None else round(qps_1m_enc, 1),
            "queries_per_sec_at_1M_corpus_incl_query_encode_by_nq": {str(k_): round(v_, 1) for k_, v_ in qps_enc_by_nq.items()},
            "queries_per_sec_at_1M_corpus_incl_query_encode_low_latency_mode": {str(k_): round(v_, 1) for k_, v_ in qps_enc_ll.items()},
-           "queries_per_sec_at_1M_corpus_k1001": k1001, "projected_8gpu": projected,
+           "queries_per_sec_at_1M_corpus_k1001": k1001, "projected_8gpu": projected, "precision_modes": modes,
            "varlen": varlen, "shard_check": shard_check,
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out))

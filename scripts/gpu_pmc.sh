@@ -6,7 +6,7 @@ cd /tmp
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $C | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmc_$tag; mkdir -p $R/gpurun_out/pmc_$tag
-  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_$tag -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-1m --no-varlen > $R/gpurun_out/pmc_$tag.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_$tag -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-1m --no-varlen --no-modes > $R/gpurun_out/pmc_$tag.log 2>&1
   echo "$tag rc=$?"
 done
 cd $R

@@ -27,7 +27,7 @@ with open(sys.argv[2], "w") as out:
                             "--precise-qk", "off" if dtype.endswith("-qk") else "auto",
                             "--precision", "x3" if dtype.endswith("-x3") else ("plain" if dtype.endswith("-qk") else "default"),
                             "--steps", "3", "--warmup", "1",
-                            "--chunk", ch, "--no-cpu-baseline", "--no-1m", "--no-varlen"], capture_output=True, text=True, timeout=900)
+                            "--chunk", ch, "--no-cpu-baseline", "--no-1m", "--no-varlen", "--no-modes"], capture_output=True, text=True, timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if not line:
             print(spec, "FAILED", r.stderr[-300:])

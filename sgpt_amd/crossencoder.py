@@ -50,6 +50,7 @@ def loglikelihood_tokens(requests, model: SGPTModel, max_length: int, instructio
     order = np.argsort([-len(x) for x in inps], kind="stable")        # longest first, as the reference's Reorderer
     # under the model's range guard: an f16 activation class that overflows gets its power-of-two shift raised and the
     # requests are scored again (otherwise inf / NaN log-probabilities would come back silently)
+    model.ensure_precision_plan(inps)           # precision='auto': probe the checkpoint on the first requests
     return model.guarded(lambda: _score_batches(inps, spans, order, model, max_tokens_per_call))
 
 

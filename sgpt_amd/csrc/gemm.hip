@@ -836,19 +836,19 @@ __global__ __launch_bounds__(512, 2) void score64_kernel(const GemmArgs p) {
             if (staged > 0) {
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const int ne = staged < 256 ? staged : 256;
-                for (int e = lane; e < ne; e += 64) {
-                    const uint2 ent = stage[e];
-                    const int m = (int)(ent.x >> 16);
-                    if (cand_room(p.cand_cnt + m, p.cand_cap)) {
+                if (staged <= 256) {                                       // one global round trip per flush (see gemm256_epilogue.inc)
+                    for (int e = lane; e < staged; e += 64) {
+                        const uint2 ent = stage[e];
+                        const int m = (int)(ent.x >> 16);
                         const int slot = atomicAdd(p.cand_cnt + m, 1);
                         if (slot < p.cand_cap) {
                             p.cand_val[(long)m * p.cand_cap + slot] = __uint_as_float(ent.y);
                             p.cand_idx[(long)m * p.cand_cap + slot] = p.idx_base + n0 + (int)(ent.x & 0xffffu);
                         }
                     }
+                } else if (lane == 0) {
+                    atomicAdd(p.cand_cnt + (int)(stage[0].x >> 16), p.cand_cap + 1);   // more than the scratch holds: force the fallback
                 }
-                if (staged > 256 && lane == 0) atomicAdd(p.cand_cnt + (int)(stage[0].x >> 16), p.cand_cap + 1);   // force the fallback
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }

@@ -422,6 +422,8 @@ __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __r
     const float* cv = s_val;
     const int64_t* ci = s_idx;
     int ccnt = cnt;
+    // (every thread ranking its own candidate against all of them -- cnt LDS reads each, all threads in parallel -- was measured
+    // too: 72.8 us per launch against 17.8 for the arg-max rounds at ~180 candidates, profiles/r04_shard_profile.txt)
     if (k <= TK_FAST_KMAX && cnt > 2 * k) {
         float* tv_ = r_val + TK_MERGE_KMAX / 2;          // (k <= 64: the upper half of the running-list arrays is free)
         int64_t* ti_ = r_idx + TK_MERGE_KMAX / 2;

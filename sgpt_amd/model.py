@@ -417,6 +417,13 @@ class SGPTModel:
         self.guarded(once)          # (an f16 range overflow inside the probe forward: shifts raised, probed again)
         return np.array(list(out), dtype=np.float32).reshape(self.cfg.num_layers, 4)
 
+    def ensure_precision_plan(self, seqs, pad_left=None) -> None:
+        """precision 'auto' / 'auto-class': run the probe on `seqs` if it has not run yet (every host entry point that takes
+        token lists calls this first: encode_ids, token_embeddings, the cross-encoder, EncodeGraph; a caller that only ever
+        uses pack() + encode_packed() calls it itself, or pins a plan with set_precision_plan())."""
+        if self._plan_pending:
+            self._auto_precision(seqs, pad_left)
+
     def _auto_precision(self, seqs, pad_left) -> None:
         """precision 'auto' / 'auto-class', first encode call: probe, decide, install."""
         self._plan_pending = False
@@ -599,9 +606,15 @@ class SGPTModel:
         contiguous slices bounded by a token budget instead of a padded [B,S] rectangle."""
         order = np.argsort(-lens, kind="stable")
         alloc = (lens[order] + ALIGN - 1) // ALIGN * ALIGN
+        # EQUAL token budgets: filling every call to max_tokens_per_call leaves a short last call (294 k token rows = 131 k +
+        # 131 k + 32 k), and a mid-size call runs the projections at ~0.6 of the bulk rate (a lone round of 256x256 tiles, DESIGN 3);
+        # three calls of 98 k rows lose ~3 % each instead.  The budget stays a multiple of the GEMM's token tile.
+        total = int(alloc.sum())
+        n_calls = max(1, -(-total // self.max_tokens_per_call))
+        budget = min(self.max_tokens_per_call, (-(-total // n_calls) + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE + int(alloc.max()))
         out, start, tok = [], 0, 0
         for i, a in enumerate(alloc):
-            full = tok + a > self.max_tokens_per_call or (max_sentences and i - start >= max_sentences)
+            full = tok + a > budget or (max_sentences and i - start >= max_sentences)
             if full and i > start:
                 out.append(order[start:i])
                 start, tok = i, 0
@@ -727,6 +740,8 @@ class SGPTModel:
         lens = np.fromiter(map(len, seqs), dtype=np.int64, count=n)
         if n == 0 or (lens <= 0).any():
             raise ValueError("Empty items should be cleaned prior to running")
+        self.ensure_precision_plan(seqs, pad_left)
+
         def once():
             out: List[Optional[torch.Tensor]] = [None] * n
             for sel in self.plan_batches(lens):
@@ -756,6 +771,7 @@ class EncodeGraph:
                  normalize: bool = False, layer_idx: int = -1, pad_left: Optional[Sequence[int]] = None,
                  bucket: Optional[Tuple[int, int, int]] = None):
         self.model, self.mode, self.normalize, self.layer_idx = model, mode, normalize, layer_idx
+        model.ensure_precision_plan(seqs, pad_left)        # (a later plan change would only force a re-capture)
         self.capacity = bucket               # None: exact layouts only; else batches are padded to this capacity
         self.pb = model.pack(seqs, pad_left, bucket)
         self.out = torch.empty((self.pb.B, model.cfg.hidden_size), dtype=torch.float32, device=model.device)
@@ -780,7 +796,10 @@ class EncodeGraph:
     def replay(self, seqs: Optional[Sequence[Sequence[int]]] = None,
                pad_left: Optional[Sequence[int]] = None, check_range: bool = True) -> torch.Tensor:
         """Re-run on new sentences whose packed layout falls in the same bucket (None: same inputs again).
-        The returned tensor is the graph's static output buffer (rows past `pb.n_real` belong to bucket fillers)."""
+        The returned tensor is the graph's static output buffer (rows past `pb.n_real` belong to bucket fillers).
+        check_range=True (default: never silent) reads the model's 4-byte guard word back after the replay -- one stream
+        synchronisation per call; a latency path that needs replay() to stay ASYNCHRONOUS passes check_range=False and owes a
+        `model.check_range()` before trusting the rows (dtype 'f16' / 'fp8mfma'; other dtypes never synchronise here)."""
         if seqs is not None:
             try:
                 self.model.pack(seqs, pad_left, self.capacity, into=self.pb)   # one pinned copy into the captured arena

@@ -168,7 +168,7 @@ def test_bench_distributed_path_on_rccl_world_one():
     s.close()
     r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                     "--master-port", str(port), "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--chunk", "1024",
-                    "--nq", "64", "--no-cpu-baseline", "--no-1m", "--no-varlen"], {"SGPT_BENCH_FORCE_DIST": "1"})
+                    "--nq", "64", "--no-cpu-baseline", "--no-1m", "--no-varlen", "--no-modes"], {"SGPT_BENCH_FORCE_DIST": "1"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
@@ -189,7 +189,7 @@ def test_two_process_rccl_world():
                     "--master-port", str(port), "tests/dist_worker.py"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert r.returncode == 0 and r.stdout.count("DIST_WORKER_OK") == 2, r.stdout[-2000:] + r.stderr[-3000:]
     r = _run_bench(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--chunk", "1024", "--nq", "64",
-                    "--no-cpu-baseline", "--no-1m", "--no-varlen"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                    "--no-cpu-baseline", "--no-1m", "--no-varlen", "--no-modes"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["shard_check"]["identical_to_single_rank"] is True
