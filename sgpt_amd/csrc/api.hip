@@ -1029,9 +1029,18 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     float* th_v = sampled ? (float*)take(tv_bytes) : nullptr;
     int64_t* th_i = sampled ? (int64_t*)take(ti_bytes) : nullptr;
     float* thr_dense = sampled ? (float*)take(align_up((size_t)nq * 4, 256)) : nullptr;
-    if (fast) {
-        if (nq_pad > nq) HIPC(c, hipMemsetAsync((char*)qpad + (size_t)nq * d * 2, 0, (size_t)(nq_pad - nq) * d * 2, s));   // the pad rows only
-        HIPC(c, hipMemcpyAsync(qpad, q, (size_t)nq * d * 2, hipMemcpyDeviceToDevice, s));
+    // prologue: one launch (query rows into their zero-padded tile, counters and flags cleared, an empty running list marked)
+    const bool fresh_list = sampled && n_run == 0;
+    if (fast && d % 8 == 0 && ((size_t)q & 15) == 0) {
+        launch_score_prep(q, qpad, (long)nq * d * 2, (long)nq_pad * d * 2, filt ? cand_cnt : nullptr, filt ? (long)(nq_pad + n_flags) : 0,
+                          fresh_list ? (long long*)ti[0] : nullptr, fresh_list ? (long)nq * k : 0, s);
+    } else {
+        if (fast) {
+            if (nq_pad > nq) HIPC(c, hipMemsetAsync((char*)qpad + (size_t)nq * d * 2, 0, (size_t)(nq_pad - nq) * d * 2, s));   // the pad rows only
+            HIPC(c, hipMemcpyAsync(qpad, q, (size_t)nq * d * 2, hipMemcpyDeviceToDevice, s));
+        }
+        if (filt) HIPC(c, hipMemsetAsync(cand_cnt, 0, (size_t)(nq_pad + n_flags) * 4, s));
+        if (fresh_list) HIPC(c, hipMemsetAsync(ti[0], 0xff, (size_t)nq * k * 8, s));
     }
     const size_t esz = dtype == SGPT_F32 ? 4 : 2;
 
@@ -1098,7 +1107,6 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         st = classic(0, N, pv0, pi0, n_run, run_val, run_idx, nullptr, chunk);
         if (st != SGPT_OK) return st;
     } else {
-        HIPC(c, hipMemsetAsync(cand_cnt, 0, (size_t)(nq_pad + n_flags) * 4, s));
         static const bool no_fallback = exp_env("SGPT_SCORE_NOFALLBACK") != nullptr;   // timing experiments ONLY: unsafe
         int cur = 0, chunk_i = 0;
         long seen = 0;                 // documents behind which the filtered chunks continue
@@ -1108,9 +1116,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             // running best going in: tv[0] / ti[0] = the caller's list padded to k columns, or empty (idx -1 everywhere)
             if (n_run > 0) {
                 launch_topk_select(run_val, k, 0, 0, run_val, run_idx, n_run, k, nq, k, 0, nullptr, tv[0], ti[0], s);
-            } else {
-                HIPC(c, hipMemsetAsync(ti[0], 0xff, (size_t)nq * k * 8, s));     // idx -1: an empty slot whatever its value says
-            }
+            }   // (n_run == 0: the prologue marked tv[0] / ti[0] empty -- idx -1, whatever the values say)
             // thresholds: the k-th best of {running best} U {S documents at stride s_stride across the shard}; only the VALUES
             // of this selection are used (its indices are sample positions) -- the filtered chunks below re-score the sampled
             // documents like any other and find them again

@@ -344,6 +344,9 @@ void launch_topk_select(const float* scores, long ld, long n, long idx_base, con
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
                         const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s,
                         const int* pred = nullptr);
+// scorer pass prologue in one launch: q -> zero-padded qpad (byte counts, multiples of 16), counters[n] = 0, idx_list[n] = -1
+void launch_score_prep(const void* q, void* qpad, long q_bytes, long qpad_bytes, int* counters, long n_counters, long long* idx_list,
+                       long n_idx, hipStream_t s);
 // thr[q] = nextafter(list[q][k-1], -inf): the inclusive form of a sampled threshold for the strict `>` filter (topk.hip)
 void launch_thr_below(const float* list, int k, int nq, float* thr, hipStream_t s);
 // k best of {running top-k} U {candidate list of the filtered score GEMM}; resets cnt[q], raises *overflow when a
