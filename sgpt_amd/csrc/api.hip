@@ -952,9 +952,10 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // long lists (1 M documents, k = 11: 2048 entries -> a 15 k-document sample instead of 60 k); short shards keep short
     // ones, because the expected survivors per row and 256-document tile, cap / (2.8 N / 256), is what the filtered GEMM's
     // append path pays for (0.37 at 125 k documents with 512 entries: 236 us per launch against ~190 without appends)
-    // (nq <= 64: the 64-row scorer tile is HBM-bound -- ~1 us per tile -- and an append flush costs it a global round trip, so
-    // short query batches keep the survivors rare: 512 entries, a sample of N / 16)
-    const int cap_n = nq <= 64 ? 512 : (N >= 800000 ? 2048 : (N >= 400000 ? 1024 : 512));
+    // nq <= 64 (the HBM-bound 64-row tile): same-box A/B of 512 / 1024 / 2048 entries at 1 M documents (profiles/r04_cap64_ab.txt):
+    // nq = 16 0.39 / 0.36 / 0.365 ms, nq = 64 0.41 / 0.375 / 0.39 ms -- the sample is 6 % / 3 % / 1.5 % of the corpus stream, and
+    // past 1024 entries the appends cost the streaming tile more than the smaller sample returns
+    const int cap_n = nq <= 64 ? (N >= 400000 ? 1024 : 512) : (N >= 800000 ? 2048 : (N >= 400000 ? 1024 : 512));
     const int cap_s = cap_n * (k <= 32 ? 1 : 2) > 2048 ? 2048 : cap_n * (k <= 32 ? 1 : 2);
     const int cap = sampled_k ? cap_s : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
     const bool half_growth = 2 * cap < 5 * k;          // k > ~340: cap < 2.5 k -> grow by half, expect ~k/2 per chunk
