@@ -1141,7 +1141,11 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             if (sampled) len = (long)((double)eff * ratio) / 256 * 256;
             else len = half_growth ? (eff / 2 / 256 * 256 > 256 ? eff / 2 / 256 * 256 : 256) : eff * growth;
             if (len < 256) len = 256;
-            if (len > (1L << 19)) len = 1L << 19;
+            // chunks of at most 2^19 documents: a merge half-way through a 1 M-document pass tightens the thresholds of the
+            // second half (nq = 1000: 380 + 10 appended candidates per query instead of 730; measured 1.62-1.64 against
+            // 1.65-1.69 ms, nq = 128 0.51 against 0.54).  Short query batches (the HBM-bound 64-row tile) take the whole shard
+            // in ONE launch instead: a merge, three no-op fallback launches and a pipeline ramp less (nq = 16: 0.36 -> 0.35 ms)
+            if (len > (1L << 19) && !(sampled && nq <= 64)) len = 1L << 19;
             if (len >= n256 - seen) len = n256 - seen;          // the last chunk takes what is left (no whole-wave rounding: that
             else if (len >= unit) len = len / unit * unit;      //  left a 17 k-document sixth launch behind 1 M documents at nq = 16)
             GemmArgs g{};
