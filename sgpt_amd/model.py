@@ -359,6 +359,9 @@ class SGPTModel:
                 base = self._x3_plan()
             if base.any():
                 self.set_precision_plan(base, _keep_pending=True)
+            if self._plan_pending:
+                S = min(64, cfg.max_position_embeddings)
+                self._auto_precision(np.random.default_rng(4321).integers(0, cfg.vocab_size, size=(64, S), dtype=np.int64), None, final=False)
 
     # ---- precision plan (split-precision operand classes per block) ----
     def _base_plan(self) -> np.ndarray:
@@ -424,9 +427,13 @@ class SGPTModel:
         if self._plan_pending:
             self._auto_precision(seqs, pad_left)
 
-    def _auto_precision(self, seqs, pad_left) -> None:
-        """precision 'auto' / 'auto-class', first encode call: probe, decide, install."""
-        self._plan_pending = False
+    def _auto_precision(self, seqs, pad_left, final: bool = True) -> None:
+        """precision 'auto' / 'auto-class': probe, decide, install.  Runs twice at most: at load on 64 synthetic random-token
+        sequences (outlier channels are a property of the checkpoint -- in real GPT-2 / GPT-Neo checkpoints the massive
+        activations sit on the first position and on delimiter tokens, which any sequence has) and, if that found nothing, on
+        the first real encode call (final=True: the plan is the caller's data's from then on)."""
+        if final:
+            self._plan_pending = False
         crest = self.probe_precision(seqs, pad_left)
         lim = np.array([CREST_LIMIT_LN, CREST_LIMIT_LN, CREST_LIMIT_LN, CREST_LIMIT_H], dtype=np.float32)
         hot = crest > lim[None, :]                        # [L, 4]: LN1, CTX, LN2, H
@@ -443,8 +450,8 @@ class SGPTModel:
                 plan[hot[:, 3], PC_H] = 1
                 if self.cfg.model_type == "gptj":
                     plan[:, PC_LN2] = (plan[:, PC_LN1] != 0).astype(np.int32)
-            self.set_precision_plan(plan)
-        self.precision_report = dict(crest=crest, limits=lim.tolist(), flagged=int(hot.sum()),
+            self.set_precision_plan(plan)          # (ends the probing: an ill-conditioned checkpoint stays escalated)
+        self.precision_report = dict(crest=crest, limits=lim.tolist(), flagged=int(hot.sum()), probed="first call" if final else "load (synthetic)",
                                      decided="x3" if (hot.any() and self.precision == "auto") else ("classes" if hot.any() else "plain"))
 
     def calibrate(self, seqs: Optional[Sequence[Sequence[int]]] = None, margin: float = 2.0) -> np.ndarray:
