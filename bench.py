@@ -618,6 +618,8 @@ def main():
                 "sample": f"{len(sample)} sentences x {S} tokens, numpy fp32 oracle (oracle/sgpt_oracle.py), "
                           f"encode+pool+normalise, {cdt:.1f}s"}
         parity = {"checked_rows": len(sample), "gpu_call_sentences": 1024, "gpu_dtype": args.dtype,
+                  "note": "embeddings = L2-NORMALISED rows (what cosine retrieval consumes; raw pooled rows are O(1-3) and deviate by the same "
+                          "figure relative to their norm)",
                   "gpu_vs_oracle_max_abs_emb_diff": float(np.abs(got - ce).max()),
                   "gpu_vs_oracle_max_abs_cos_diff": float(np.abs(gcos - ce @ ce.T).max())}
         try:

@@ -460,3 +460,48 @@ def test_score_topk_short_query_batches_use_the_64_row_tile_exactly(ctx, nq, dt1
     v1, i1, n1 = ctx.score_topk(q[:nq].contiguous(), c[:70_000].contiguous(), k, idx_base=3, dtype=dt16)
     v2, i2, n2 = ctx.score_topk(q[:nq].contiguous(), c[70_000:].contiguous(), k, idx_base=70_003, run=(v1, i1, n1), dtype=dt16)
     assert torch.equal(v2, val) and torch.equal(i2, idx)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_score_topk_sampled_schedule_random_shapes(ctx, seed):
+    """Round 4's scorer schedule (strided-sample thresholds, list-sized chunks, LDS-staged appends, arg-max merges, one-launch
+    prologue) against the materialise-and-select loop on random shapes: query counts on both sides of the 64-row / 256-row tile
+    switch, corpus lengths around the chunk boundaries with ragged tails, k from 1 to 64 (sampled) and beyond (doubling),
+    an index base, an incoming running list, anisotropic / duplicated / drifting / plain data.  Bit-for-bit."""
+    rng = np.random.default_rng(1000 + seed)
+    nq = int(rng.choice([1, 17, 64, 65, 200, 1000, 2048]))
+    k = int(rng.choice([1, 5, 11, 33, 64, 65, 101]))
+    d = int(rng.choice([128, 192, 768]))
+    chunk = 131072 if nq <= 64 else max(256, min(131072, (160 << 20) // (nq * 4) // 256 * 256))
+    N = int(2 * chunk + rng.integers(0, 3 * chunk)) + int(rng.choice([0, 1, 72, 255]))      # long enough for the filtered path
+    if nq > 1000 or d == 768:
+        N = min(N, 400_000 if nq <= 64 else 150_000)
+        N = max(N, 2 * chunk + 300)
+    kind = str(rng.choice(["plain", "aniso", "dup", "drift"]))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    base = torch.randn(1, d, device="cuda", generator=g) * (3.0 if kind != "plain" else 0.0)
+    c = base + torch.randn(N, d, device="cuda", generator=g)
+    if kind == "dup":
+        blk = 16384
+        for s0 in range(blk, N, blk):
+            e0 = min(N, s0 + blk)
+            c[s0:e0] = c[: e0 - s0] + 0.02 * torch.randn(e0 - s0, d, device="cuda", generator=g)
+    if kind == "drift":
+        c[int(0.7 * N):] += 2.0 * base
+    q = torch.nn.functional.normalize(base + torch.randn(nq, d, device="cuda", generator=g), dim=1)
+    dt = torch.float16 if seed % 2 == 0 else torch.bfloat16
+    c = torch.nn.functional.normalize(c, dim=1).to(dt)
+    q = q.to(dt)
+    idx_base = int(rng.choice([0, 123_456_789]))
+    run = None
+    if seed % 3 == 0:                                           # an incoming running best from earlier documents
+        prev = torch.nn.functional.normalize(base + torch.randn(3000, d, device="cuda", generator=g), dim=1).to(dt)
+        v0, i0, n0 = ctx.score_topk(q, prev, k, idx_base=7)
+        run = (v0.clone(), i0.clone(), n0)
+        val, idx, n = ctx.score_topk(q, c, k, idx_base=idx_base + 10_000, run=(v0, i0, n0))
+        wv, wi, wn = _sliced_classic(ctx, q, c, k, chunk, idx_base=idx_base + 10_000, run=run)
+    else:
+        val, idx, n = ctx.score_topk(q, c, k, idx_base=idx_base)
+        wv, wi, wn = _sliced_classic(ctx, q, c, k, chunk, idx_base=idx_base)
+    assert n == wn == k, (nq, N, k, d, kind)
+    assert torch.equal(val, wv) and torch.equal(idx, wi), (nq, N, k, d, kind, str(dt))
