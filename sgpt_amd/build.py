@@ -80,12 +80,10 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        # librccl: the exchange steps of the multi-GPU search (comm.hip).  torch ships its own copy under the same soname
-        # (librccl.so.1): in a process that imported torch first, the loader resolves to that one -- a single RCCL per process.
-        # (A process that loads this library BEFORE torch would bind ROCm's copy and torch then its own: import torch first,
-        # as sgpt_amd/runtime.py does.)
-        rl = _rocm_libdir(hipcc)
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [f"-L{rl}", "-lrccl", f"-Wl,-rpath,{rl}"])
+        # No -lrccl: comm.hip binds RCCL lazily (dlopen, preferring the copy already in the process -- torch ships its own
+        # librccl.so.1 -- and checking its NCCL major version against the header it was compiled with).  A single-GPU user
+        # needs no RCCL to build or load the library; rccl.h (types only) comes from the ROCm include directory.
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -6,11 +6,17 @@
 // ncclAllGather moves the rows; the top-k exchange of the corpus-sharded search gathers the per-rank
 // [nq, k] (score, index) lists and folds them with the library's own merge kernel on the same stream.
 //
-// Linked against librccl (rccl.h is the NCCL API).  torch.distributed is only the bootstrap that carries the 128-byte
-// unique id from rank 0 to the other ranks (sgpt_amd/dist.py).
+// RCCL is bound LAZILY (round 4; rccl.h supplies the types only, the library is not linked against librccl): the first
+// communicator call dlopens it, preferring the copy that is already in the process -- torch ships its own librccl.so.1, and a
+// process must never hold two -- and checks that its NCCL major version is the one of the header this file was compiled
+// against.  A single-GPU user needs no RCCL to build or load libsgpt_hip.so, and the order of `import torch` and the dlopen of
+// this library no longer decides which RCCL the collectives run on.  torch.distributed is only the bootstrap that carries the
+// 128-byte unique id from rank 0 to the other ranks (sgpt_amd/dist.py).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,6 +28,48 @@
 static_assert(SGPT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique-id size");
 
 namespace {
+
+// The seven RCCL entry points this file calls, resolved once per process (an immutable table after the first use).
+struct Rccl {
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;          // empty: usable
+    std::string path;
+};
+
+const Rccl& rccl() {
+    static const Rccl table = [] {
+        Rccl r;
+        void* h = nullptr;
+        std::vector<std::string> names = {"librccl.so.1", "librccl.so"};
+        for (const auto& n : names) if (!h) h = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD);        // the copy already in the process
+        if (const char* rp = getenv("ROCM_PATH")) { names.push_back(std::string(rp) + "/lib/librccl.so.1"); }
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (const auto& n : names) if (!h) h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { r.err = std::string("librccl.so.1 not found (") + (dlerror() ? dlerror() : "") + "): the multi-GPU exchange steps need RCCL"; return r; }
+#define SGPT_SYM(field, name)                                                                   \
+        r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, #name));                            \
+        if (!r.field && r.err.empty()) r.err = std::string("librccl does not export ") + #name;
+        SGPT_SYM(GetVersion, ncclGetVersion) SGPT_SYM(GetUniqueId, ncclGetUniqueId) SGPT_SYM(CommInitRank, ncclCommInitRank)
+        SGPT_SYM(CommDestroy, ncclCommDestroy) SGPT_SYM(AllGather, ncclAllGather) SGPT_SYM(GroupStart, ncclGroupStart)
+        SGPT_SYM(GroupEnd, ncclGroupEnd) SGPT_SYM(GetErrorString, ncclGetErrorString)
+#undef SGPT_SYM
+        Dl_info info;
+        if (r.GetVersion && dladdr(reinterpret_cast<void*>(r.GetVersion), &info) && info.dli_fname) r.path = info.dli_fname;
+        int v = 0;
+        if (r.err.empty() && (r.GetVersion(&v) != ncclSuccess || v / 10000 != NCCL_MAJOR))
+            r.err = "librccl at " + r.path + " reports NCCL version " + std::to_string(v) + ", this library was compiled against major " +
+                    std::to_string(NCCL_MAJOR);
+        return r;
+    }();
+    return table;
+}
 
 #define HIPC(ctx, call)                                                                       \
     do {                                                                                      \
@@ -35,7 +83,7 @@ namespace {
     do {                                                                                      \
         ncclResult_t r_ = (call);                                                             \
         if (r_ != ncclSuccess) {                                                              \
-            (ctx)->err = std::string(#call) + ": " + ncclGetErrorString(r_);                  \
+            (ctx)->err = std::string(#call) + ": " + rccl().GetErrorString(r_);               \
             return SGPT_ERR_COMM;                                                             \
         }                                                                                     \
     } while (0)
@@ -73,8 +121,9 @@ extern "C" {
 
 sgpt_status sgpt_comm_unique_id(uint8_t* id) {
     if (!id) return SGPT_ERR_INVALID;
+    if (!rccl().err.empty()) return SGPT_ERR_COMM;
     ncclUniqueId u;
-    if (ncclGetUniqueId(&u) != ncclSuccess) return SGPT_ERR_COMM;
+    if (rccl().GetUniqueId(&u) != ncclSuccess) return SGPT_ERR_COMM;
     memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
     return SGPT_OK;
 }
@@ -83,11 +132,12 @@ sgpt_status sgpt_comm_init(sgpt_ctx* c, const uint8_t* id, int32_t rank, int32_t
     if (!c) return SGPT_ERR_INVALID;
     if (!id || world <= 0 || rank < 0 || rank >= world) return cfail(c, SGPT_ERR_INVALID, "sgpt_comm_init: bad rank / world");
     if (c->comm) return cfail(c, SGPT_ERR_INVALID, "sgpt_comm_init: this ctx already has a communicator (sgpt_comm_destroy first)");
+    if (!rccl().err.empty()) { c->err = rccl().err; return SGPT_ERR_COMM; }
     HIPC(c, hipSetDevice(c->device));
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t comm = nullptr;
-    NCCLC(c, ncclCommInitRank(&comm, world, u, rank));
+    NCCLC(c, rccl().CommInitRank(&comm, world, u, rank));
     c->comm = comm;
     c->comm_rank = rank;
     c->comm_world = world;
@@ -99,7 +149,7 @@ sgpt_status sgpt_comm_destroy(sgpt_ctx* c) {
     if (c->comm) {
         (void)hipSetDevice(c->device);
         (void)hipDeviceSynchronize();
-        (void)ncclCommDestroy((ncclComm_t)c->comm);
+        (void)rccl().CommDestroy((ncclComm_t)c->comm);
         c->comm = nullptr;
         c->comm_world = 0;
         c->comm_rank = 0;
@@ -130,7 +180,7 @@ static sgpt_status allgather_rows_impl(sgpt_ctx* c, const void* local, const int
     hipStream_t s = (hipStream_t)stream;
     const size_t blk = (size_t)mx * row_bytes;
     if (equal && !force_padded) {            // the common case (shard sizes differ by at most one row only when n % world != 0)
-        NCCLC(c, ncclAllGather(local, out, blk, ncclInt8, (ncclComm_t)c->comm, s));
+        NCCLC(c, rccl().AllGather(local, out, blk, ncclInt8, (ncclComm_t)c->comm, s));
         return SGPT_OK;
     }
     // ragged: pad this rank's block to the largest one, gather into the exchange workspace, compact in rank order
@@ -141,7 +191,7 @@ static sgpt_status allgather_rows_impl(sgpt_ctx* c, const void* local, const int
     const size_t mine = (size_t)counts[rank] * row_bytes;
     if (mine) HIPC(c, hipMemcpyAsync(send, local, mine, hipMemcpyDeviceToDevice, s));
     if (mine < blk) HIPC(c, hipMemsetAsync(send + mine, 0, blk - mine, s));
-    NCCLC(c, ncclAllGather(send, recv, blk, ncclInt8, (ncclComm_t)c->comm, s));
+    NCCLC(c, rccl().AllGather(send, recv, blk, ncclInt8, (ncclComm_t)c->comm, s));
     size_t o = 0;
     for (int r = 0; r < world; ++r) {
         const size_t b = (size_t)counts[r] * row_bytes;
@@ -218,10 +268,10 @@ sgpt_status sgpt_exchange_topk(sgpt_ctx* c, const float* val, const int64_t* idx
     long long* gi = (long long*)(base + vb);
     float* rv = (float*)(base + vb + ib);
     long long* ri = (long long*)(base + 2 * vb + ib);
-    NCCLC(c, ncclGroupStart());
-    ncclResult_t r1 = ncclAllGather(val, gv, n1, ncclFloat32, (ncclComm_t)c->comm, s);
-    ncclResult_t r2 = ncclAllGather(idx, gi, n1, ncclInt64, (ncclComm_t)c->comm, s);
-    NCCLC(c, ncclGroupEnd());
+    NCCLC(c, rccl().GroupStart());
+    ncclResult_t r1 = rccl().AllGather(val, gv, n1, ncclFloat32, (ncclComm_t)c->comm, s);
+    ncclResult_t r2 = rccl().AllGather(idx, gi, n1, ncclInt64, (ncclComm_t)c->comm, s);
+    NCCLC(c, rccl().GroupEnd());
     NCCLC(c, r1);
     NCCLC(c, r2);
     return fold_gathered(c, gv, gi, world, nq, k, k_out, exclude_idx, out_val, out_idx, rv, ri, s);
