@@ -126,7 +126,7 @@ def test_f16_range_shifts_cover_outliers_and_the_guard_stays_loud():
     seqs = [[1, 2, 3, 4, 5], [7] * 40]
     w = dict(base); w["h.1.attn.attention.q_proj.weight"] = base["h.1.attn.attention.q_proj.weight"] * 0 + 1e5
     with pytest.raises(SgptRangeError):
-        SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
+        SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16", precision="plain")
 
     def rel(m, wts):
         want = O.encode(wts, cfg, seqs, mode="weightedmean", batch_size=len(seqs))
@@ -135,14 +135,14 @@ def test_f16_range_shifts_cover_outliers_and_the_guard_stays_loud():
         return float(np.abs(got - want).max() / np.abs(want).max())
     # (1) LayerNorm gamma 4000: 4000 * sqrt(128) > 32768 -> load-time shift on the LayerNorm outputs of every block
     w = dict(base); w["h.0.ln_2.weight"] = base["h.0.ln_2.weight"] * 0 + 4000.0
-    m = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
+    m = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16", precision="plain")
     sh = m.range_shifts()
     assert (sh[:, 0] > 0).all() and (sh[:, 2] > 0).all() and (sh[:, [1, 3]] == 0).all()
     e1 = rel(m, w)
     m.close()
     # (2) an fc bias of 5e4 drives the GELU output past the format at run time: adapt + re-run inside encode_ids
     w = dict(base); w["h.1.mlp.c_fc.bias"] = base["h.1.mlp.c_fc.bias"] * 0 + 5e4
-    m = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16")
+    m = SGPTModel(SGPTConfig(**kw), w, device="cuda:0", dtype="f16", precision="plain")
     assert (m.range_shifts() == 0).all()
     e2 = rel(m, w)
     sh = m.range_shifts()
@@ -160,7 +160,7 @@ def test_f16_range_shifts_cover_outliers_and_the_guard_stays_loud():
     m.close()
     print(f"f16 range shifts: LayerNorm-gamma case rel err {e1:.2e}, GELU-overflow case rel err {e2:.2e}")
     assert e1 < 5e-3 and e2 < 5e-3
-    ok = SGPTModel(SGPTConfig(**kw), base, device="cuda:0", dtype="f16")
+    ok = SGPTModel(SGPTConfig(**kw), base, device="cuda:0", dtype="f16", precision="plain")
     assert torch.isfinite(ok.encode_ids(seqs)).all() and (ok.range_shifts() == 0).all()   # a clean model is untouched
     ok.close()
 
