@@ -894,7 +894,12 @@ void launch(const GemmArgs& a, hipStream_t s) {
     // (SGPT_T128_MIN sweep): 1536 token rows prefer 64^2 tiles up to fc1's 288 tiles of 128^2 (1.26 -> 1.15 ms), 6912 rows
     // prefer 128^2 tiles from the N = 768 launches' 324 on.
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    static const long t128_min = exp_env("SGPT_T128_MIN") ? atol(exp_env("SGPT_T128_MIN")) : 300;   // measured switch point
+    // Round 4 (scripts/small_tile_sweep.py, profiles/r04_small_tile_sweep.txt): with a short k-loop (K <= 1024: 12 k-steps) the
+    // 64^2 tiles keep winning up to ~600 tiles of 128^2 -- 576 of them are 1.1 rounds of the 512 resident slots, the second
+    // round 12 % full (fc1 at 3072 rows: 37.6 us on 128^2 tiles, 32.4 on 64^2; Q/K at 4096 rows 25.0 -> 22.5; out-projection
+    // at 8192 rows 31.8 -> 29.2); the 48-step k-loop of fc2 keeps the 300 (8192 rows: 64.1 us on 128^2, 69.5 on 64^2).
+    static const long t128_env = exp_env("SGPT_T128_MIN") ? atol(exp_env("SGPT_T128_MIN")) : -1;
+    const long t128_min = t128_env >= 0 ? t128_env : (a.K <= 1024 ? 600 : 300);
     const bool small = t128 < t128_min;
     const int B = small ? 64 : 128;
     const int MT = (a.M + B - 1) / B, NT = (a.N + B - 1) / B;
@@ -938,7 +943,11 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     const bool scorer = epi == EPI_SCORE || epi == EPI_SCORE_FILTER;
     // a.force256 (per ctx, sgpt_ctx_set_tile_policy): keep 256x256 tiles for problems the small-tile rule would hand to
     // the register-staged kernel -- kernel-level tests of single-tile shapes
-    const bool few = small_tiles && !a.force256 && !scorer && (long)(a.M / 256) * (a.N / 256) <= SGPT_FEW_TILES;
+    // (the GELU launch -- N = 4 d, a VALU-heavy epilogue -- wants a whole round of 256x256 tiles before the LDS-DMA kernel pays:
+    //  fc1 at 3072 / 4096 rows is 144 / 192 tiles, 43.3 / 43.5 us there against 32.4 / 38.8 us on the small tiles; the other
+    //  launches are faster on 256x256 tiles from half a round on -- Q/K at 6144 rows: 22.6 us against 31.7)
+    const long few_limit = epi == EPI_BIAS_GELU ? 255 : SGPT_FEW_TILES;
+    const bool few = small_tiles && !a.force256 && !scorer && (long)(a.M / 256) * (a.N / 256) <= few_limit;
     static const bool use256 = exp_env("SGPT_GEMM128") == nullptr;
     const bool shape256 = a.M % 256 == 0 && a.N % 256 == 0 && a.K % 64 == 0 && a.K >= 128;
     // short query batches: the 64-row scorer tile (M = 64 padded query rows, N % 256 == 0, K % 64 == 0, K >= 128)
