@@ -31,17 +31,29 @@
 #ifndef SGPT_ATTN_W16
 #define SGPT_ATTN_W16 1
 #endif
-#ifndef SGPT_ATTN_Q32
-#define SGPT_ATTN_Q32 0   // 1: also build / use the two-fragments-per-wave variant for head_dim 64 (A/B builds)
+#ifndef SGPT_ATTN_ZZ
+#define SGPT_ATTN_ZZ 1   // zig-zag fragment pairs (see attn16_lds_kernel) in 16-wave blocks for head_dim 64, sequences of > SGPT_ATTN_ZZ_MINLEN rows
 #endif
-#ifndef SGPT_ATTN_Q32_WAVES
-#define SGPT_ATTN_Q32_WAVES 3   // 4-wave blocks: resident blocks per CU
+#ifndef SGPT_ATTN_ZZ_MINLEN
+#define SGPT_ATTN_ZZ_MINLEN 384
 #endif
-#ifndef SGPT_ATTN_Q32_MINLEN
-#define SGPT_ATTN_Q32_MINLEN 64
+#ifndef SGPT_ATTN_ZZ_NW
+#define SGPT_ATTN_ZZ_NW 0   // A/B builds: n = always blocks of n waves, whatever the pair count (4, 5, 8 or 16)
 #endif
 #ifndef SGPT_ATTN_STAGES
 #define SGPT_ATTN_STAGES 1
+#endif
+#ifndef SGPT_ATTN_PIPE
+#define SGPT_ATTN_PIPE 0   // 1: software-pipelined schedule (next tile's K.Q^T under this tile's softmax) for head_dim 64, sequences of > SGPT_ATTN_PIPE_MINLEN rows
+#endif
+#ifndef SGPT_ATTN_PIPE_ALT
+#define SGPT_ATTN_PIPE_ALT 1   // pipelined schedule: half of each SIMD's waves take (next scores | softmax + P.V) in the opposite order
+#endif
+#ifndef SGPT_ATTN_WINSKIP
+#define SGPT_ATTN_WINSKIP 1   // local layers: a wave skips key tiles wholly below the window of its first query
+#endif
+#ifndef SGPT_ATTN_PIPE_MINLEN
+#define SGPT_ATTN_PIPE_MINLEN 128
 #endif
 #ifndef SGPT_ATTN_NT_LOAD
 #define SGPT_ATTN_NT_LOAD 1   // K / V^T tiles are read once per (sequence, head): non-temporal loads (+0.2 % end to end)
@@ -86,9 +98,14 @@ __device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor
 // and every wave takes its MFMA operands from there.  Same math / lane maps as above.
 // H = bf16_t | f16_t: the 16-bit format of q / k / V^T, of the probabilities fed to the P.V MFMA and of the context
 // OUT8: the context leaves as e4m3 codes of ctx / out_scale (fp8 out-projection operand) instead of the 16-bit format
-// NQ = 16-query fragments per wave.  NQ = 1: 8 waves x 16 queries.  NQ = 2 (DH = 64): 4 waves x 32 queries -- every K / V^T
-// fragment read from LDS feeds two MFMAs, halving the LDS bytes per query; the SQ counters at S = 512 put the LDS array
-// right behind the VALU as this kernel's busiest unit (profiles/r03_attn_pmc.txt).
+// NQ = 16-query fragments per wave, processed one after the other inside a key tile.  NQ = 1: fragment = queries q0 .. q0+15.
+// ZZ (NQ = 2, "zig-zag"): wave w of block b owns the PAIR of fragments (i, nf-1-i), i = b NW + w, of a sequence of nf
+// fragments.  Under the causal mask fragment f needs f/4 + 1 key tiles, so a block of consecutive fragments leaves its low
+// waves idle behind barriers while the high ones walk the diagonal (S = 512: 36 of 48 wave-steps used; S = 300 in 128-query
+// blocks: 55 of 88); the mirror pair makes every wave's work (i/4 + 1) + ((nf-1-i)/4 + 1) ~ constant, and gives a wave two
+// independent dependency chains wherever both fragments see the tile.  Same arithmetic per (fragment, tile) in the same tile
+// order: bits identical to NQ = 1.  (Round 3's other two-fragment variant -- adjacent fragments sharing every K / V^T LDS
+// read, +0.6 % at S = 512, build option SGPT_ATTN_Q32 -- was removed when this one replaced it.)
 // MODE 0: the kernel as described.  MODE 1: the context additionally leaves as a split-precision pair (hi at ctx, lo = round16(v - hi)
 // at ctx + ctx_lo_delta, a second hi at ctx + ctx_hi2_delta: the [hi | lo | hi] row the split out-projection contracts over).
 // MODE 2 ("x3" attention): q, k, V^T and the probabilities ALL enter their MFMAs as hi + lo pairs of 16-bit values --
@@ -96,15 +113,17 @@ __device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor
 // the lo halves of q | k and V^T sit qk_lo_delta / v_lo_delta elements behind the hi halves (written by the projections'
 // split epilogues).  Twice the LDS and three times the MFMAs of an attention that is < 2 % of a block's FLOPs; 2 waves per
 // SIMD (the second fragment set does not fit 128 VGPRs).  Context split as MODE 1 when ctx_lo_delta != 0.
-template <typename H, int DH, bool OUT8, int NQ, int NW = (NQ == 1 ? 8 : 4), int MODE = 0>
-__global__ __launch_bounds__(64 * NW, MODE == 2 ? 2 : (NQ == 2 ? SGPT_ATTN_Q32_WAVES : (NW <= 2 ? 3 : ATTN_WAVES_PER_SIMD)))   // (NW = 2: 4 staging loads per thread)
+template <typename H, int DH, bool OUT8, int NQ, int NW = 8, int MODE = 0, bool PIPE = false, bool ZZ = false>
+__global__ __launch_bounds__(64 * NW, MODE == 2 ? 2 : (NW <= 2 ? 3 : ATTN_WAVES_PER_SIMD))   // (NW = 2: 4 staging loads per thread)
 void attn16_lds_kernel(const AttnArgs p) {
     constexpr bool X3 = MODE == 2;
     static_assert(!(MODE != 0 && OUT8), "split-precision modes write 16-bit contexts");
+    static_assert(!PIPE || (NQ == 1 && !X3 && DH <= 128), "pipelined variant: one fragment per wave, 16-bit operands");
+    static_assert(ZZ ? NQ == 2 : NQ == 1, "two fragments per wave = the zig-zag pairing");
     constexpr int KS = DH / 32, DT = DH / 16, CPR = DH / 8;  // CPR = 16-B chunks per K row
     constexpr int NT = 64 * NW, QW = 16 * NQ, QB = NW * QW;    // NW waves per block, QW queries per wave, QB per block
     constexpr int ORS = DH * 2 + 16;                           // output-transpose row stride (bytes)
-    constexpr int NB = (DH <= 64 && SGPT_ATTN_STAGES == 2) ? 2 : 1;   // LDS stages of the K / V^T tiles
+    constexpr int NB = (PIPE || (DH <= 64 && SGPT_ATTN_STAGES == 2)) ? 2 : 1;   // LDS stages of the K / V^T tiles
     __shared__ __attribute__((aligned(16))) uint4 Ks[NB][64 * CPR];
     __shared__ __attribute__((aligned(16))) uint4 Vs[NB][DH * 8];
     __shared__ __attribute__((aligned(16))) uint4 KsL[X3 ? 64 * CPR : 1];     // lo halves of the key / V^T tile (MODE 2)
@@ -114,11 +133,24 @@ void attn16_lds_kernel(const AttnArgs p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int s0 = p.seq_off[sq];
     const int alloc = p.seq_off[sq + 1] - s0;
-    const int qb0 = blockIdx.x * QB;
-    if (qb0 >= alloc) return;                       // whole block out of range (uniform)
-    const int q0 = qb0 + wave * QW;
-    const bool wave_on = q0 < alloc;
     const int fr = lane & 15, g = lane >> 4;
+    // qpos[f] = first query row of the wave's fragment f (-1: none); qb0 = lowest query row of the block
+    int qpos[NQ], qb0;
+    bool wave_on;
+    if constexpr (ZZ) {
+        const int nf = (alloc + 15) >> 4, pi0 = blockIdx.x * NW, pi = pi0 + wave;
+        if (2 * pi0 > nf - 1) return;                // whole block out of range (uniform)
+        wave_on = 2 * pi <= nf - 1;
+        qpos[0] = 16 * pi;
+        qpos[1] = (nf - 1 - pi > pi) ? 16 * (nf - 1 - pi) : -1;   // (the middle fragment of an odd count is a pair of one)
+        qb0 = 16 * pi0;
+    } else {
+        qb0 = blockIdx.x * QB;
+        if (qb0 >= alloc) return;                    // whole block out of range (uniform)
+        qpos[0] = qb0 + wave * QW;
+        wave_on = qpos[0] < alloc;
+    }
+    const int q0 = qpos[0];
 
     const bf16_t* __restrict__ qb = static_cast<const bf16_t*>(p.q) + (long)head * DH;
     const bf16_t* __restrict__ kb = static_cast<const bf16_t*>(p.k) + (long)head * DH;
@@ -130,14 +162,14 @@ void attn16_lds_kernel(const AttnArgs p) {
     for (int f = 0; f < NQ; ++f)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            qf[f][ks] = *reinterpret_cast<const uint4*>(qb + (long)(s0 + q0 + 16 * f + fr) * p.ldq + ks * 32 + 8 * g);
+            qf[f][ks] = *reinterpret_cast<const uint4*>(qb + (long)(s0 + (qpos[f] < 0 ? 0 : qpos[f]) + fr) * p.ldq + ks * 32 + 8 * g);
     uint4 qfl[X3 ? NQ : 1][X3 ? KS : 1];
     if constexpr (X3) {
 #pragma unroll
         for (int f = 0; f < NQ; ++f)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                qfl[f][ks] = *reinterpret_cast<const uint4*>(qb + p.qk_lo_delta + (long)(s0 + q0 + 16 * f + fr) * p.ldq + ks * 32 + 8 * g);
+                qfl[f][ks] = *reinterpret_cast<const uint4*>(qb + p.qk_lo_delta + (long)(s0 + (qpos[f] < 0 ? 0 : qpos[f]) + fr) * p.ldq + ks * 32 + 8 * g);
     }
 
     f32x4 o[NQ][DT];
@@ -152,7 +184,7 @@ void attn16_lds_kernel(const AttnArgs p) {
 
     int j_lo = 0;
     if (p.window > 0) { j_lo = qb0 - p.window + 1; j_lo = j_lo < 0 ? 0 : (j_lo & ~63); }
-    int j_hi = qb0 + QB - 1;                         // last key any query of the block may see
+    int j_hi = ZZ ? 16 * (((alloc + 15) >> 4) - 1 - blockIdx.x * NW) + 15 : qb0 + QB - 1;   // last key any query of the block may see
     if (j_hi > alloc - 1) j_hi = alloc - 1;
     // ---- cooperative tile load (row-contiguous 16-B pieces), one tile ahead: the global loads of key tile j+1 are
     // issued before tile j is consumed from LDS, so a sequence of several key tiles (S >= 128) does not pay one
@@ -206,6 +238,205 @@ void attn16_lds_kernel(const AttnArgs p) {
             }
         }
     };
+    const float c2 = p.scale * 1.44269504088896341f;
+    const float s2 = slope * 1.44269504088896341f;
+    // ---- the three phases of one 64-key tile, for fragment f of the wave (f is a compile-time index after unrolling) ----
+    // S^T = K.Q^T : 4 tiles of [16 keys][16 queries]
+    auto qk_frag = [&](const uint4* __restrict__ Kc, const uint4 (&q)[KS], const uint4 (&ql)[X3 ? KS : 1], f32x4 (&s)[4]) {
+        // (k-step outer, key tile inner: consecutive MFMAs accumulate into different score tiles -- no back-to-back dependent pair)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int row = nt * 16 + fr;
+                const uint4 kv = Kc[row * CPR + ((ks * 4 + g) ^ (row & 7))];
+                s[nt] = Half<H>::mfma16(kv, q[ks], s[nt]);
+                if constexpr (X3) {
+                    const uint4 kl = KsL[row * CPR + ((ks * 4 + g) ^ (row & 7))];
+                    s[nt] = Half<H>::mfma16(kl, q[ks], s[nt]);
+                    s[nt] = Half<H>::mfma16(kv, ql[ks], s[nt]);
+                }
+            }
+        }
+    };
+    // Softmax in the log2 domain: t = s * (scale * log2 e) [+ alibi * log2 e], p = 2^(t - m).  SQ counters at S = 512
+    // (profiles/r03_attn_pmc.txt) put this kernel's VALU at 77 % busy with 4 waves per SIMD -- 255 VALU instructions per
+    // 64-key tile and wave, half of them the per-score mask (key index, two compares, select, int -> float for the
+    // ALiBi term).  A tile every query of the fragment sees whole (all but the diagonal tile of a fragment, and the
+    // window's low edge) takes the lean path: one multiply per score.  Elsewhere the compares run against
+    // compile-time offsets of one per-lane distance.
+    auto softmax_frag = [&](int j0, int qf0, f32x4 (&s)[4], float& m_r, float& l_r, f32x4 (&oo_)[DT], uint32_t (&pw)[8], uint32_t (&pwl)[8]) {
+        const int qi = qf0 + fr;
+        // (DH = 128: the second code path costs 14 spilled VGPRs at 4 waves per SIMD -- lean path for DH = 64 only)
+        const bool full = DH <= 64 && (j0 + 63 <= qf0) && (p.window <= 0 || j0 > qf0 + 15 - p.window);
+        float mx = -INFINITY;
+        if (full && slope == 0.f) {                  // wave-uniform
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[nt][r] *= c2;
+                mx = fmaxf(mx, fmaxf(fmaxf(s[nt][0], s[nt][1]), fmaxf(s[nt][2], s[nt][3])));
+            }
+        } else {
+            const int dq = qi - (j0 + 4 * g);         // key offset o = 16 nt + r is visible iff o <= dq (and o > dq - window)
+            const int dw = p.window > 0 ? dq - p.window : -(1 << 30);
+            const float ab = s2 * (float)(j0 + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int oo = nt * 16 + r;
+                    const bool vis = (oo <= dq) && (oo > dw);
+                    const float v = vis ? __builtin_fmaf(s[nt][r], c2, __builtin_fmaf(s2, (float)oo, ab)) : -INFINITY;
+                    s[nt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
+        mx = xor16_max(mx);                      // the other three lane groups' keys of this query: two VALU lane swaps
+        mx = xor32_max(mx);                      // (ds_bpermute round trips sat on every tile's dependent chain)
+        const float m_new = fmaxf(m_r, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_r - m_new);
+        m_r = m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float e0 = __builtin_amdgcn_exp2f(s[nt][0] - m_new), e1 = __builtin_amdgcn_exp2f(s[nt][1] - m_new);
+            const float e2 = __builtin_amdgcn_exp2f(s[nt][2] - m_new), e3 = __builtin_amdgcn_exp2f(s[nt][3] - m_new);
+            ps += (e0 + e1) + (e2 + e3);
+            pw[nt * 2] = Half<H>::pack2(e0, e1);          // probabilities in [0, 1]: inside either format's range
+            pw[nt * 2 + 1] = Half<H>::pack2(e2, e3);
+            if constexpr (X3) {
+                pwl[nt * 2] = Half<H>::pack2(e0 - Half<H>::lo(pw[nt * 2]), e1 - Half<H>::hi(pw[nt * 2]));
+                pwl[nt * 2 + 1] = Half<H>::pack2(e2 - Half<H>::lo(pw[nt * 2 + 1]), e3 - Half<H>::hi(pw[nt * 2 + 1]));
+            }
+        }
+        l_r = l_r * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            oo_[dt][0] *= alpha; oo_[dt][1] *= alpha; oo_[dt][2] *= alpha; oo_[dt][3] *= alpha;
+        }
+    };
+    // O^T += V^T . P^T, two 32-key steps; k-slot j <-> key 32*step + 16*(j>>2) + 4g + (j&3)
+    auto pv_frag = [&](const uint4* __restrict__ Vc, f32x4 (&oo_)[DT], const uint32_t (&pw)[8], const uint32_t (&pwl)[8]) {
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            uint4 pu, pul;
+            pu.x = pw[step * 4]; pu.y = pw[step * 4 + 1]; pu.z = pw[step * 4 + 2]; pu.w = pw[step * 4 + 3];
+            if constexpr (X3) { pul.x = pwl[step * 4]; pul.y = pwl[step * 4 + 1]; pul.z = pwl[step * 4 + 2]; pul.w = pwl[step * 4 + 3]; }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int row = dt * 16 + fr;
+                // chunk 4*step + g of the k-slot-permuted row = this lane group's eight k-slots (see the staging store)
+                const uint4 vu = Vc[row * 8 + ((4 * step + g) ^ (row & 7))];
+                oo_[dt] = Half<H>::mfma16(vu, pu, oo_[dt]);
+                if constexpr (X3) {
+                    const uint4 vl = VsL[row * 8 + ((4 * step + g) ^ (row & 7))];
+                    oo_[dt] = Half<H>::mfma16(vl, pu, oo_[dt]);
+                    oo_[dt] = Half<H>::mfma16(vu, pul, oo_[dt]);
+                }
+            }
+        }
+    };
+    // fragment at query row qf0 has work in the key tile at j0 iff some query of it sees some key of the tile: not past the
+    // diagonal, and (local layers) not wholly below the window of its first query -- a skipped tile would contribute p = 0
+    // everywhere (same bits)
+    auto frag_visible = [&](int qf0, int j0) {
+        return wave_on && qf0 >= 0 && j0 <= j_hi && j0 <= qf0 + 15 && (!SGPT_ATTN_WINSKIP || p.window <= 0 || j0 + 63 > qf0 - p.window);
+    };
+    auto tile_compute = [&](const uint4* __restrict__ Kc, const uint4* __restrict__ Vc, int j0) {
+#pragma unroll
+        for (int f = 0; f < NQ; ++f) {
+            if (frag_visible(qpos[f], j0)) {
+                f32x4 s[4];
+                uint32_t pw[8], pwl[8];
+                qk_frag(Kc, qf[f], qfl[X3 ? f : 0], s);
+                softmax_frag(j0, qpos[f], s, m_run[f], l_run[f], o[f], pw, pwl);
+                pv_frag(Vc, o[f], pw, pwl);
+            }
+        }
+    };
+    if constexpr (PIPE) {
+        // Software-pipelined schedule for sequences of several key tiles: a wave issues the K.Q^T MFMAs of
+        // tile i+1 BEFORE the softmax of tile i, so the LDS fragment reads and the MFMA latency of the next scores run under
+        // this tile's ~150 VALU instructions instead of in front of them.  K runs one tile ahead of V^T through two LDS
+        // stages each: during step i the LDS holds K_{i+1} (Ks[(i+1)&1]) and V_i (Vs[i&1]); K_{i+2} and V_{i+1} (global
+        // loads issued a step earlier) are written into the two retired stages at the start of the step and published by
+        // the ONE barrier that ends it.  Same arithmetic per tile, same order over tiles: bits identical to the plain schedule.
+        // Measured (profiles/r04_attn_ab.txt): S = 512 377 -> 413 us per launch, S = 300 315 -> 317 -- the waves are not
+        // waiting for their own MFMAs.  Build option SGPT_ATTN_PIPE, off.
+        uint4 kreg2[KU];
+        auto k_load = [&](int j0, uint4 (&r)[KU]) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int c = t + NT * u, row = c / CPR, ch = c % CPR;
+                if (c < 64 * CPR) r[u] = ldg16u<ATTN_NT_LOAD>(kb + (long)(s0 + j0 + row) * p.ldq + ch * 8);
+            }
+        };
+        auto k_store = [&](int b, const uint4 (&r)[KU]) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int c = t + NT * u, row = c / CPR, ch = c % CPR;
+                if (c < 64 * CPR) Ks[b][row * CPR + (ch ^ (row & 7))] = r[u];
+            }
+        };
+        auto v_load = [&](int j0) {
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int c = t + NT * u, row = c >> 3, ch = c & 7;
+                if (c < DH * 8) vreg[u] = ldg16u<ATTN_NT_LOAD>(vt + (long)row * p.ldvt + s0 + j0 + ch * 8);
+            }
+        };
+        auto v_store = [&](int b) {
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int c = t + NT * u, row = c >> 3, ch = c & 7;
+                if (c < DH * 8) {
+                    const int blk = ch >> 2, w = ch & 3, hf = w >> 1, g0 = 2 * (w & 1);   // (k-slot permutation: see tile_store)
+                    char* vrow = reinterpret_cast<char*>(&Vs[b][row * 8]);
+                    *reinterpret_cast<uint2*>(vrow + ((4 * blk + g0) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vreg[u].x, vreg[u].y);
+                    *reinterpret_cast<uint2*>(vrow + ((4 * blk + g0 + 1) ^ (row & 7)) * 16 + hf * 8) = make_uint2(vreg[u].z, vreg[u].w);
+                }
+            }
+        };
+        if (j_lo <= j_hi) {
+            k_load(j_lo, kreg); v_load(j_lo);
+            if (j_lo + 64 <= j_hi) k_load(j_lo + 64, kreg2);
+            k_store(0, kreg); v_store(0);
+            if (j_lo + 64 <= j_hi) { k_store(1, kreg2); v_load(j_lo + 64); }
+            if (j_lo + 128 <= j_hi) k_load(j_lo + 128, kreg);
+        }
+        __syncthreads();
+        f32x4 sa[4], sb[4];
+        if (frag_visible(q0, j_lo)) qk_frag(Ks[0], qf[0], qfl[0], sa);
+        __syncthreads();
+        // one step: tile at j0 in stage b (scores already in sc), next scores into sn
+        auto pipe_step = [&](int j0, int b, f32x4 (&sc)[4], f32x4 (&sn)[4]) {
+            if (j0 + 128 <= j_hi) k_store(b, kreg);          // K_{i+2} over K_i (consumed a step ago)
+            if (j0 + 64 <= j_hi) v_store(b ^ 1);             // V_{i+1} over V_{i-1}
+            if (j0 + 192 <= j_hi) k_load(j0 + 192, kreg);
+            if (j0 + 128 <= j_hi) v_load(j0 + 128);
+            // The barriers phase-lock a block's waves: left alone they all read K fragments, then all issue MFMAs, then all run
+            // the softmax's VALU work -- LDS, MFMA and VALU time ADD UP (S = 512: ~2 300 + 1 000 + 3 500 cycles per step and
+            // CU against the 6 500 measured).  The next tile's scores do not depend on this tile's softmax, so half of the
+            // waves of every SIMD (waves w, w+4, w+8, w+12 share one) take the two pieces in the opposite order: while one
+            // half reads LDS and feeds the MFMA pipe, the other half is in its softmax.
+            const bool next_first = !SGPT_ATTN_PIPE_ALT || ((wave >> 2) & 1) == 0;
+            if (next_first && frag_visible(q0, j0 + 64)) qk_frag(Ks[b ^ 1], qf[0], qfl[0], sn);
+            if (frag_visible(q0, j0)) {
+                uint32_t pw[8], pwl[8];
+                softmax_frag(j0, q0, sc, m_run[0], l_run[0], o[0], pw, pwl);
+                pv_frag(Vs[b], o[0], pw, pwl);
+            }
+            if (!next_first && frag_visible(q0, j0 + 64)) qk_frag(Ks[b ^ 1], qf[0], qfl[0], sn);
+            __syncthreads();
+        };
+        for (int j0 = j_lo; j0 <= j_hi; j0 += 128) {
+            pipe_step(j0, 0, sa, sb);
+            if (j0 + 64 <= j_hi) pipe_step(j0 + 64, 1, sb, sa);
+        }
+    } else {
     // NB = 2: two LDS stages, ONE barrier per key tile -- tile j+1 is written into the other stage behind tile j's MFMAs,
     // and the barrier at the end of the step both publishes it and retires stage j.  Measured: no gain (the waves do not
     // wait for the barriers, profiles/r03_attn_pmc.txt), so NB = 1 is what ships: store, barrier, consume, barrier.
@@ -214,8 +445,6 @@ void attn16_lds_kernel(const AttnArgs p) {
         tile_load(j_lo);
         if constexpr (NB == 2) { tile_store(0); __syncthreads(); }
     }
-    const float c2 = p.scale * 1.44269504088896341f;
-    const float s2 = slope * 1.44269504088896341f;
     for (int j0 = j_lo; j0 <= j_hi; j0 += 64) {
         if constexpr (NB == 1) {
             __syncthreads();                         // previous tile fully consumed
@@ -224,124 +453,13 @@ void attn16_lds_kernel(const AttnArgs p) {
         }
         const bool more = j0 + 64 <= j_hi;
         if (more) tile_load(j0 + 64);                // next tile's loads fly under this tile's MFMAs and softmax
-        if (wave_on && j0 <= q0 + QW - 1) {          // else: nothing visible for this wave in this tile
-        const uint4* __restrict__ Kc = Ks[cur];
-        const uint4* __restrict__ Vc = Vs[cur];
-        // ---- S^T = K.Q^T : 4 tiles of [16 keys][16 queries] per fragment ----
-        f32x4 s[NQ][4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-            for (int f = 0; f < NQ; ++f) s[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int row = nt * 16 + fr;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const uint4 kv = Kc[row * CPR + ((ks * 4 + g) ^ (row & 7))];
-#pragma unroll
-                for (int f = 0; f < NQ; ++f) s[f][nt] = Half<H>::mfma16(kv, qf[f][ks], s[f][nt]);
-                if constexpr (X3) {
-                    const uint4 kl = KsL[row * CPR + ((ks * 4 + g) ^ (row & 7))];
-#pragma unroll
-                    for (int f = 0; f < NQ; ++f) {
-                        s[f][nt] = Half<H>::mfma16(kl, qf[f][ks], s[f][nt]);
-                        s[f][nt] = Half<H>::mfma16(kv, qfl[f][ks], s[f][nt]);
-                    }
-                }
-            }
-        }
-        // Softmax in the log2 domain: t = s * (scale * log2 e) [+ alibi * log2 e], p = 2^(t - m).  SQ counters at S = 512
-        // (profiles/r03_attn_pmc.txt) put this kernel's VALU at 77 % busy with 4 waves per SIMD -- 255 VALU instructions per
-        // 64-key tile and wave, half of them the per-score mask (key index, two compares, select, int -> float for the
-        // ALiBi term).  A tile every query of the fragment sees whole (all but the diagonal tile of a fragment, and the
-        // window's low edge) takes the lean path: one multiply per score.  Elsewhere the compares run against
-        // compile-time offsets of one per-lane distance.
-        uint32_t pw[NQ][8], pwl[X3 ? NQ : 1][8];
-#pragma unroll
-        for (int f = 0; f < NQ; ++f) {
-            const int qf0 = q0 + 16 * f, qi = qf0 + fr;
-            // (DH = 128: the second code path costs 14 spilled VGPRs at 4 waves per SIMD -- lean path for DH = 64 only)
-            const bool full = DH <= 64 && (j0 + 63 <= qf0) && (p.window <= 0 || j0 > qf0 + 15 - p.window);
-            float mx = -INFINITY;
-            if (full && slope == 0.f) {                  // wave-uniform
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[f][nt][r] *= c2;
-                    mx = fmaxf(mx, fmaxf(fmaxf(s[f][nt][0], s[f][nt][1]), fmaxf(s[f][nt][2], s[f][nt][3])));
-                }
-            } else {
-                const int dq = qi - (j0 + 4 * g);         // key offset o = 16 nt + r is visible iff o <= dq (and o > dq - window)
-                const int dw = p.window > 0 ? dq - p.window : -(1 << 30);
-                const float ab = s2 * (float)(j0 + 4 * g);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int oo = nt * 16 + r;
-                        const bool vis = (oo <= dq) && (oo > dw);
-                        const float v = vis ? __builtin_fmaf(s[f][nt][r], c2, __builtin_fmaf(s2, (float)oo, ab)) : -INFINITY;
-                        s[f][nt][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-            }
-            mx = xor16_max(mx);                      // the other three lane groups' keys of this query: two VALU lane swaps
-            mx = xor32_max(mx);                      // (ds_bpermute round trips sat on every tile's dependent chain)
-            const float m_new = fmaxf(m_run[f], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
-            m_run[f] = m_new;
-            float ps = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const float e0 = __builtin_amdgcn_exp2f(s[f][nt][0] - m_new), e1 = __builtin_amdgcn_exp2f(s[f][nt][1] - m_new);
-                const float e2 = __builtin_amdgcn_exp2f(s[f][nt][2] - m_new), e3 = __builtin_amdgcn_exp2f(s[f][nt][3] - m_new);
-                ps += (e0 + e1) + (e2 + e3);
-                pw[f][nt * 2] = Half<H>::pack2(e0, e1);          // probabilities in [0, 1]: inside either format's range
-                pw[f][nt * 2 + 1] = Half<H>::pack2(e2, e3);
-                if constexpr (X3) {
-                    pwl[f][nt * 2] = Half<H>::pack2(e0 - Half<H>::lo(pw[f][nt * 2]), e1 - Half<H>::hi(pw[f][nt * 2]));
-                    pwl[f][nt * 2 + 1] = Half<H>::pack2(e2 - Half<H>::lo(pw[f][nt * 2 + 1]), e3 - Half<H>::hi(pw[f][nt * 2 + 1]));
-                }
-            }
-            l_run[f] = l_run[f] * alpha + ps;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                o[f][dt][0] *= alpha; o[f][dt][1] *= alpha; o[f][dt][2] *= alpha; o[f][dt][3] *= alpha;
-            }
-        }
-        // ---- O^T += V^T . P^T, two 32-key steps; k-slot j <-> key 32*step + 16*(j>>2) + 4g + (j&3) ----
-#pragma unroll
-        for (int step = 0; step < 2; ++step) {
-            uint4 pu[NQ], pul[X3 ? NQ : 1];
-#pragma unroll
-            for (int f = 0; f < NQ; ++f) {
-                pu[f].x = pw[f][step * 4]; pu[f].y = pw[f][step * 4 + 1]; pu[f].z = pw[f][step * 4 + 2]; pu[f].w = pw[f][step * 4 + 3];
-                if constexpr (X3) {
-                    pul[f].x = pwl[f][step * 4]; pul[f].y = pwl[f][step * 4 + 1]; pul[f].z = pwl[f][step * 4 + 2]; pul[f].w = pwl[f][step * 4 + 3];
-                }
-            }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int row = dt * 16 + fr;
-                // chunk 4*step + g of the k-slot-permuted row = this lane group's eight k-slots (see the staging store)
-                const uint4 vu = Vc[row * 8 + ((4 * step + g) ^ (row & 7))];
-#pragma unroll
-                for (int f = 0; f < NQ; ++f) o[f][dt] = Half<H>::mfma16(vu, pu[f], o[f][dt]);
-                if constexpr (X3) {
-                    const uint4 vl = VsL[row * 8 + ((4 * step + g) ^ (row & 7))];
-#pragma unroll
-                    for (int f = 0; f < NQ; ++f) {
-                        o[f][dt] = Half<H>::mfma16(vl, pu[f], o[f][dt]);
-                        o[f][dt] = Half<H>::mfma16(vu, pul[f], o[f][dt]);
-                    }
-                }
-            }
-        }
-        }
+        tile_compute(Ks[cur], Vs[cur], j0);
         if constexpr (NB == 2) {
             if (more) tile_store(cur ^ 1);
             __syncthreads();
             cur ^= 1;
         }
+    }
     }
     if (!wave_on) return;
     // O^T tile dt: lane holds head-dim elements dt*16 + 4g + r of query fr.  Transpose through a per-wave
@@ -352,8 +470,8 @@ void attn16_lds_kernel(const AttnArgs p) {
     char* os = Os[wave];
 #pragma unroll
     for (int f = 0; f < NQ; ++f) {
-        const int qf0 = q0 + 16 * f;
-        if (qf0 >= alloc) break;
+        const int qf0 = qpos[f];
+        if (qf0 < 0 || qf0 >= alloc) continue;
         float lr = l_run[f];
         lr += __shfl_xor(lr, 16, 64);
         lr += __shfl_xor(lr, 32, 64);
@@ -495,10 +613,32 @@ void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     // Long sequences, head_dim 64: 16-wave blocks of 256 queries stage every K / V^T tile once per 256 queries instead of
     // once per 128 (seq 512: 118.9 -> 117.4 ms per step; 64-query blocks, the other direction: -2 ... -8 %).  Only where the
     // last block of a sequence is at least half full (seq 300 = 256 + 48 queries: -1.4 %).
+    // Zig-zag fragment pairs, head_dim 64, sequences of more than 384 rows: a block of 16 waves owns 16 pairs = up to 512 rows
+    // (longer sequences: block b owns pairs 16 b .. 16 b + 15), used where the last block is at least three quarters full.
+    // Same box, attention launch alone (profiles/r04_attn_ab.txt): S = 512 388 -> 337 us (-13 %; the step 29.9 -> 29.45 ms).
+    // Short blocks lose more than the balance returns -- S = 300 (10 pairs): 322 us in three 8-wave blocks of consecutive
+    // fragments, 362 us as one 16-wave block of pairs (6 idle waves), 415 us in 8-wave blocks of pairs, 528 us in 5-wave
+    // blocks: the per-tile staging + two barriers want many waves behind them.
+    const int zz_pairs = ((a.max_alloc_len + 15) / 16 + 1) / 2;
+    const bool zz_fit = SGPT_ATTN_ZZ_NW != 0 || zz_pairs % 16 == 0 || zz_pairs % 16 >= 12;
+    if (SGPT_ATTN_ZZ && a.dh == 64 && !a.out_fp8 && a.max_alloc_len > SGPT_ATTN_ZZ_MINLEN && zz_fit) {
+        constexpr int ZW = SGPT_ATTN_ZZ_NW ? SGPT_ATTN_ZZ_NW : 16;
+        dim3 gz((zz_pairs + ZW - 1) / ZW, a.H, a.B);
+        if (a.dtype == DT_F16) hipLaunchKernelGGL((attn16_lds_kernel<f16_t, 64, false, 2, ZW, 0, false, true>), gz, dim3(64 * ZW), 0, s, a);
+        else hipLaunchKernelGGL((attn16_lds_kernel<bf16_t, 64, false, 2, ZW, 0, false, true>), gz, dim3(64 * ZW), 0, s, a);
+        return;
+    }
+    constexpr bool PIPE = SGPT_ATTN_PIPE != 0;
+    const bool pipe = PIPE && a.dh == 64 && !a.out_fp8 && a.max_alloc_len > SGPT_ATTN_PIPE_MINLEN;
     if (SGPT_ATTN_W16 && a.dh == 64 && !a.out_fp8 && a.max_alloc_len > 384 && (a.max_alloc_len - 1) % 256 >= 128) {
         dim3 g16((a.max_alloc_len + 255) / 256, a.H, a.B);
-        if (a.dtype == DT_F16) hipLaunchKernelGGL((attn16_lds_kernel<f16_t, 64, false, 1, 16>), g16, dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL((attn16_lds_kernel<bf16_t, 64, false, 1, 16>), g16, dim3(1024), 0, s, a);
+        if (a.dtype == DT_F16) hipLaunchKernelGGL((attn16_lds_kernel<f16_t, 64, false, 1, 16, 0, PIPE>), g16, dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((attn16_lds_kernel<bf16_t, 64, false, 1, 16, 0, PIPE>), g16, dim3(1024), 0, s, a);
+        return;
+    }
+    if (pipe) {
+        if (a.dtype == DT_F16) hipLaunchKernelGGL((attn16_lds_kernel<f16_t, 64, false, 1, 8, 0, PIPE>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((attn16_lds_kernel<bf16_t, 64, false, 1, 8, 0, PIPE>), grid, dim3(512), 0, s, a);
         return;
     }
     // Short sequences, head_dim 64 (query batches: 4..32 tokens each): blocks of 2 / 4 waves instead of 8 -- a 128-query block
@@ -516,18 +656,7 @@ void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
         }
         return;
     }
-#if SGPT_ATTN_Q32
-    // head_dim 64: two 16-query fragments per wave (4-wave blocks of the same 128 queries) once sequences have more than one
-    // 64-key tile.  Measured against eight 16-query waves: seq 512 +0.6 %, seq 300 -0.4 %, seq 128 -0.3 % at three blocks per
-    // CU, -5 % at two (profiles/r03_attn_pmc.txt) -- what the second fragment adds in independent work per wave it takes
-    // away in resident waves.  Not used by default.
-    const bool q32 = a.max_alloc_len > SGPT_ATTN_Q32_MINLEN;
-#define ATTN_Q32_CASE(H, O8) if (a.dh == 64 && q32) hipLaunchKernelGGL((attn16_lds_kernel<H, 64, O8, 2>), grid, dim3(256), 0, s, a); else
-#else
-#define ATTN_Q32_CASE(H, O8)
-#endif
 #define ATTN_CASE(H, O8)                                                                                          \
-    ATTN_Q32_CASE(H, O8)                                                                                          \
     if (a.dh == 64) hipLaunchKernelGGL((attn16_lds_kernel<H, 64, O8, 1>), grid, dim3(512), 0, s, a);          \
     else if (a.dh == 128) hipLaunchKernelGGL((attn16_lds_kernel<H, 128, O8, 1>), grid, dim3(512), 0, s, a);        \
     else if (a.dh == 256) hipLaunchKernelGGL((attn16_lds_kernel<H, 256, O8, 1>), grid, dim3(512), 0, s, a);        \
@@ -535,7 +664,6 @@ void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     if (a.out_fp8) { ATTN_CASE(bf16_t, true) }
     else if (a.dtype == DT_F16) { ATTN_CASE(f16_t, false) } else { ATTN_CASE(bf16_t, false) }
 #undef ATTN_CASE
-#undef ATTN_Q32_CASE
 }
 
 void launch_attn_f32(const AttnArgs& a, hipStream_t s) {
