@@ -32,13 +32,13 @@
 #define SGPT_ATTN_W16 1
 #endif
 #ifndef SGPT_ATTN_ZZ
-#define SGPT_ATTN_ZZ 1   // zig-zag fragment pairs (see attn16_lds_kernel) in 16-wave blocks for head_dim 64, sequences of > SGPT_ATTN_ZZ_MINLEN rows
+#define SGPT_ATTN_ZZ 1   // zig-zag fragment pairs (see attn16_lds_kernel) for head_dim 64, sequences of > SGPT_ATTN_ZZ_MINLEN rows
 #endif
 #ifndef SGPT_ATTN_ZZ_MINLEN
-#define SGPT_ATTN_ZZ_MINLEN 384
+#define SGPT_ATTN_ZZ_MINLEN 128
 #endif
 #ifndef SGPT_ATTN_ZZ_NW
-#define SGPT_ATTN_ZZ_NW 0   // A/B builds: n = always blocks of n waves, whatever the pair count (4, 5, 8 or 16)
+#define SGPT_ATTN_ZZ_NW 0   // A/B builds: 8 / 16 = always blocks of that many waves, whatever the pair count
 #endif
 #ifndef SGPT_ATTN_STAGES
 #define SGPT_ATTN_STAGES 1
@@ -102,10 +102,11 @@ __device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor
 // ZZ (NQ = 2, "zig-zag"): wave w of block b owns the PAIR of fragments (i, nf-1-i), i = b NW + w, of a sequence of nf
 // fragments.  Under the causal mask fragment f needs f/4 + 1 key tiles, so a block of consecutive fragments leaves its low
 // waves idle behind barriers while the high ones walk the diagonal (S = 512: 36 of 48 wave-steps used; S = 300 in 128-query
-// blocks: 55 of 88); the mirror pair makes every wave's work (i/4 + 1) + ((nf-1-i)/4 + 1) ~ constant, and gives a wave two
-// independent dependency chains wherever both fragments see the tile.  Same arithmetic per (fragment, tile) in the same tile
-// order: bits identical to NQ = 1.  (Round 3's other two-fragment variant -- adjacent fragments sharing every K / V^T LDS
-// read, +0.6 % at S = 512, build option SGPT_ATTN_Q32 -- was removed when this one replaced it.)
+// blocks: 55 of 88); the mirror pair makes every wave's work (i/4 + 1) + ((nf-1-i)/4 + 1) ~ constant, gives a wave two
+// independent dependency chains wherever both fragments see the tile, and halves the blocks (and K / V^T stagings) per
+// sequence.  Same arithmetic per (fragment, tile) in the same tile order: bits identical to NQ = 1.  Launch rule and numbers:
+// launch_attn_bf16.  (Round 3's other two-fragment variant -- adjacent fragments sharing every K / V^T LDS read, +0.6 % at
+// S = 512, build option SGPT_ATTN_Q32 -- was removed when this one replaced it.)
 // MODE 0: the kernel as described.  MODE 1: the context additionally leaves as a split-precision pair (hi at ctx, lo = round16(v - hi)
 // at ctx + ctx_lo_delta, a second hi at ctx + ctx_hi2_delta: the [hi | lo | hi] row the split out-projection contracts over).
 // MODE 2 ("x3" attention): q, k, V^T and the probabilities ALL enter their MFMAs as hi + lo pairs of 16-bit values --
@@ -243,14 +244,12 @@ void attn16_lds_kernel(const AttnArgs p) {
     // ---- the three phases of one 64-key tile, for fragment f of the wave (f is a compile-time index after unrolling) ----
     // S^T = K.Q^T : 4 tiles of [16 keys][16 queries]
     auto qk_frag = [&](const uint4* __restrict__ Kc, const uint4 (&q)[KS], const uint4 (&ql)[X3 ? KS : 1], f32x4 (&s)[4]) {
-        // (k-step outer, key tile inner: consecutive MFMAs accumulate into different score tiles -- no back-to-back dependent pair)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < 4; ++nt) {
+            s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int row = nt * 16 + fr;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int row = nt * 16 + fr;
+            for (int ks = 0; ks < KS; ++ks) {
                 const uint4 kv = Kc[row * CPR + ((ks * 4 + g) ^ (row & 7))];
                 s[nt] = Half<H>::mfma16(kv, q[ks], s[nt]);
                 if constexpr (X3) {
@@ -365,7 +364,8 @@ void attn16_lds_kernel(const AttnArgs p) {
         // loads issued a step earlier) are written into the two retired stages at the start of the step and published by
         // the ONE barrier that ends it.  Same arithmetic per tile, same order over tiles: bits identical to the plain schedule.
         // Measured (profiles/r04_attn_ab.txt): S = 512 377 -> 413 us per launch, S = 300 315 -> 317 -- the waves are not
-        // waiting for their own MFMAs.  Build option SGPT_ATTN_PIPE, off.
+        // waiting for their own MFMAs.  Build option SGPT_ATTN_PIPE, off.  (What they WERE waiting for was found afterwards:
+        // the plain loop's s_waitcnt vmcnt(0) in front of its K.Q^T MFMAs, see the explicit wait below.)
         uint4 kreg2[KU];
         auto k_load = [&](int j0, uint4 (&r)[KU]) {
 #pragma unroll
@@ -445,6 +445,12 @@ void attn16_lds_kernel(const AttnArgs p) {
         tile_load(j_lo);
         if constexpr (NB == 2) { tile_store(0); __syncthreads(); }
     }
+    // The query fragments (global loads issued above) are first used by the MFMAs inside the loop.  Left to the compiler's
+    // counter bookkeeping, the loop's back edge keeps them "pending" and every iteration waited s_waitcnt vmcnt(0) in front of
+    // its K.Q^T MFMAs -- i.e. for the NEXT tile's prefetch it had just issued: a full global round trip per tile and wave, on
+    // the dependent chain.  Retiring everything that is in flight once, here (the first tile is needed by the first
+    // tile_store anyway), leaves only the prefetch pending inside the loop, and that is waited for where it is stored.
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
     for (int j0 = j_lo; j0 <= j_hi; j0 += 64) {
         if constexpr (NB == 1) {
             __syncthreads();                         // previous tile fully consumed
@@ -613,20 +619,31 @@ void launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     // Long sequences, head_dim 64: 16-wave blocks of 256 queries stage every K / V^T tile once per 256 queries instead of
     // once per 128 (seq 512: 118.9 -> 117.4 ms per step; 64-query blocks, the other direction: -2 ... -8 %).  Only where the
     // last block of a sequence is at least half full (seq 300 = 256 + 48 queries: -1.4 %).
-    // Zig-zag fragment pairs, head_dim 64, sequences of more than 384 rows: a block of 16 waves owns 16 pairs = up to 512 rows
-    // (longer sequences: block b owns pairs 16 b .. 16 b + 15), used where the last block is at least three quarters full.
-    // Same box, attention launch alone (profiles/r04_attn_ab.txt): S = 512 388 -> 337 us (-13 %; the step 29.9 -> 29.45 ms).
-    // Short blocks lose more than the balance returns -- S = 300 (10 pairs): 322 us in three 8-wave blocks of consecutive
-    // fragments, 362 us as one 16-wave block of pairs (6 idle waves), 415 us in 8-wave blocks of pairs, 528 us in 5-wave
-    // blocks: the per-tile staging + two barriers want many waves behind them.
-    const int zz_pairs = ((a.max_alloc_len + 15) / 16 + 1) / 2;
-    const bool zz_fit = SGPT_ATTN_ZZ_NW != 0 || zz_pairs % 16 == 0 || zz_pairs % 16 >= 12;
-    if (SGPT_ATTN_ZZ && a.dh == 64 && !a.out_fp8 && a.max_alloc_len > SGPT_ATTN_ZZ_MINLEN && zz_fit) {
-        constexpr int ZW = SGPT_ATTN_ZZ_NW ? SGPT_ATTN_ZZ_NW : 16;
-        dim3 gz((zz_pairs + ZW - 1) / ZW, a.H, a.B);
-        if (a.dtype == DT_F16) hipLaunchKernelGGL((attn16_lds_kernel<f16_t, 64, false, 2, ZW, 0, false, true>), gz, dim3(64 * ZW), 0, s, a);
-        else hipLaunchKernelGGL((attn16_lds_kernel<bf16_t, 64, false, 2, ZW, 0, false, true>), gz, dim3(64 * ZW), 0, s, a);
-        return;
+    // Zig-zag fragment pairs (head_dim 64, sequences of more than 128 rows; block b of NW waves owns pairs b NW .. b NW + NW - 1).
+    // Attention launch alone at 131 072 token rows, same box per column (profiles/r04_attn_ab.txt), us:
+    //     rows                            160    200    256    300    384    512
+    //     consecutive fragments, 8 waves  267    288    217    294    235    (372: 16 waves)
+    //     pairs, 16-wave blocks           344    322    256    286    259    271
+    //     pairs, 8-wave blocks            207    213    169    306    271    255
+    // -> 8-wave blocks of pairs wherever the last block is at least three quarters full (always up to 256 rows: one block, and
+    //    two of them share a CU); else consecutive fragments if THEIR last block is that full (384 rows: 3 x 8); else one
+    //    16-wave block of pairs up to 512 rows (300 rows: 10 of 16 waves have a pair); else the round-3 shapes below.
+    const int zz_nf = (a.max_alloc_len + 15) / 16, zz_pairs = (zz_nf + 1) / 2;
+    if (SGPT_ATTN_ZZ && a.dh == 64 && !a.out_fp8 && a.max_alloc_len > SGPT_ATTN_ZZ_MINLEN) {
+        const bool fit8 = zz_pairs <= 8 || zz_pairs % 8 == 0 || zz_pairs % 8 >= 6;
+        const bool consecutive_fit = zz_nf % 8 == 0 || zz_nf % 8 >= 6;
+        const int zw = SGPT_ATTN_ZZ_NW ? SGPT_ATTN_ZZ_NW : (fit8 ? 8 : ((!consecutive_fit && zz_pairs <= 16) ? 16 : 0));
+        if (zw != 0) {
+            dim3 gz((zz_pairs + zw - 1) / zw, a.H, a.B);
+            if (zw == 8) {
+                if (a.dtype == DT_F16) hipLaunchKernelGGL((attn16_lds_kernel<f16_t, 64, false, 2, 8, 0, false, true>), gz, dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((attn16_lds_kernel<bf16_t, 64, false, 2, 8, 0, false, true>), gz, dim3(512), 0, s, a);
+            } else {
+                if (a.dtype == DT_F16) hipLaunchKernelGGL((attn16_lds_kernel<f16_t, 64, false, 2, 16, 0, false, true>), gz, dim3(1024), 0, s, a);
+                else hipLaunchKernelGGL((attn16_lds_kernel<bf16_t, 64, false, 2, 16, 0, false, true>), gz, dim3(1024), 0, s, a);
+            }
+            return;
+        }
     }
     constexpr bool PIPE = SGPT_ATTN_PIPE != 0;
     const bool pipe = PIPE && a.dh == 64 && !a.out_fp8 && a.max_alloc_len > SGPT_ATTN_PIPE_MINLEN;
