@@ -566,6 +566,9 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     // k-step 0's MFMAs instead of sitting between two tiles: ~1 k cycles per tile on the critical path otherwise).
     int ntile = tile + gridDim.x, nm0 = 0, nn0 = 0;
     while (ntile < tiles_total && !tile_coords(ntile, nm0, nn0)) ntile += gridDim.x;
+    // EPI_SCORE_FILTER: the thresholds of this tile's rows, loaded under k-step 0 -- at the head of the epilogue they were an
+    // un-hidden L2 round trip per tile (behind the next tile's run-ahead DMA, which the compiler's vmcnt wait also retires)
+    float thv_pre[8];
     while (true) {
         const bool has_next = ntile < tiles_total;
         int n2tile = ntile, n2m0 = 0, n2n0 = 0;
@@ -623,6 +626,15 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
             }
             ss ^= 1;
             sd = sdn;
+            if constexpr (EPI == EPI_SCORE_FILTER) {
+                if (kt == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int m = m0 + wm * 128 + i * 16 + fr;
+                        thv_pre[i] = m < p.m_valid ? p.thr[(long)m * p.thr_ld] : INFINITY;
+                    }
+                }
+            }
             if (kt == 0 && has_next) {          // look up the tile after the next one (wave-uniform scalar work)
                 n2tile = ntile + gridDim.x;
                 while (n2tile < tiles_total && !tile_coords(n2tile, n2m0, n2n0)) n2tile += gridDim.x;

@@ -251,6 +251,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(const GemmArgs p) {
                 OutT* out = static_cast<OutT*>(p.out);
                 typename OutRange<OutT>::type range;
                 constexpr bool LO = false;                 // (split-precision outputs: 16-bit operand kernels only)
+                const float thv_pre[8] = {};               // (the scorer's filtered epilogue is never instantiated here)
 #include "gemm256_epilogue.inc"
                 range.finish(p.range_flag);
             } else {
