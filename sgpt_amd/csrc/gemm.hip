@@ -237,6 +237,29 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
         }
     };
 
+    // Query-sized launches (64x64 tiles) are a serial chain of a few microseconds.  The epilogue's bias / residual operands do
+    // not depend on the product, so they are fetched HERE, under the k-loop, instead of one dependent L2 round trip per 16x16
+    // piece at the end (the residual is updated in place: every piece's load also waited for the previous piece's store).
+    // Same values, same arithmetic: identical bits.
+    constexpr bool PRE = NI == 2 && SWAP && (EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_GELU || EPI == EPI_STORE || EPI == EPI_QKV);
+    float4 bpre[PRE ? NI : 1], rpre[(PRE && EPI == EPI_BIAS_RESID) ? NI : 1][NI];
+    if constexpr (PRE) {
+        if (kg == 0) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * (16 * NI) + j * 16 + 4 * g;
+                bpre[j] = (p.bias != nullptr && n + 3 < N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int m = m0 + wm * (16 * NI) + i * 16 + fr;
+                        rpre[i][j] = (m < p.m_valid && n + 3 < N) ? *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n)
+                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int d = 0; d < PF; ++d)
         if (d < nk) gload(d, d);
@@ -340,13 +363,18 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
                 const float bsc = EPI == EPI_BIAS_GELU ? 1.0f : om;
                 if constexpr (EPI == EPI_BIAS_RESID) {
                     // acc (* in_mul) + (bias + resid): the association of gemm256_kernel's epilogue, bit for bit
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                    const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
+                    float4 bb, rr;
+                    if constexpr (PRE) { bb = bpre[j]; rr = rpre[i][j]; }
+                    else {
+                        bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        rr = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n);
+                    }
                     v[0] = __builtin_fmaf(v[0], cs, bb.x + rr.x); v[1] = __builtin_fmaf(v[1], cs, bb.y + rr.y);
                     v[2] = __builtin_fmaf(v[2], cs, bb.z + rr.z); v[3] = __builtin_fmaf(v[3], cs, bb.w + rr.w);
                 } else if (EPI == EPI_BIAS_GELU || ((EPI == EPI_STORE || EPI == EPI_QKV) && p.bias != nullptr)) {
                     if (full) {
-                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        float4 bb;
+                        if constexpr (PRE) bb = bpre[j]; else bb = *reinterpret_cast<const float4*>(p.bias + n);
                         v[0] = __builtin_fmaf(v[0], cs, bb.x * bsc); v[1] = __builtin_fmaf(v[1], cs, bb.y * bsc);
                         v[2] = __builtin_fmaf(v[2], cs, bb.z * bsc); v[3] = __builtin_fmaf(v[3], cs, bb.w * bsc);
                     } else {       // ragged last column group (LM head: vocab % 4 != 0): no read past the bias array
