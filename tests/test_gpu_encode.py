@@ -418,27 +418,35 @@ def test_query_sized_and_bulk_batches_give_identical_bits(dtype):
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_long_sequences_attention_block_shapes_agree_and_match_the_oracle(dtype):
-    """head_dim 64, sequences of 460..700 tokens over global and local-window (256) layers: calls whose longest sequence
-    leaves the last 256-query block at least half full take the 16-wave / 256-query attention blocks, the others the
-    8-wave / 128-query ones (sgpt_amd/csrc/attn.hip::launch_attn_bf16).  The same sequence must come out bit-identical
-    from both (a wave's arithmetic does not depend on the block it sits in), and both must match the fp32 oracle."""
+    """head_dim 64, sequences of 300..700 tokens over global and local-window (256) layers.  The longest sequence of a call
+    picks the attention block shape (sgpt_amd/csrc/attn.hip::launch_attn_bf16): mirror pairs of query fragments in 8-wave
+    blocks (longest 700: 22 pairs), one 16-wave block of pairs (longest 300: 10 pairs), consecutive fragments in 8-wave
+    blocks (longest 600: 38 fragments) or in 16-wave blocks (longest 660: 42 fragments).  The same sequence must come out
+    bit-identical from all of them (a fragment's arithmetic does not depend on the wave or block it sits in), and the
+    results must match the fp32 oracle."""
     kw = dict(vocab_size=311, max_position_embeddings=768, hidden_size=128, num_layers=4, num_heads=2, window_size=256)
     m = build_model(kw, 5, 0.06, dtype)
     rng = np.random.default_rng(17)
     mk = lambda n: rng.integers(0, 311, size=n).tolist()  # noqa: E731
-    a600, a460, a512, a700 = mk(600), mk(460), mk(512), mk(700)
-    alone = m.encode_ids([a600], normalize=True).cpu().numpy()            # longest 600: (599 % 256) = 87 -> 128-query blocks
-    wide = m.encode_ids([a700, a600], normalize=True).cpu().numpy()       # longest 704 rows: (703 % 256) = 191 -> 256-query blocks
-    assert np.array_equal(alone[0], wide[1])
-    seqs = [a512, a460, a600, a700]
-    got = m.encode_ids(seqs, normalize=True).cpu().numpy()
-    assert np.array_equal(got[2], alone[0])
+    a300, a460, a512, a600, a660, a700 = mk(300), mk(460), mk(512), mk(600), mk(660), mk(700)
+    enc = lambda seqs: m.encode_ids(seqs, normalize=True).cpu().numpy()  # noqa: E731
+    c300 = enc([a300])                                   # 16-wave block of pairs
+    c600 = enc([a600, a300])                             # consecutive fragments, 8-wave blocks
+    c660 = enc([a660, a300, a600])                       # consecutive fragments, 16-wave blocks
+    seqs = [a700, a660, a600, a512, a460, a300]
+    got = enc(seqs)                                      # 8-wave blocks of pairs
+    for other in (c600[1], c660[1], got[5]):
+        assert np.array_equal(c300[0], other)
+    assert np.array_equal(c600[0], c660[2]) and np.array_equal(c600[0], got[2])
+    assert np.array_equal(c660[0], got[1])
+    only512 = enc([a512, a460])                          # longest 512: 16 pairs = two full 8-wave blocks
+    assert np.array_equal(only512, got[3:5])
+    a200, a384 = mk(200), mk(384)
+    assert np.array_equal(enc([a200])[0], enc([a384, a200])[1])   # 7 pairs in one 8-wave block | 24 consecutive fragments
     cfg = O.NeoConfig(**kw)
     ref = O.encode(O.synth_weights(cfg, seed=5, std=0.06), cfg, seqs, normalize_embeddings=True)
     tol = 5e-3 if dtype == "f16" else 3e-2
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
-    only512 = m.encode_ids([a512, a460], normalize=True).cpu().numpy()    # longest 512: (511 % 256) = 255 -> 256-query blocks
-    assert np.array_equal(only512, got[:2])
 
 
 def test_encode_graph_capture_and_replay():
