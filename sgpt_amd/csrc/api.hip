@@ -955,7 +955,12 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // nq <= 64 (the HBM-bound 64-row tile): same-box A/B of 512 / 1024 / 2048 entries at 1 M documents (profiles/r04_cap64_ab.txt):
     // nq = 16 0.39 / 0.36 / 0.365 ms, nq = 64 0.41 / 0.375 / 0.39 ms -- the sample is 6 % / 3 % / 1.5 % of the corpus stream, and
     // past 1024 entries the appends cost the streaming tile more than the smaller sample returns
-    const int cap_n = nq <= 64 ? (N >= 400000 ? 1024 : 512) : (N >= 800000 ? 2048 : (N >= 400000 ? 1024 : 512));
+    // (re-measured with the LDS-staged appends, nq = 1000: 125 k documents 0.28 / 0.36 / 0.40 ms with 512 / 1024 / 2048 entries,
+    //  250 k documents 0.51 / 0.50 / 0.58 -- the short lists stay)
+#ifndef SGPT_CAP_SHORT
+#define SGPT_CAP_SHORT 512
+#endif
+    const int cap_n = nq <= 64 ? (N >= 400000 ? 1024 : 512) : (N >= 800000 ? 2048 : (N >= 400000 ? 1024 : SGPT_CAP_SHORT));
     const int cap_s = cap_n * (k <= 32 ? 1 : 2) > 2048 ? 2048 : cap_n * (k <= 32 ? 1 : 2);
     const int cap = sampled_k ? cap_s : ((4 * k < 2048 - k) ? 4 * k : 2048 - k);
     const bool half_growth = 2 * cap < 5 * k;          // k > ~340: cap < 2.5 k -> grow by half, expect ~k/2 per chunk
