@@ -468,8 +468,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
                                float* out, float* hidden_out, float* layer_out, float* layer_mean, void* stream) {
     if (!m) return SGPT_ERR_INVALID;
     sgpt_ctx* c = m->ctx;
-    if (!ids || !pos || !seq_off || !seq_len || B <= 0 || T <= 0 || T % 128 || max_alloc <= 0 || max_alloc % 8)
-        return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad token layout (T_pad % 128, max_alloc_len % 8)");
+    if (!ids || !pos || !seq_off || !seq_len || B <= 0 || T <= 0 || T % 128 || max_alloc <= 0 || max_alloc % 2)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad token layout (T_pad % 128, max_alloc_len % 2)");
     if (n_layers_run < 0 || n_layers_run > m->d.n_layers) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: n_layers_run out of range");
     if (pool_mode < 0 || pool_mode > 3) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad pool_mode");
     if (pool_mode == SGPT_POOL_LEARNTMEAN && (out || layer_out || layer_mean)) {

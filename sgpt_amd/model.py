@@ -27,7 +27,12 @@ CREST_LIMIT_LN = 12.0
 CREST_LIMIT_H = 20.0
 PROBE_MAX_ROWS = 8192   # token rows of the probe forward (a bounded sample of the first call's sequences)
 
-ALIGN = 8          # sequence starts on the packed token axis: multiples of 8 rows (16-byte V^T tile loads in attention)
+# Sequence starts on the packed token axis: multiples of ALIGN rows.  The only kernel that cares is the attention's V^T tile
+# staging (16-byte loads along the token axis), and a dwordx4 load needs dword alignment = an EVEN token offset, not 16 bytes.
+# Round 4, same box (scripts/small_batch_profile.py / mid_batch_profile.py, bench.py varlen leg), ALIGN 8 / 4 / 2: 1000 queries of
+# 4..32 tokens 6.44 / 4.93 / 4.85 ms (21 760 / 19 968 / 18 944 padded rows), 128 queries 1.57 / 1.53 / 1.52 ms, lengths
+# U{16..128} 62.8 / 63.4 / 63.9 k sentences/s; bit-identical embeddings per sequence (a sequence's arithmetic does not see its offset).
+ALIGN = 2
 TOKEN_TILE = 256   # GEMM M tile (256x256 LDS-DMA kernel)
 
 

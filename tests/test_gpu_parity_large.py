@@ -106,7 +106,8 @@ def test_full_shape_cosine_and_ranked_top10_vs_reference(tag, dtype):
             m.calibrate(seqs[:: max(1, len(seqs) // 16)])                # calibrated on a slice of the case's own inputs
         # every projection of the call must take the 256x256 LDS-DMA kernel: more than half a wave of tiles for the
         # narrowest launch (N = d_model), sgpt_amd/csrc/gemm.hip::launch_gemm16
-        alloc = int(((lens + 7) // 8 * 8).sum())
+        from sgpt_amd.model import ALIGN
+        alloc = int(((lens + ALIGN - 1) // ALIGN * ALIGN).sum())
         T_pad = (alloc + 255) // 256 * 256
         assert alloc <= m.max_tokens_per_call and (T_pad // 256) * (scfg.hidden_size // 256) * 2 > 256, (alloc, T_pad)
         t = time.time()

@@ -64,19 +64,20 @@ def test_pack_host_layout():
     from sgpt_amd.model import pack_host, ALIGN
     seqs = [[5, 6, 7], list(range(1, 18)), [9] * 16, [1]]
     h = pack_host(seqs, pad_left=[2, 0, 0, 7])
-    assert h["B"] == 4 and h["T_pad"] % 256 == 0 and h["max_alloc"] == 24 and h["n_tokens"] == 37
+    up = lambda n: (n + ALIGN - 1) // ALIGN * ALIGN  # noqa: E731
+    assert h["B"] == 4 and h["T_pad"] % 256 == 0 and h["max_alloc"] == up(17) and h["n_tokens"] == 37
     off = h["seq_off"]
-    assert off.tolist() == [0, 8, 32, 48, 56] and all(o % ALIGN == 0 for o in off)
+    assert off.tolist() == [0, up(3), up(3) + up(17), up(3) + up(17) + 16, up(3) + up(17) + 16 + up(1)] and all(o % ALIGN == 0 for o in off)
     for b, s in enumerate(seqs):
         assert h["ids"][off[b]: off[b] + len(s)].tolist() == s
         assert h["pos"][off[b]: off[b] + len(s)].tolist() == [h["pad_left"][b] + t for t in range(len(s))]
-    assert h["ids"][3:8].tolist() == [0] * 5            # filler rows
+    assert h["ids"][3:off[1]].tolist() == [0] * (off[1] - 3)            # filler rows
     with pytest.raises(ValueError, match="Empty items should be cleaned prior to running"):
         pack_host([[1], []])
 
 
 def test_plan_batches_covers_everything_sorted():
-    from sgpt_amd.model import SGPTModel
+    from sgpt_amd.model import ALIGN, SGPTModel
     lens = np.random.default_rng(0).integers(1, 129, size=1000)
     fake = SGPTModel.__new__(SGPTModel)
     fake.max_tokens_per_call = 4096
@@ -86,7 +87,7 @@ def test_plan_batches_covers_everything_sorted():
     srt = lens[allidx]
     assert (np.diff(srt) <= 0).all()                    # longest first
     for sel in plan:
-        assert ((lens[sel] + 7) // 8 * 8).sum() <= 4096
+        assert ((lens[sel] + ALIGN - 1) // ALIGN * ALIGN).sum() <= 4096
 
 
 def test_text_pipeline_specb_matches_oracle_ids():
@@ -262,13 +263,13 @@ def test_crossencoder_host_logic_matches_oracle():
 
 def test_bucketed_layout_keeps_the_real_rows_and_appends_one_token_fillers():
     """pack_layout(bucket=(B_cap, T_cap, A_cap)) (EncodeGraph capacity buckets): the caller's sequences sit exactly where
-    the un-bucketed layout puts them; fillers are one-token sequences on their own 16-row allocations behind them."""
-    from sgpt_amd.model import pack_host
+    the un-bucketed layout puts them; fillers are one-token sequences on their own ALIGN-row allocations behind them."""
+    from sgpt_amd.model import ALIGN, pack_host
     rng = np.random.default_rng(0)
     for n in (1, 11, 16, 17, 40):
         seqs = [rng.integers(1, 100, size=int(rng.integers(1, 40))).tolist() for _ in range(n)]
         h0 = pack_host(seqs)
-        al = [(len(q) + 7) // 8 * 8 for q in seqs]
+        al = [(len(q) + ALIGN - 1) // ALIGN * ALIGN for q in seqs]
         b = (max(16, 1 << (n - 1).bit_length()), (sum(al) + 8 * 64 + 255) // 256 * 256, max(32, 1 << (max(al) - 1).bit_length()))
         h = pack_host(seqs, bucket=b)
         assert (h["B"], h["T_pad"], h["max_alloc"], h["n_real"], h["n_tokens"]) == (b[0], b[1], b[2], n, h0["n_tokens"])
@@ -276,7 +277,7 @@ def test_bucketed_layout_keeps_the_real_rows_and_appends_one_token_fillers():
         n0 = int(h0["seq_off"][-1])
         assert (h["ids"][:n0] == h0["ids"][:n0]).all() and (h["pos"][:n0] == h0["pos"][:n0]).all()
         assert (h["ids"][n0:] == 0).all() and (h["pos"][n0:] == 0).all()
-        assert (h["seq_len"][n:] == 1).all() and (np.diff(h["seq_off"][n:]) == 8).all() and h["seq_off"][-1] <= b[1]
+        assert (h["seq_len"][n:] == 1).all() and (np.diff(h["seq_off"][n:]) == ALIGN).all() and h["seq_off"][-1] <= b[1]
         pl = list(range(n))
         h2 = pack_host(seqs, pl, bucket=b)
         assert (h2["pad_left"][:n] == pl).all() and (h2["pad_left"][n:] == 0).all() and h2["max_pos"] == pack_host(seqs, pl)["max_pos"]
