@@ -13,6 +13,6 @@ BENCH_STEPS=3 bash scripts/gpu_prof.sh > gpurun_out/prof.log 2>&1; head -12 gpur
 ( for n in 1000000 500000 250000 125000; do N=$n python scripts/score_bench.py; done; for nq in 128 64 16; do NQ=$nq python scripts/score_bench.py; done; for dr in 0.1 0.3 0.6 0.9; do echo -n "DRIFT=$dr "; DRIFT=$dr python scripts/score_bench.py; done; echo -n "K=101 "; K=101 python scripts/score_bench.py; echo -n "K=1001 "; K=1001 python scripts/score_bench.py; echo -n "K=1001 N=125000 "; K=1001 N=125000 python scripts/score_bench.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_bench.txt
 bash scripts/score_prof.sh > gpurun_out/score_prof.log 2>&1; head -8 gpurun_out/score_prof_summary.csv | cut -c1-200
 ( for nq in 1 16 128; do LL=0 NQ=$nq python scripts/small_batch_profile.py 2>&1 | grep "per encode"; done; python scripts/query_side_breakdown.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/query_side.txt
-# (calls of at most 131 072 ALLOCATED rows: 430 x 304 at S = 300 -- 436 x 304 would split every call in two)
-( for cfg in "300 1720 430" "512 1024 256"; do set -- $cfg; timeout 300 python bench.py --seq $1 --chunk $2 --call $3 --steps 4 --warmup 1 --no-cpu-baseline --no-1m --no-varlen --no-modes 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('seq', $1, d['value'], 'sent/s', d['roofline']['end_to_end_frac_of_mfma_roofline'])"; done ) | tee gpurun_out/seq_lengths.txt
+# (calls of at most 131 072 allocated rows: 436 x 300 at S = 300 since sequences are packed on even rows)
+( for cfg in "300 1744 436" "512 1024 256"; do set -- $cfg; timeout 300 python bench.py --seq $1 --chunk $2 --call $3 --steps 4 --warmup 1 --no-cpu-baseline --no-1m --no-varlen --no-modes 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('seq', $1, d['value'], 'sent/s', d['roofline']['end_to_end_frac_of_mfma_roofline'])"; done ) | tee gpurun_out/seq_lengths.txt
 ( timeout 600 python bench.py --model 1.3b --no-cpu-baseline --no-1m --no-varlen --no-modes 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('1.3b', d['value'], 'sent/s', d['roofline']['end_to_end_frac_of_mfma_roofline'], d['config'].get('precise_qk'))" ) | tee gpurun_out/model_13b.txt
