@@ -214,6 +214,7 @@ struct GemmArgs {
     int m_valid;        // rows >= m_valid are computed from clamped reads and not stored
     int skew;           // persistent kernel: start-up stagger (shader cycles per phase), see gemm256_kernel
     int gm, gn;         // gemm256d: supertile shape in tiles (major x minor); 0 = default 4 x 8
+    int balanced;       // gemm256d: 1 = few-round launch -- every XCD takes a contiguous, equally long run of the tile list (set by the launcher)
     const int* pred;    // device flag or null: the kernel exits at once when *pred == 0 (sync-free fallback launches)
     // EPI_SCORE_FILTER
     const float* thr;   // per-query threshold thr[m * thr_ld] (the running k-th best score; -inf = keep all)

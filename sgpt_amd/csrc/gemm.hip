@@ -131,20 +131,33 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void gemm_kernel(const G
 
     const int M = p.M, N = p.N, K = p.K;
     const int MT = (M + BM - 1) / BM, NT = (N + BN - 1) / BN;
-    // XCD-aware supertile order (block b runs on XCD b%8, ~64 blocks resident per XCD):
-    // XCD x owns M-tiles x, x+8, ...; its blocks walk GM x GN supertiles so the ~64 co-resident
-    // blocks share GM activation panels and GN weight panels (<= 16 x 192 KiB, fits the 4 MiB L2).
+    // XCD-aware block order (block b runs on XCD b%8, ~64 blocks resident per XCD).
+    // More than one resident round (MT NT > 512): XCD x owns M-tiles x, x+8, ...; its blocks walk GM x GN supertiles so the ~64
+    // co-resident blocks share GM activation panels and GN weight panels (<= 16 x 192 KiB, fits the 4 MiB L2).
+    // Query-sized launches (at most 512 tiles, everything fits the L2s): XCD x takes a contiguous run of the M-major tile list,
+    // runs equal to within one tile -- the supertile order hands XCD x NT x ceil or floor(MT / 8) tiles (8 x 12 tiles: 12 per
+    // XCD either way, but 44 x 12: 72 against 60), and a launch that fits one round must not spill into a second on half of
+    // the chip.  Round 4, same box: 16 queries 0.793 -> 0.764 ms; with the runs also on larger launches 300 queries 2.61 -> 2.70 ms
+    // (a run of 64 consecutive tiles of a 48-tile-wide launch streams the whole weight matrix through the L2), hence the limit.
     const int b = blockIdx.x;
     const int xcd = b & 7, local = b >> 3;
-    constexpr int GM = 8, GN = 8;
-    const int per_band = GM * NT;              // blocks per band of GM M-tiles
-    const int band = local / per_band, inb = local % per_band;
-    const int ng = inb / (GM * GN);            // N-group inside the band
-    const int gn = (NT - ng * GN) < GN ? (NT - ng * GN) : GN;   // width of this N-group
-    const int r = inb - ng * GM * GN;
-    const int mi = r / gn, ni = r % gn;
-    const int mt = xcd + 8 * (band * GM + mi), nt = ng * GN + ni;
-    if (mt >= MT) return;
+    int mt, nt;
+    if (MT * NT <= 512) {
+        const int R = MT * NT, c0 = R >> 3, rem = R & 7;
+        if (local >= c0 + (xcd < rem ? 1 : 0)) return;
+        const int gi = xcd * c0 + (xcd < rem ? xcd : rem) + local;
+        mt = gi / NT; nt = gi - mt * NT;
+    } else {
+        constexpr int GM = 8, GN = 8;
+        const int per_band = GM * NT;              // blocks per band of GM M-tiles
+        const int band = local / per_band, inb = local % per_band;
+        const int ng = inb / (GM * GN);            // N-group inside the band
+        const int gn = (NT - ng * GN) < GN ? (NT - ng * GN) : GN;   // width of this N-group
+        const int r = inb - ng * GM * GN;
+        const int mi = r / gn, ni = r % gn;
+        mt = xcd + 8 * (band * GM + mi); nt = ng * GN + ni;
+        if (mt >= MT) return;
+    }
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int t = threadIdx.x & 255;
@@ -487,8 +500,21 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     const bool m_major = MT >= NT;
     const int AT = m_major ? MT : NT, BT = m_major ? NT : MT;
     const int per_band = GM * BT;
-    const int tiles_total = ((AT + 7) / 8 + GM - 1) / GM * GM * 8 * BT;
+    // Few-round launches (p.balanced, mid-size batches): the supertile order gives XCD x the A-tiles x, x+8, ... -- BT x
+    // ceil or floor(AT / 8) tiles -- and a launch of 85 x 3 tiles put 33 on five XCDs' 32 CUs: a second round for 3 tiles
+    // (the "lone round costs 1.67 x" of round 3).  Here XCD x takes a contiguous run of the A-major tile list instead, runs that
+    // differ by at most one tile; the B-tiles of one A-tile still sit next to each other on one XCD.
+    const int R = AT * BT, c0 = R >> 3, rem = R & 7;
+    const int tiles_total = p.balanced ? 8 * ((R + 7) >> 3) : ((AT + 7) / 8 + GM - 1) / GM * GM * 8 * BT;
     auto tile_coords = [&](int tile, int& m0, int& n0) -> bool {
+        if (p.balanced) {
+            const int xcd = tile & 7, l = tile >> 3;
+            if (l >= c0 + (xcd < rem ? 1 : 0)) return false;
+            const int gi = xcd * c0 + (xcd < rem ? xcd : rem) + l;
+            const int at = gi / BT, bt = gi - at * BT;
+            m0 = (m_major ? at : bt) * TM; n0 = (m_major ? bt : at) * TN;
+            return true;
+        }
         const int xcd = tile & 7, local = tile >> 3;
         const int band = local / per_band, inb = local % per_band;
         const int ng = inb / (GM * GN);
@@ -705,7 +731,8 @@ void launch256d(const GemmArgs& a, hipStream_t s, bool deep_a) {
     if (env_gn > 0) b.gn = env_gn;
 #endif
     const int gm = b.gm > 0 ? b.gm : 4;
-    const int tiles_pad = ((AT + 7) / 8 + gm - 1) / gm * gm * 8 * BT;
+    b.balanced = (long)AT * BT <= 4L * ncu ? 1 : 0;        // up to ~4 rounds: XCD-balanced tile runs (see the kernel)
+    const int tiles_pad = b.balanced ? 8 * ((AT * BT + 7) / 8) : ((AT + 7) / 8 + gm - 1) / gm * gm * 8 * BT;
     // a.cu_cap (per ctx): leave CUs to a second pipeline on another stream (its LayerNorm / attention / embed kernels run on
     // the free CUs while this launch is in its k-loops); multiples of 8 keep the XCD interleave of the tile order
     const int cus = (a.cu_cap >= 8 && a.cu_cap < ncu) ? a.cu_cap / 8 * 8 : ncu;
@@ -945,7 +972,8 @@ void launch(const GemmArgs& a, hipStream_t s) {
     const int MT = (a.M + B - 1) / B, NT = (a.N + B - 1) / B;
     const int mt_per_xcd = (MT + 7) / 8;
     const int bands = (mt_per_xcd + 7) / 8;
-    const int grid = 8 * bands * 8 * NT;
+    // (at most 512 tiles: XCD x = blocks x, x+8, ... walks its own run of the tile list; else the supertile order -- gemm_kernel)
+    const int grid = (long)MT * NT <= 512 ? 8 * ((MT * NT + 7) / 8) : 8 * bands * 8 * NT;
     // Query-sized launches (at most one resident round of 64x64 tiles: 2 workgroups x 256 CUs) walk 128-element k-steps
     // (CHS = 16): half as many load -> LDS -> MFMA round trips on each tile's serial chain, same MFMA order per output
     // element, so results stay bit-identical.  16-query encode (512 token rows) 0.97 -> 0.82 ms; with more tiles than that
