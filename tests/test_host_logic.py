@@ -408,3 +408,39 @@ def test_one_rccl_per_process_and_it_exports_what_comm_hip_calls():
     if hdr is not None:
         m = re.search(r"#define\s+NCCL_MAJOR\s+(\d+)", hdr)
         assert m and int(m.group(1)) == v.value // 10000, (m.group(1) if m else None, v.value)
+
+
+def test_xcd_balanced_tile_runs_cover_every_tile_once():
+    """The block -> tile maps of sgpt_amd/csrc/gemm.hip restated (gemm256d_kernel with GemmArgs.balanced, gemm_kernel at <= 512
+    tiles): block / tile index t runs on XCD t % 8 and takes entry t // 8 of that XCD's contiguous run of the major-axis-first
+    tile list.  Every tile exactly once, runs equal to within one tile, for the grids the launchers compute."""
+    def run_tile(R, t):
+        c0, rem = R >> 3, R & 7
+        xcd, l = t & 7, t >> 3
+        if l >= c0 + (1 if xcd < rem else 0):
+            return None
+        return xcd * c0 + min(xcd, rem) + l
+
+    for AT in list(range(1, 40)) + [73, 74, 85, 128, 219]:
+        for BT in (1, 2, 3, 4, 6, 9, 12):
+            R = AT * BT
+            if R > 1024:
+                continue
+            tiles_pad = 8 * ((R + 7) // 8)
+            # gemm_kernel: one block per index; gemm256d_kernel: block b of `grid` walks b, b + grid, ... (grid a multiple of 8)
+            for grid in (tiles_pad, min(tiles_pad, 256)):
+                seen, per_xcd = [], [0] * 8
+                for b in range(grid):
+                    t = b
+                    while t < tiles_pad:
+                        assert t % 8 == b % 8                      # a block never leaves its XCD
+                        g = run_tile(R, t)
+                        if g is not None:
+                            seen.append(g)
+                            per_xcd[t % 8] += 1
+                        t += grid
+                assert sorted(seen) == list(range(R)), (AT, BT, grid)
+                assert max(per_xcd) - min(per_xcd) <= 1
+                # the B-tiles of one A-tile are neighbours in the list, so they share an XCD except where a run ends
+                at_of = lambda g: g // BT  # noqa: E731
+                assert all(at_of(a) <= at_of(b2) for a, b2 in zip(sorted(seen), sorted(seen)[1:]))
