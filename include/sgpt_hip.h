@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPT_ABI_VERSION 6
+#define SGPT_ABI_VERSION 7
 
 typedef int sgpt_status;
 #define SGPT_OK 0
@@ -280,6 +280,12 @@ sgpt_status sgpt_range_check(sgpt_ctx* ctx, int32_t* flagged, int32_t reset, voi
 enum { SGPT_PC_LN1 = 0, SGPT_PC_ATT = 1, SGPT_PC_CTX = 2, SGPT_PC_LN2 = 3, SGPT_PC_H = 4 };
 sgpt_status sgpt_model_set_precision(sgpt_model* model, const int32_t* plan, int32_t n);
 sgpt_status sgpt_model_get_precision(sgpt_model* model, int32_t* plan, int32_t n);
+/* sgpt_model_release_split_weights: give the [W_hi | W_hi | W_lo] copies of sgpt_model_desc.split_weights back (3 x the 16-bit
+ *   weight bytes: +0.5 GB at SGPT-125M, +35 GB at GPT-J-6B shape) once the plan is known not to need them -- what the host does when
+ *   the probe of precision='auto' settles on plain operands.  Refused while the installed plan reads them; afterwards
+ *   sgpt_model_set_precision refuses plans that would, exactly as for a model loaded without split_weights.  bytes_freed may
+ *   be NULL.  (The reference keeps one fp32 copy of the weights: `AutoModel.from_pretrained`, beir_dense_retriever.py:123.) */
+sgpt_status sgpt_model_release_split_weights(sgpt_model* model, int64_t* bytes_freed);
 sgpt_status sgpt_model_precision_probe_begin(sgpt_model* model);
 sgpt_status sgpt_model_precision_probe_end(sgpt_model* model, float* crest_out /* host float[4 * n_layers] or NULL */);
  /* sgpt_row_crest: the probe's statistic for caller-owned 16-bit rows [n, d] (leading dimension ld): max over the rows of

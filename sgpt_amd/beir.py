@@ -216,6 +216,17 @@ class DenseRetrievalExactSearch:
         nq = len(query_ids)
         self.results = {qid: {} for qid in query_ids}
         qlist = [(qid, queries[qid]) for qid in queries]
+        sgpt = getattr(self.model, "model", None)
+        if comm is not None and hasattr(sgpt, "sync_precision") and hasattr(self.model, "tokenize") and qlist:
+            # precision='auto' settles from the first sequences a process encodes -- a different query slice and corpus shard
+            # on every rank.  Decide ONCE for the group, before anything is encoded: every rank probes a bounded sample of its
+            # own queries, the flags are max-reduced, every rank installs the same plan (and logs it).
+            from .dist import max_reducer
+            own = qlist[rank::world][:64] or qlist[:64]
+            sgpt.sync_precision(self.model.tokenize([q for (_, q) in own], True), max_reducer(ctx, self.group))
+        if getattr(sgpt, "precision_report", None):
+            rep = sgpt.precision_report
+            logger.info("Encoder precision: %s (%s; %d operand classes flagged)", rep["decided"], rep["probed"], rep["flagged"])
         if comm is not None and (nq >= 4 * world or world == 1):
             # this rank's contiguous slice of the queries (cuts balanced on text length, never empty: an empty slice has no
             # embedding width to contribute and would leave the other ranks waiting in the collective), then ONE all-gather.

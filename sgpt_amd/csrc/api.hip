@@ -1006,7 +1006,13 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     // sampled schedule: an overflow needs an adversarial mass of near-equal scores now, so the fallback is sized for few
     // no-op launches (a predicated 256x256 launch that exits at once still costs ~4.4 us, two per piece: ~60 of them were
     // 0.05-0.08 ms of a 1 M-document pass) rather than for the cache: pieces of up to 131 072 documents
-    if (sampled && fchunk < 131072) fchunk = 131072;
+    // -- but never beyond a byte budget: the tile is allocated whether or not a fallback ever runs (nq = 10 000 x 131 072 x 4 B
+    // would be 5 GB of workspace for launches that exit at once)
+    if (sampled && fchunk < 131072) {
+        const long by_bytes = (long)(((size_t)512 << 20) / ((size_t)nq * 4)) / 256 * 256;
+        const long want = by_bytes < 131072 ? by_bytes : 131072;
+        if (fchunk < want) fchunk = want;
+    }
     if (fchunk > (long)align_up((size_t)N, 256)) fchunk = (long)align_up((size_t)N, 256);
     if (fchunk < chunk) fchunk = chunk;
     const long n_flags = 64 + N / (1L << 19) + 1;      // one overflow flag per filtered chunk
@@ -1382,6 +1388,46 @@ sgpt_status sgpt_model_set_precision(sgpt_model* m, const int32_t* plan, int32_t
 sgpt_status sgpt_model_get_precision(sgpt_model* m, int32_t* plan, int32_t n) {
     if (!m || !plan || n != m->d.n_layers * PC_N) return m ? fail(m->ctx, SGPT_ERR_INVALID, "sgpt_model_get_precision: n must be 5 * n_layers") : SGPT_ERR_INVALID;
     for (int i = 0; i < n; ++i) plan[i] = m->prec[i];
+    return SGPT_OK;
+}
+
+// The [W_hi | W_hi | W_lo] copies of sgpt_model_desc.split_weights are 3 x the 16-bit weight bytes on top of the plain copy
+// (+35 GB at GPT-J-6B shape).  A model whose probe settled on plain operands gives them back here; a later plan
+// that needs them is refused by sgpt_model_set_precision as for a model loaded without them.  The round-3 qk_split copies
+// (q and k rows) stay when a plan entry still reads them.
+sgpt_status sgpt_model_release_split_weights(sgpt_model* m, int64_t* bytes_freed) {
+    if (!m) return SGPT_ERR_INVALID;
+    sgpt_ctx* c = m->ctx;
+    if (bytes_freed) *bytes_freed = 0;
+    if (!m->split_all) return SGPT_OK;
+    bool qk_used = false;
+    for (int i = 0; i < m->d.n_layers; ++i)
+        for (int cls = 0; cls < PC_N; ++cls) {
+            const int v = m->prec[(size_t)i * PC_N + cls];
+            if (v == 0 || cls == PC_ATT) continue;
+            if (cls == PC_LN1 && (v == 1 || v == 3)) { qk_used = true; continue; }
+            return fail(c, SGPT_ERR_INVALID, "sgpt_model_release_split_weights: the installed precision plan reads the split copies");
+        }
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipDeviceSynchronize());
+    const size_t dm = m->d.d_model, ffn = m->d.d_ffn;
+    int64_t freed = 0;
+    auto drop = [&](void*& p, size_t bytes) {
+        if (!p) return;
+        for (size_t i = 0; i < m->allocs.size(); ++i)
+            if (m->allocs[i] == p) { m->allocs[i] = m->allocs.back(); m->allocs.pop_back(); break; }
+        (void)hipFree(p);
+        p = nullptr;
+        freed += (int64_t)bytes;
+    };
+    for (int i = 0; i < m->d.n_layers; ++i) {
+        LayerW& l = m->L[i];
+        drop(l.w_o3, dm * 3 * dm * 2); drop(l.w_fc3, ffn * 3 * dm * 2); drop(l.w_proj3, dm * 3 * ffn * 2);
+        if (!qk_used) drop(l.w_qkv3, 3 * dm * 3 * dm * 2);
+    }
+    m->split_all = false;
+    c->generation++;
+    if (bytes_freed) *bytes_freed = freed;
     return SGPT_OK;
 }
 

@@ -512,7 +512,7 @@ void attn16_lds_kernel(const AttnArgs p) {
             for (int h = 0; h < 16 / RPI; ++h) {
                 const int row = h * RPI + lane / CPR, ch = lane % CPR;
                 const uint4 v = *reinterpret_cast<const uint4_a*>(os + row * ORS + ch * 16);
-                if (qf0 + row < alloc) gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);   // (allocations are multiples of 8 rows)
+                if (qf0 + row < alloc) gstore16<ATTN_NT>(obase + (long)row * p.ldo + ch * 8, v);   // (rows past the allocation -- an even row count since round 4 -- are the next sequence's)
             }
             if constexpr (MODE != 0) {
                 if (p.ctx_lo_delta != 0) {

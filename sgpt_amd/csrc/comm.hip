@@ -52,7 +52,11 @@ const Rccl& rccl() {
         if (const char* rp = getenv("ROCM_PATH")) { names.push_back(std::string(rp) + "/lib/librccl.so.1"); }
         names.push_back("/opt/rocm/lib/librccl.so.1");
         for (const auto& n : names) if (!h) h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
-        if (!h) { r.err = std::string("librccl.so.1 not found (") + (dlerror() ? dlerror() : "") + "): the multi-GPU exchange steps need RCCL"; return r; }
+        if (!h) {
+            const char* e = dlerror();      // (one call: dlerror() clears the state it returns)
+            r.err = std::string("librccl.so.1 not found (") + (e ? e : "") + "): the multi-GPU exchange steps need RCCL";
+            return r;
+        }
 #define SGPT_SYM(field, name)                                                                   \
         r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, #name));                            \
         if (!r.field && r.err.empty()) r.err = std::string("librccl does not export ") + #name;

@@ -123,13 +123,13 @@ __device__ __forceinline__ void gstore16(void* ptr, uint4 v) {
 
 template <bool NT>
 __device__ __forceinline__ uint4 ldg16u(const void* ptr) {
-    if constexpr (NT) {
-        typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4)));
-        const u32x4v_t w = __builtin_nontemporal_load(reinterpret_cast<const u32x4v_t*>(ptr));
-        return make_uint4(w[0], w[1], w[2], w[3]);
-    } else {
-        return *reinterpret_cast<const uint4*>(ptr);
-    }
+    // dword-aligned source (sequences start on even rows of the token axis: a V^T tile row begins on a 4-byte boundary, not a
+    // 16-byte one): the vector type carries aligned(4), so the compiler may not assume more; global_load_dwordx4 needs no more
+    typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4), aligned(4)));
+    u32x4v_t w;
+    if constexpr (NT) w = __builtin_nontemporal_load(reinterpret_cast<const u32x4v_t*>(ptr));
+    else w = *reinterpret_cast<const u32x4v_t*>(ptr);
+    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 template <bool NT>

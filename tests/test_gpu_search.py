@@ -195,6 +195,22 @@ def test_st_encode_and_useb_semb_fn():
     assert isinstance(lst, list) and len(lst) == 3
     tokemb = st.encode(sents, output_value="token_embeddings")
     assert [e.shape[0] for e in tokemb] == [3, 5, 1]
+    # output_value=None: every output of the module chain, one dict per sentence (SentenceTransformer.py:242-246)
+    rows = st.encode(sents, output_value=None, convert_to_numpy=True)       # (conversion flags are ignored for it, :133-135)
+    assert isinstance(rows, list) and len(rows) == 3 and set(rows[0]) == {"input_ids", "attention_mask", "token_embeddings", "sentence_embedding"}
+    for r_, s_, te in zip(rows, sents, tokemb):
+        assert r_["input_ids"].tolist() == tok.convert_tokens_to_ids(tok.tokenize(s_)) and int(r_["attention_mask"].sum()) == len(r_["input_ids"])
+        assert torch.equal(r_["token_embeddings"], te)
+    assert maxabs(torch.stack([r_["sentence_embedding"] for r_ in rows]).cpu().numpy(), want) < 1e-3
+    assert set(st.encode("paris", output_value=None)) == set(rows[0])                # single string -> one dict
+    # device / num_proc (SentenceTransformer.py:110-127,180-203): honoured where they mean this GPU / this process, refused loudly otherwise
+    assert np.array_equal(st.encode(sents, device="cuda:0", num_proc=1), out) and np.array_equal(st.encode(sents, device="cuda"), out)
+    with pytest.raises(ValueError, match="resident on"):
+        st.encode(sents, device="cpu")
+    with pytest.raises(ValueError, match="num_proc"):
+        st.encode(sents, num_proc=2)
+    with pytest.raises(ValueError, match="output_value"):
+        st.encode(sents, output_value="pooler_output")
     # USEB closure: torch.Tensor[len, d] on the CPU (useb_dense_retriever.py:455-497)
     fn = make_semb_fn(UsebEmbedder(m, tok, method="weightedmean"))
     r = fn(sents, dataset_name="askubuntu", add_name="", idx=0)
