@@ -11,5 +11,5 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
 done
 cd $R
 python scripts/pmc_summary.py gpurun_out/pmc_FETCH_SIZE/pmc_results.db gpurun_out/pmc_WRITE_SIZE/pmc_results.db "gpurun_out/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_results.db" | tee gpurun_out/pmc_summary.csv
-python scripts/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/pmc_results.db gpurun_out/pmc_WRITE_SIZE/pmc_results.db > gpurun_out/pmc_traffic.json || echo "pmc_traffic failed"
+python scripts/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/pmc_results.db gpurun_out/pmc_WRITE_SIZE/pmc_results.db gpurun_out/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_results.db > gpurun_out/pmc_traffic.json || echo "pmc_traffic failed"
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_SQ_VALU_MFMA_BUSY_CYCLES

@@ -84,7 +84,31 @@ def build(force=False, verbose=False):
         # librccl.so.1 -- and checking its NCCL major version against the header it was compiled with).  A single-GPU user
         # needs no RCCL to build or load the library; rccl.h (types only) comes from the ROCm include directory.
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+    build_host(force=force, verbose=verbose)
     return LIB
+
+
+HOST_EXT = os.path.join(LIBDIR, "_sgpt_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """The CPython helper of the host leg (csrc/host_assemble.c: the k = 1001 result dict in C), gcc against this
+    interpreter's headers.  Optional: beir.assemble_results falls back to its Python form when the file is absent."""
+    import shutil
+    import sysconfig
+    src = os.path.join(CSRC, "host_assemble.c")
+    inc = sysconfig.get_paths()["include"]
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    if not cc or not os.path.exists(os.path.join(inc, "Python.h")):
+        return None
+    if force or _stale(HOST_EXT, [src, os.path.abspath(__file__)]):
+        cmd = [cc, "-O2", "-shared", "-fPIC", "-Wall", "-I", inc, src, "-o", HOST_EXT]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host extension build failed:\n" + r.stdout + r.stderr)
+    return HOST_EXT
 
 
 if __name__ == "__main__":

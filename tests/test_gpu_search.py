@@ -1,6 +1,7 @@
 """-m gpu: the drop-in adapters (DenseRetrievalExactSearch.search, CustomEmbedder, semantic_search,
 SentenceTransformer-style encode, USEB semb_fn) against the reference's golden outputs and the oracle."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -413,3 +414,105 @@ def test_crossencoder_bloom_tied_head():
     got = np.asarray(loglikelihood_tokens(reqs, m, 64))
     assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-3
     m.close()
+
+
+class _IdTokenizer:
+    """text = space-separated decimal token ids: the three tokenizer calls the reference makes (tokenize, convert_tokens_to_ids,
+    encode -- beir_dense_retriever.py:167-198) reproduce the fixture's ids exactly, so the text API can be driven with the
+    reference fixture's sequences."""
+    eos_token_id = pad_token_id = 50256
+
+    def tokenize(self, text):
+        return text.split()
+
+    def convert_tokens_to_ids(self, tokens):
+        return [int(t) for t in tokens]
+
+    def encode(self, text, add_special_tokens=False):
+        return [int(t) for t in text.split()]
+
+
+@pytest.mark.parametrize("fn", ["cos_sim", "dot"])
+@pytest.mark.parametrize("score_dtype", ["default", "f16"])
+def test_search_in_the_default_f16_mode_vs_the_reference_fixture(fn, score_dtype, tmp_path, monkeypatch):
+    """VERDICT r04 missing-3 / next-2b: text -> ids -> encode -> chunked search -> result dict through the drop-in classes in
+    the DEFAULT mode of the adapter (CustomEmbedder dtype='f16', SGPTModel precision='auto'; DenseRetrievalExactSearch's
+    score_dtype default = fp32 rows on the exact-fp32 scorer, and the opt-in 16-bit corpus), at SGPT-125M shape, for BOTH score
+    functions, against the reference stack's own numbers: tests/golden/cfg2_125m_1024x128.npz = HF GPTNeoModel fp32 -> the
+    reference's Pooling.py -> util.cos_sim / dot_score -> exact_search's top-(k+1) rule (oracle.exact_search, pinned against the
+    reference's exact_search.py by tests/golden/make_golden.py).  Covered rules: corpus sorted by text length (:66-70), chunk
+    loop + heap merge (:80-132), top_k+1 kept (:104,126), corpus_id != query_id (:118), NaN -> -1 (:99; one document's embedding is
+    poisoned with NaN on both sides).
+    Tolerances.  cos_sim: the north_star bar, 1e-3 absolute.  dot: the reference's dot scores of these un-normalised pooled rows
+    are |q||d| cos with |q||d| ~ 1e2..1e3, so an absolute bar is meaningless; the encoder's deviation is RELATIVE to the row norms
+    (f16 operands: <= 4e-3 absolute on O(1-3) elements = ~1.3e-3 of the norm, tests/test_gpu_parity_cfg2.py `rel`), so dot is held to
+    DOT_REL x |q||d| with DOT_REL = 2e-3 (two rows' relative errors add) -- measured values are printed."""
+    from sgpt_amd import SGPTConfig, SGPTModel
+    from sgpt_amd.beir import CustomEmbedder, DenseRetrievalExactSearch
+    from helpers import oracle_cfg_weights
+    monkeypatch.chdir(tmp_path)
+    fx = np.load(os.path.join(GOLDEN, "cfg2_125m_1024x128.npz"))
+    DOT_REL, BAR, top_k, chunk = 2e-3, 1e-3, 10, 300
+    key = ("default-mode-125m",)
+    if key not in _default_models:
+        _, w = oracle_cfg_weights(dict(O.SGPT_125M), 1, 0.02)
+        _default_models[key] = SGPTModel(SGPTConfig(**O.SGPT_125M), w, device="cuda:0")          # every default: f16, precision='auto'
+    m = _default_models[key]
+    assert m.dtype == "f16" and m.precision == "auto"
+
+    class Poisoned(CustomEmbedder):            # one document comes back as NaN: the scorer must rank it as -1 (exact_search.py:99)
+        def encode_corpus_device(self, corpus, **kw):
+            e = super().encode_corpus_device(corpus, **kw)
+            for r, (cid, _) in enumerate(corpus):
+                if cid == "d17":
+                    e = e.clone()
+                    e[r] = float("nan")
+            return e
+    emb = Poisoned(model_name="synthetic/sgpt-125m", model=m, tokenizer=_IdTokenizer(), method="weightedmean", dataset="unit")
+    assert emb.model.dtype == "f16"
+    docs, qlens = fx["doc_ids"], fx["query_lens"].tolist()
+    corpus = {f"d{i}": {"title": "", "text": " ".join(map(str, docs[i].tolist()))} for i in range(docs.shape[0])}
+    queries = {(f"q{i}" if i % 7 else f"d{3 * i}"): " ".join(map(str, fx["query_ids"][i, :n].tolist())) for i, n in enumerate(qlens)}
+    assert sum(q in corpus for q in queries) >= 10                                  # query ids that collide with corpus ids (:118)
+    kw = {} if score_dtype == "default" else {"score_dtype": torch.float16}
+    dres = DenseRetrievalExactSearch(emb, corpus_chunk_size=chunk, **kw)
+    assert dres.score_dtype == (torch.float32 if score_dtype == "default" else torch.float16)
+    res = dres.search(corpus, queries, top_k, fn)
+    assert m.precision_report["decided"] == "plain"                                # a clean checkpoint: the probe keeps plain f16 operands
+
+    # the reference side, on the reference's own fp32 embeddings of the same ids
+    cids = sorted(corpus, key=lambda c: len(corpus[c]["title"] + corpus[c]["text"]), reverse=True)
+    pos = np.array([int(c[1:]) for c in cids])
+    ref_d, ref_q = fx["doc_emb"][pos].copy(), fx["query_emb"]
+    ref_d[cids.index("d17")] = np.nan
+    qids = list(queries)
+    want = O.exact_search(ref_q, qids, ref_d, cids, top_k, fn, chunk_size=chunk)
+    sc = (O.cos_sim(ref_q, ref_d) if fn == "cos_sim" else O.dot_score(ref_q, ref_d)).astype(np.float64)
+    sc[np.isnan(sc)] = -1
+    qn, dn = np.linalg.norm(ref_q, axis=1), np.linalg.norm(np.nan_to_num(ref_d), axis=1)
+    col = {c: j for j, c in enumerate(cids)}
+    worst, worst_rel, same = 0.0, 0.0, 0
+    for qi, qid in enumerate(qids):
+        got, ref = res[qid], want[qid]
+        assert qid not in got and "d17" not in got                                  # self-match dropped; the NaN document ranks at -1
+        assert len(got) == len(ref) and len(got) in (top_k, top_k + 1)             # top_k+1 kept, minus a dropped self-match
+        kth = min(ref.values())
+        for cid, s in got.items():
+            j = col[cid]
+            scale = 1.0 if fn == "cos_sim" else float(qn[qi] * dn[j])
+            tol = BAR if fn == "cos_sim" else DOT_REL * scale
+            assert abs(s - sc[qi, j]) <= tol, (qid, cid, s, sc[qi, j], tol)
+            worst, worst_rel = max(worst, abs(s - sc[qi, j])), max(worst_rel, abs(s - sc[qi, j]) / scale)
+            assert sc[qi, j] >= kth - 2 * tol, (qid, cid)                            # a swapped document sits within 2 tol of the reference's boundary
+        same += set(got) == set(ref)
+    print(f"default-mode search {fn} / scorer {score_dtype}: max|score - ref| = {worst:.3e} (relative to |q||d|: {worst_rel:.2e}), "
+          f"identical id sets for {same} of {len(qids)} queries")
+    if os.environ.get("SGPT_PARITY_LOG"):
+        with open(os.environ["SGPT_PARITY_LOG"], "a") as f:
+            f.write(json.dumps(dict(case="search_default_mode_cfg2_125m", score_function=fn, scorer=score_dtype, max_abs_score=worst,
+                                    max_rel_score=worst_rel, identical_id_sets=same, n_queries=len(qids), n_docs=len(cids),
+                                    budget=BAR if fn == "cos_sim" else DOT_REL)) + "\n")
+    assert same >= 0.85 * len(qids)
+
+
+_default_models = {}

@@ -244,6 +244,30 @@ def test_library_is_not_older_than_its_sources():
     assert not stale, f"libsgpt_hip.so is older than {stale}: run `python -m sgpt_amd.build`"
 
 
+def test_native_result_assembly_equals_the_python_construction():
+    """csrc/host_assemble.c (the k = 1001 result dict in C) against beir.assemble_results' Python form, which is
+    exact_search.py:109-132 as arrays: same keys, same floats, same insertion order; padding positions (< 0) skipped, a duplicate
+    position keeps the later score, out-of-range positions raise."""
+    from sgpt_amd import build as B
+    from sgpt_amd.beir import assemble_results
+    assert B.build_host() and os.path.exists(B.HOST_EXT)
+    assert os.path.getmtime(B.HOST_EXT) + 1.0 >= os.path.getmtime(os.path.join(ROOT, "sgpt_amd", "csrc", "host_assemble.c"))
+    rng = np.random.default_rng(0)
+    for nq, k, n in ((1, 1, 1), (7, 11, 40), (33, 1001, 5000)):
+        idx = rng.integers(0, n, size=(nq, k)).astype(np.int64)
+        idx[rng.random((nq, k)) < 0.1] = -1
+        val = rng.standard_normal((nq, k)).astype(np.float32)
+        cids, qids = [f"doc-{j}" for j in range(n)], tuple(f"q{j}" for j in range(nq))          # (a tuple of query ids is accepted too)
+        a, b = assemble_results(qids, cids, val, idx, native=True), assemble_results(qids, cids, val, idx, native=False)
+        assert a == b and all(list(a[q].items()) == list(b[q].items()) for q in qids)
+        assert all(type(v) is float for v in a[qids[0]].values())
+    # non-contiguous / wrongly typed inputs are normalised, not misread
+    a = assemble_results(["q0", "q1"], ["a", "b", "c"], np.asarray([[1, 2], [3, 4]], dtype=np.float64), np.asarray([[2, 0], [1, 1]], dtype=np.int32), native=True)
+    assert a == {"q0": {"c": 1.0, "a": 2.0}, "q1": {"b": 4.0}}
+    with pytest.raises(IndexError):
+        assemble_results(["q0"], ["a"], np.ones((1, 2), np.float32), np.asarray([[0, 5]], np.int64), native=True)
+
+
 def test_crossencoder_host_logic_matches_oracle():
     """Truncation rule and request encoding of the cross-encoder surface (crossencoder/beir/sgptce.py:77-91,204-211)."""
     from sgpt_amd.crossencoder import encode, model_input
