@@ -622,6 +622,13 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
                 g.N = 3 * dm; g.n_split = 2 * dm; g.out2 = vt; g.ldo2 = T;
                 gemm(c, dt, EPI_QKV, dt, g, s);
                 g.out2 = nullptr; g.n_split = 0;
+            } else if (p_ln1 == 0 && !p_att && g.bias == nullptr && gemm_qkv_bulk(T, 3 * dm, dm, 2 * dm, c->force256 != 0)) {
+                // bulk batch, plain operands, no bias (GPT-Neo / GPT-J): q | k | V^T from ONE launch of the 256x256 kernel -- the V
+                // column tiles run with swapped operand roles and leave through the same whole-row store epilogue (gemm.hip);
+                // the LayerNorm output panel is read once, one launch boundary less per block.  Same sums: identical bits.
+                g.N = 3 * dm; g.n_split = 2 * dm; g.out2 = vt; g.ldo2 = T;
+                gemm(c, dt, EPI_QKV, dt, g, s);
+                g.out2 = nullptr; g.n_split = 0;
             } else {
                 // split Q / K: a_hi.W_hi + a_lo.W_hi + a_hi.W_lo as ONE contraction over K' = 3d; V from the hi block alone
                 // unless the plan splits it too (p_ln1 == 2)

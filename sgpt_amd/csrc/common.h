@@ -255,6 +255,7 @@ struct GemmArgs {
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
 bool gemm_qkv_one_launch(int M, int n_split, bool force256);   // 16-bit operands: does EPI_QKV apply (query-sized batch)?
+bool gemm_qkv_bulk(int M, int N, int K, int n_split, bool force256);   // 16-bit operands: EPI_QKV on the 256x256 kernel (bulk batch)?
 #ifdef SGPT_EXPERIMENTS        // A/B knobs of the measurement scripts (libsgpt_hip_exp.so only)
 int set_gemm_skew(int cycles);  // start-up stagger of the persistent 256^2 kernel (shader cycles per phase); returns the previous value
 int set_gemm_use_w(int on);     // 1: the 32x32x16-MFMA re-tiling of the 256^2 kernel (gemm256w.hip); returns the previous value

@@ -566,9 +566,20 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     int tile = blockIdx.x, m0 = 0, n0 = 0;
     while (tile < tiles_total && !tile_coords(tile, m0, n0)) tile += gridDim.x;
     if (tile >= tiles_total) return;
+    // EPI_QKV (the bulk fused QKV projection, N = 3 d in ONE launch): a tile of the q | k columns (n0 < n_split) is the plain
+    // store tile; a tile of the V columns is computed with the operand ROLES SWAPPED -- the V weight rows take the "A" side, the
+    // token rows the "W" side (lda == ldw, checked by the launcher: the per-lane DMA offsets are the same) -- so its accumulators
+    // hold V^T[n][m] in the row-major store orientation and the SAME 16-bit store epilogue writes whole 128-byte runs of
+    // out2[n][m..] (what EPI_VT does with the non-swapped MFMA orientation; same k-ascending sums per element: same bits).
+    auto tile_src = [&](int tm0, int tn0, const bf16_t*& a_, const bf16_t*& w_) {
+        if constexpr (EPI == EPI_QKV) {
+            if (tn0 >= p.n_split) { a_ = Wg + (long)tn0 * p.ldw; w_ = Ag + (long)tm0 * p.lda; return; }
+        }
+        a_ = Ag + (long)tm0 * p.lda; w_ = Wg + (long)tn0 * p.ldw;
+    };
     // per-lane source rows of the two operands for the current tile
-    const bf16_t* asrc = Ag + (long)m0 * p.lda;          // wave-uniform tile bases
-    const bf16_t* wsrc = Wg + (long)n0 * p.ldw;
+    const bf16_t *asrc, *wsrc;                            // wave-uniform tile bases
+    tile_src(m0, n0, asrc, wsrc);
     const long dld = DEEP_A ? p.lda : p.ldw, sld = DEEP_A ? p.ldw : p.lda;
     const unsigned dloff = DEEP_A ? a_loff : w_loff, sloff = DEEP_A ? w_loff : a_loff;
     int sd = 0, ss = 0;      // ring slots of the k-step about to be computed
@@ -626,8 +637,8 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     while (true) {
         const bool has_next = ntile < tiles_total;
         int n2tile = ntile, n2m0 = 0, n2n0 = 0;
-        const bf16_t* nasrc = has_next ? Ag + (long)nm0 * p.lda : asrc;   // past the end: harmless re-fetch
-        const bf16_t* nwsrc = has_next ? Wg + (long)nn0 * p.ldw : wsrc;
+        const bf16_t *nasrc = asrc, *nwsrc = wsrc;                         // past the end: harmless re-fetch
+        if (has_next) tile_src(nm0, nn0, nasrc, nwsrc);
         const bf16_t* d_cur = DEEP_A ? asrc : wsrc, *d_nxt = DEEP_A ? nasrc : nwsrc;
         const bf16_t* s_cur = DEEP_A ? wsrc : asrc, *s_nxt = DEEP_A ? nwsrc : nasrc;
         for (int kt = 0; kt < nk; ++kt) {
@@ -1024,7 +1035,13 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
         return launch_score64<H, EPI_SCORE_FILTER>(a, s);
     }
     if (epi == EPI_SCORE_FILTER && !shape256) return launch<H, EPI_SCORE_FILTER, float, true>(a, s);   // ragged document tail
-    if (epi == EPI_QKV) return launch<H, EPI_QKV, H, true>(a, s);   // caller checked gemm_qkv_one_launch()
+    if (epi == EPI_QKV) {
+        // bulk: the 256x256 kernel with per-tile operand roles (caller checked gemm_qkv_bulk()); else the query-sized form
+        if (gemm_qkv_bulk(a.M, a.N, a.K, a.n_split, a.force256 != 0) && a.lda == a.ldw && a.bias == nullptr && a.lo_delta == 0 &&
+            a.lo_delta2 == 0 && a.m_valid == a.M)
+            return launch256d<H, EPI_QKV, H, true>(a, s, true);
+        return launch<H, EPI_QKV, H, true>(a, s);                   // caller checked gemm_qkv_one_launch()
+    }
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
 #ifdef SGPT_EXPERIMENTS
@@ -1063,6 +1080,19 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
 bool gemm_qkv_one_launch(int M, int n_split, bool force256) {
     static const bool small_tiles = exp_env("SGPT_NO_SMALL_TILE") == nullptr && exp_env("SGPT_QKV_TWO") == nullptr;
     return small_tiles && !force256 && n_split % 128 == 0 && (long)(M / 256) * (n_split / 256) * 2 <= 256;
+}
+// Bulk batches: q | k | V^T from ONE launch of the 256x256 kernel (N = 3 d: nine column tiles per row tile at d = 768; the
+// LayerNorm output panel is fetched once instead of once per launch and a launch boundary goes away).  Shapes the 256x256 kernel
+// takes with more than half a wave of q | k tiles; n_split a multiple of 256.  The caller adds: no bias (GPT-Neo / GPT-J), plain
+// operands (lda == ldw == K), no split outputs.  -DSGPT_QKV_BULK=0 builds the two-launch form for same-box A/Bs.
+#ifndef SGPT_QKV_BULK
+#define SGPT_QKV_BULK 1
+#endif
+bool gemm_qkv_bulk(int M, int N, int K, int n_split, bool force256) {
+    (void)force256;
+    if (!SGPT_QKV_BULK || exp_env("SGPT_QKV_TWO") != nullptr || exp_env("SGPT_GEMM128") != nullptr) return false;
+    return M % 256 == 0 && N % 256 == 0 && n_split % 256 == 0 && n_split < N && K % 64 == 0 && K >= 128 &&
+           (long)(M / 256) * (n_split / 256) > SGPT_FEW_TILES;
 }
 #ifdef SGPT_EXPERIMENTS
 int set_gemm_skew(int cycles) { const int old = g_skew; g_skew = cycles; return old; }

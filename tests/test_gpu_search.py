@@ -446,13 +446,13 @@ def test_search_in_the_default_f16_mode_vs_the_reference_fixture(fn, score_dtype
     Tolerances.  cos_sim: the north_star bar, 1e-3 absolute.  dot: the reference's dot scores of these un-normalised pooled rows
     are |q||d| cos with |q||d| ~ 1e2..1e3, so an absolute bar is meaningless; the encoder's deviation is RELATIVE to the row norms
     (f16 operands: <= 4e-3 absolute on O(1-3) elements = ~1.3e-3 of the norm, tests/test_gpu_parity_cfg2.py `rel`), so dot is held to
-    DOT_REL x |q||d| with DOT_REL = 2e-3 (two rows' relative errors add) -- measured values are printed."""
+    DOT_REL x |q||d| with DOT_REL = 1e-3 -- the cosine bar carried to the scale of the score; measured 2.1e-4 (fp32 and f16 corpus rows alike), printed."""
     from sgpt_amd import SGPTConfig, SGPTModel
     from sgpt_amd.beir import CustomEmbedder, DenseRetrievalExactSearch
     from helpers import oracle_cfg_weights
     monkeypatch.chdir(tmp_path)
     fx = np.load(os.path.join(GOLDEN, "cfg2_125m_1024x128.npz"))
-    DOT_REL, BAR, top_k, chunk = 2e-3, 1e-3, 10, 300
+    DOT_REL, BAR, top_k, chunk = 1e-3, 1e-3, 10, 300
     key = ("default-mode-125m",)
     if key not in _default_models:
         _, w = oracle_cfg_weights(dict(O.SGPT_125M), 1, 0.02)
