@@ -1140,8 +1140,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             // of this selection are used (its indices are sample positions) -- the filtered chunks below re-score the sampled
             // documents like any other and find them again
             score_tile(0, S, S, nullptr, s_stride);
-            launch_topk_select(sc, S, S, 0, tv[0], ti[0], k, k, nq, k, 0, nullptr, th_v, th_i, s);
-            launch_thr_below(th_v, k, nq, thr_dense, s);
+            launch_topk_select(sc, S, S, 0, tv[0], ti[0], k, k, nq, k, 0, nullptr, th_v, th_i, s, nullptr, thr_dense);   // (+ the inclusive threshold)
             eff = S;
         } else {
             // first chunk: materialise + select -> the initial thresholds.  One whole wave of tiles is enough (the

@@ -345,7 +345,7 @@ void launch_fill_rand(void* p, long n, int dtype, unsigned seed, float scale, hi
 void launch_topk_select(const float* scores, long ld, long n, long idx_base, const float* prev_val,
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
                         const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s,
-                        const int* pred = nullptr);
+                        const int* pred = nullptr, float* thr_out = nullptr);   // thr_out[q] = the k-th best, one ulp lower (or null)
 // scorer pass prologue in one launch: q -> zero-padded qpad (byte counts, multiples of 16), counters[n] = 0, idx_list[n] = -1
 void launch_score_prep(const void* q, void* qpad, long q_bytes, long qpad_bytes, int* counters, long n_counters, long long* idx_list,
                        long n_idx, hipStream_t s);

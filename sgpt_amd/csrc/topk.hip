@@ -100,11 +100,21 @@ __device__ __forceinline__ void hist_add(unsigned* hist, bool match, unsigned dg
     if ((todo >> lane) & 1ull) atomicAdd(&hist[dgt & 0xff], 1u);
 }
 
+// one ulp towards -inf: the INCLUSIVE form of a filter threshold (`v > below(t)` is `v >= t`); -inf / NaN stay as they are
+__device__ __forceinline__ float thr_below(float t) {
+    if (!(t == t) || !(t > -INFINITY)) return t;
+    if (t == 0.0f) return -__uint_as_float(1u);                       // below +-0: the smallest negative subnormal
+    const uint32_t u = __float_as_uint(t);
+    return __uint_as_float((u & 0x80000000u) ? u + 1 : u - 1);
+}
+
+// thr_out (optional): the row's k-th best, lowered by one ulp, as the scorer's dense filter threshold -- written by the select
+// itself (round 5; a launch of its own before: ~5 us of a 0.28 ms shard pass)
 __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* scores, long ld, long n, long idx_base,
                                                                 const float* prev_val, const int64_t* prev_idx,
                                                                 int n_prev, long prev_ld, int k, int nan_to_m1,
                                                                 const int64_t* exclude_idx, float* out_val,
-                                                                int64_t* out_idx, const int* pred) {
+                                                                int64_t* out_idx, const int* pred, float* thr_out) {
     if (pred && *pred == 0) return;   // predicated fallback launch that is not needed
     __shared__ unsigned hist[256];
     __shared__ unsigned sh_prefix, sh_krem, sh_cnt, sh_cnt2;
@@ -158,10 +168,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                 if (lane == 0) {
                     const bool ok = bp >= 0 && bv > -INFINITY;          // (-inf: an empty / excluded slot -> (-inf, -1) like every path)
                     ov[round] = ok ? bv : -INFINITY; oi[round] = ok ? bi : -1;
+                    if (thr_out && round == k - 1) thr_out[qrow] = thr_below(ok ? bv : -INFINITY);
                     if (bp >= 0) s_idx[bp] = -1;
                 }
             }
             for (int i = kk + lane; i < k; i += 64) { ov[i] = -INFINITY; oi[i] = -1; }
+            if (thr_out && kk < k && lane == 0) thr_out[qrow] = -INFINITY;
         }
         return;                                    // block-uniform exit: output written
     } else if (k <= TK_FAST_KMAX && total >= TK_FAST_MIN_ROW) {
@@ -242,9 +254,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                             const int op_ = __shfl_xor(bp, sd, 64);
                             if (sorts_before(ov_, (int64_t)oi_, bv, bi)) { bv = ov_; bi = (int64_t)oi_; bp = op_; }
                         }
-                        if (lane == 0) { ov[round] = bv; oi[round] = bi; s_val[bp] = -INFINITY; s_idx[bp] = 0x7fffffffffffffffLL; }
+                        if (lane == 0) {
+                            ov[round] = bv; oi[round] = bi; s_val[bp] = -INFINITY; s_idx[bp] = 0x7fffffffffffffffLL;
+                            if (thr_out && round == k - 1) thr_out[qrow] = thr_below(bv);
+                        }
                     }
                     for (int i = kk + lane; i < k; i += 64) { ov[i] = -INFINITY; oi[i] = -1; }
+                    if (thr_out && kk < k && lane == 0) thr_out[qrow] = -INFINITY;
                 }
                 return;                            // block-uniform exit: output written
             }
@@ -362,6 +378,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
         const bool ok = i < kk;
         ov[i] = ok ? s_val[i] : -INFINITY;
         oi[i] = ok ? s_idx[i] : -1;
+        if (thr_out && i == k - 1) thr_out[qrow] = thr_below(ok ? s_val[i] : -INFINITY);
     }
 }
 
@@ -471,14 +488,7 @@ __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __r
 __global__ __launch_bounds__(256) void thr_below_kernel(const float* __restrict__ list, int k, int nq, float* __restrict__ thr) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
-    const float t = list[(long)q * k + (k - 1)];
-    float r = t;
-    if (t == t && t > -INFINITY) {
-        const uint32_t u = __float_as_uint(t);
-        if (t == 0.0f) r = -__uint_as_float(1u);                       // below +-0: the smallest negative subnormal
-        else r = __uint_as_float((u & 0x80000000u) ? u + 1 : u - 1);  // one ulp towards -inf
-    }
-    thr[q] = r;
+    thr[q] = thr_below(list[(long)q * k + (k - 1)]);
 }
 
 // One launch in front of a scorer pass instead of four stream operations (each a dispatch of its own with a ~2.5 us gap):
@@ -511,9 +521,10 @@ void launch_thr_below(const float* list, int k, int nq, float* thr, hipStream_t 
 
 void launch_topk_select(const float* scores, long ld, long n, long idx_base, const float* prev_val,
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
-                        const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s, const int* pred) {
+                        const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s, const int* pred,
+                        float* thr_out) {
     hipLaunchKernelGGL(topk_select_kernel, dim3(nq), dim3(TK_THREADS), 0, s, scores, ld, n, idx_base, prev_val,
-                       prev_idx, n_prev, prev_ld, k, nan_to_m1, exclude_idx, out_val, out_idx, pred);
+                       prev_idx, n_prev, prev_ld, k, nan_to_m1, exclude_idx, out_val, out_idx, pred, thr_out);
 }
 
 void launch_cand_merge(const float* run_val, const int64_t* run_idx, const float* cand_val, const int64_t* cand_idx,
