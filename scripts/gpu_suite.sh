@@ -67,6 +67,13 @@ PY
         v=$( SGPT_HIP_LIB=$L timeout 600 python bench.py --steps ${AB_STEPS:-10} --warmup 3 --no-cpu-baseline --no-1m --no-varlen --no-modes 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'sent/s  gemm', r['achieved'], 'TF  launches', r['launches'], 'avg_ms', r['avg_launch_ms'])" )
         echo "round $rnd lib $tag: $v" | tee -a gpurun_out/ab_bench.txt
       done; done ;;
+    ab_score)
+      : > gpurun_out/ab_score.txt
+      for rnd in 1 2 3; do for tag in default ${LIBS}; do
+        L=$(libpath $tag)
+        for n in 125000 1000000; do echo -n "round $rnd lib $tag: " | tee -a gpurun_out/ab_score.txt; SGPT_HIP_LIB=$L N=$n python scripts/score_bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a gpurun_out/ab_score.txt; done
+      done; done ;;
+    probe) ( python scripts/score_shape_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_shape_probe.txt ;;
     ab_shapes)
       : > gpurun_out/ab_shapes.txt
       for tag in default ${LIBS}; do

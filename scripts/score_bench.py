@@ -25,7 +25,7 @@ for _ in range(2):
     ctx.score_topk(q, c, k, dtype=DT)
 torch.cuda.synchronize()
 t = time.perf_counter()
-reps = 5
+reps = int(os.environ.get("REPS", 20))
 for _ in range(reps):
     ctx.score_topk(q, c, k, dtype=DT)
 torch.cuda.synchronize()

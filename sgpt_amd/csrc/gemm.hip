@@ -35,6 +35,9 @@ constexpr bool RESID_NT = SGPT_RESID_NT != 0;
 #define SGPT_RESID_LD_NT 0
 #endif
 constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
+#ifndef SGPT_THV_UNCOND
+#define SGPT_THV_UNCOND 1
+#endif
 #ifndef SGPT_SMALL_PF
 #define SGPT_SMALL_PF 2
 #endif
@@ -693,10 +696,22 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
             sd = sdn;
             if constexpr (EPI == EPI_SCORE_FILTER) {
                 if (kt == 0) {
+                    // UNCONDITIONAL loads from a clamped row (padded query rows are masked in the epilogue): written as
+                    // `m < m_valid ? load : inf`, every tile's k-step 0 began with `v_mov inf` into registers whose previous
+                    // loads the compiler's counter model still held pending across the k-loop's back edge -- it cannot count the
+                    // inline-asm DMA pieces, so the write-after-write wait came out as `s_waitcnt vmcnt(0)`: a full memory round
+                    // trip, the deep operand's run-ahead pieces included, in front of every tile's second k-step (round 5;
+                    // the same compiler bookkeeping that stalled the attention tile loop until round 4).  Load after load to the
+                    // same register needs no wait: VMEM loads return in order.
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const int m = m0 + wm * 128 + i * 16 + fr;
-                        thv_pre[i] = m < p.m_valid ? p.thr[(long)m * p.thr_ld] : INFINITY;
+                        int m = m0 + wm * 128 + i * 16 + fr;
+#if SGPT_THV_UNCOND
+                        m = m < p.m_valid ? m : p.m_valid - 1;
+                        thv_pre[i] = p.thr[(long)m * p.thr_ld];
+#else
+                        thv_pre[i] = m < p.m_valid ? p.thr[(long)m * p.thr_ld] : INFINITY;     // (A/B build: rounds 3-4)
+#endif
                     }
                 }
             }
