@@ -282,7 +282,8 @@ sgpt_status sgpt_model_set_precision(sgpt_model* model, const int32_t* plan, int
 sgpt_status sgpt_model_get_precision(sgpt_model* model, int32_t* plan, int32_t n);
 /* sgpt_model_release_split_weights: give the [W_hi | W_hi | W_lo] copies of sgpt_model_desc.split_weights back (3 x the 16-bit
  *   weight bytes: +0.5 GB at SGPT-125M, +35 GB at GPT-J-6B shape) once the plan is known not to need them -- what the host does when
- *   the probe of precision='auto' settles on plain operands.  Refused while the installed plan reads them; afterwards
+ *   the probe of precision='auto' settles on plain operands.  Refused while the installed plan reads the out-projection / fc1 /
+ *   fc2 copies (context, LayerNorm-2, GELU classes); the Q / K / V copy stays when a LayerNorm-1 entry (precise_qk) reads it; afterwards
  *   sgpt_model_set_precision refuses plans that would, exactly as for a model loaded without split_weights.  bytes_freed may
  *   be NULL.  (The reference keeps one fp32 copy of the weights: `AutoModel.from_pretrained`, beir_dense_retriever.py:123.) */
 sgpt_status sgpt_model_release_split_weights(sgpt_model* model, int64_t* bytes_freed);

@@ -57,6 +57,7 @@ struct sgpt_model {
     // != 0 (classes: PC_*).  crest_dev: device fp32 bits [n_layers * RS_N] collected while `probing` (sgpt_model_precision_probe_*).
     std::vector<int> prec;
     bool split_all = false;            // the split copies of all four matrices exist (sgpt_model_desc.split_weights)
+    int qkv3_rows = 0;                 // row blocks of w_qkv3: 2 (q, k: qk_split alone) | 3 (q, k, v: split_weights) | 0 (none)
     unsigned* crest_dev = nullptr;
     bool probing = false;
     std::vector<void*> allocs;
@@ -409,6 +410,7 @@ sgpt_status sgpt_model_load(sgpt_ctx* c, const sgpt_model_desc* d, const sgpt_te
     m->ln_floor.assign((size_t)d->n_layers, 0);
     m->prec.assign((size_t)d->n_layers * PC_N, 0);
     m->split_all = d->split_weights != 0;
+    m->qkv3_rows = d->split_weights != 0 ? 3 : (d->qk_split != 0 ? 2 : 0);
     if (d->qk_split != 0)              // the round-3 switch: the Q / K projection of every block contracts over hi + lo pairs
         for (int i = 0; i < d->n_layers; ++i) m->prec[(size_t)i * PC_N + PC_LN1] = 1;
     if (st == SGPT_OK && bf && !fp8) {
@@ -1377,7 +1379,7 @@ sgpt_status sgpt_model_set_precision(sgpt_model* m, const int32_t* plan, int32_t
         const int cls = i % PC_N, v = plan[i];
         if (v < 0 || v > (cls == PC_LN1 ? 3 : 1)) return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: entries are 0 | 1 (LayerNorm-1 class: 0 ... 3)");
         any |= v != 0;
-        const bool legacy_ok = cls == PC_LN1 && (v == 1 || v == 3) && m->L[i / PC_N].w_qkv3 != nullptr;
+        const bool legacy_ok = cls == PC_LN1 && (v == 1 || v == 3 || (v == 2 && m->qkv3_rows == 3)) && m->L[i / PC_N].w_qkv3 != nullptr;
         if (v != 0 && cls != PC_ATT && !m->split_all && !legacy_ok)      // (the attention class splits activations only)
             return fail(c, SGPT_ERR_INVALID, "sgpt_model_set_precision: the model was loaded without split weight copies (sgpt_model_desc.split_weights)");
         if (cls == PC_ATT && v != 0 && (m->d.arch == SGPT_ARCH_GPTJ || !attn_x3_supported(dh)))
@@ -1411,7 +1413,7 @@ sgpt_status sgpt_model_release_split_weights(sgpt_model* m, int64_t* bytes_freed
         for (int cls = 0; cls < PC_N; ++cls) {
             const int v = m->prec[(size_t)i * PC_N + cls];
             if (v == 0 || cls == PC_ATT) continue;
-            if (cls == PC_LN1 && (v == 1 || v == 3)) { qk_used = true; continue; }
+            if (cls == PC_LN1) { qk_used = true; continue; }            // any LayerNorm-1 level reads w_qkv3 (level 2: its V rows too): kept whole
             return fail(c, SGPT_ERR_INVALID, "sgpt_model_release_split_weights: the installed precision plan reads the split copies");
         }
     HIPC(c, hipSetDevice(c->device));
@@ -1431,6 +1433,7 @@ sgpt_status sgpt_model_release_split_weights(sgpt_model* m, int64_t* bytes_freed
         drop(l.w_o3, dm * 3 * dm * 2); drop(l.w_fc3, ffn * 3 * dm * 2); drop(l.w_proj3, dm * 3 * ffn * 2);
         if (!qk_used) drop(l.w_qkv3, 3 * dm * 3 * dm * 2);
     }
+    if (!qk_used) m->qkv3_rows = 0;
     m->split_all = false;
     c->generation++;
     if (bytes_freed) *bytes_freed = freed;

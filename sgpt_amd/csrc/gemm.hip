@@ -637,6 +637,11 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     // EPI_SCORE_FILTER: the thresholds of this tile's rows, loaded under k-step 0 -- at the head of the epilogue they were an
     // un-hidden L2 round trip per tile (behind the next tile's run-ahead DMA, which the compiler's vmcnt wait also retires)
     float thv_pre[8];
+    // (Round 5 probe, removed again: the GELU launch's bias fragments fetched under k-step 0 by inline-asm loads the compiler's
+    // s_waitcnt bookkeeping does not see -- so that the epilogue's head carries no `vmcnt(0)` behind the next tile's run-ahead
+    // DMA -- changed nothing: fc1 628.9 -> 643.4 us median, 628.7 -> 630.9 best, same box.  The wait is not where the epilogue's
+    // time goes; neither was the `vmcnt(0)` the conditional threshold loads of the filtered scorer launch had put in front of
+    // every tile's second k-step -- removed, 0.28 / 1.47 ms per pass either way, profiles/r05_score_thv_ab.txt.)
     while (true) {
         const bool has_next = ntile < tiles_total;
         int n2tile = ntile, n2m0 = 0, n2n0 = 0;

@@ -62,7 +62,8 @@ BUDGET = {
                    "f16-fulllogits": (1.5e-3, 1.5e-3), "f16-qkvlogits": (1.5e-3, 1.5e-3), "f16-attn": (1.5e-3, 1.5e-3), "f16-x3": (BAR, BAR)},
     # round 5: SECOND seeds of the two GPT-Neo shapes whose default sits within 20 % of the bar on the first
     # fixture; the 2.7B one with 160-300-token documents (the 256-token local window live at d = 2560 / head_dim 128)
-    "cfg3_neo13b_specb_s2": {"f16": (BAR, BAR), "f16-qk": (1.5e-3, 2e-3), "f16-fulllogits": (BAR, BAR)},
+    "cfg3_neo13b_specb_s2": {"f16": (BAR, BAR), "f16-qk": (1.5e-3, 2e-3), "f16-logits": (BAR, 1.3e-3), "f16-act": (BAR, 1.2e-3), "f16-full": (BAR, 1.2e-3),
+                             "f16-fulllogits": (BAR, BAR)},
     "cfg_neo27b_s2": {"f16": (BAR, BAR), "f16-qk": (3e-3, 4e-3), "f16-qkvlogits": (BAR, BAR), "f16-attn": (BAR, BAR)},
     "cfg4_gptj6b": {"f16": (BAR, BAR), "bf16": (BAR, BAR), "fp8mfma": (1.0e-2, 1.0e-2)},
     "cfg5_bloom7b1": {"f16": (BAR, BAR), "bf16": (BAR, BAR), "fp8": (1.0e-2, 1.0e-2), "fp8mfma": (1.0e-2, 1.0e-2)},
