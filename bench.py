@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--no-1m", action="store_true", help="skip the queries/sec @ 1M-doc scoring leg")
     ap.add_argument("--cpu-sample", type=int, default=128, help="sentences in the bounded CPU-baseline sample (a slice of the 1024 x seq probe)")
     ap.add_argument("--no-varlen", action="store_true", help="skip the lengths ~U{16..128} leg")
+    ap.add_argument("--equal-calls", action="store_true", help="A/B: round 4's equal token budgets per sgpt_encode call instead of the round-aware ones (variable-length leg)")
     ap.add_argument("--no-modes", action="store_true", help="skip the precision-mode leg (f16x3 and exact-fp32 encode rates beside the headline)")
     args = ap.parse_args()
 
@@ -230,6 +231,7 @@ def main():
                       precise_qk={"auto": None, "on": True, "off": False}.get(args.precise_qk, args.precise_qk),
                       **({} if args.precision == "default" else {"precision": args.precision}))
     del weights
+    model.round_aware_calls = not args.equal_calls
     torch.cuda.empty_cache()
     d, S, k1 = cfg.hidden_size, args.seq, args.topk + 1      # the reference keeps top_k+1 (exact_search.py:104)
     score_dt = {"fp32": torch.float32, "f16": torch.float16}.get(args.dtype, torch.bfloat16)
@@ -562,7 +564,7 @@ def main():
             tv = torch.tensor([vdt], dtype=torch.float64, device=dev)
             dist.all_reduce(tv, op=dist.ReduceOp.MAX)
             vdt = float(tv.item())
-        varlen = {"lengths": f"U{{16..{S}}}", "steps": v_steps, "sentences_per_s": round(world * v_steps * args.chunk / vdt, 1),
+        varlen = {"lengths": f"U{{16..{S}}}", "steps": v_steps, "rows_per_call": [int(pb.T_pad) for pb in vpacked[0]], "sentences_per_s": round(world * v_steps * args.chunk / vdt, 1),
                   "tokens_per_s": round(world * v_steps * per_step_tokens / vdt, 1),
                   "mean_len": round(per_step_tokens / args.chunk, 2),
                   "end_to_end_frac_of_mfma_roofline": round(v_steps * per_step_flops / vdt / (PEAK_BF16_TFLOPS * 1e12), 4)}

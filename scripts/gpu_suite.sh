@@ -73,6 +73,12 @@ PY
         L=$(libpath $tag)
         for n in 125000 1000000; do echo -n "round $rnd lib $tag: " | tee -a gpurun_out/ab_score.txt; SGPT_HIP_LIB=$L N=$n python scripts/score_bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a gpurun_out/ab_score.txt; done
       done; done ;;
+    ab_varlen)
+      : > gpurun_out/ab_varlen.txt
+      for rnd in 1 2 3; do for mode in "" "--equal-calls"; do
+        v=$( timeout 600 python bench.py --steps 9 --warmup 2 --no-cpu-baseline --no-1m --no-modes $mode 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); v=d['varlen']; print(v['sentences_per_s'], 'sent/s', v['end_to_end_frac_of_mfma_roofline'], v['rows_per_call'], '| fixed-128', d['value'])" )
+        echo "round $rnd calls ${mode:-round-aware}: $v" | tee -a gpurun_out/ab_varlen.txt
+      done; done ;;
     probe) ( python scripts/score_shape_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_shape_probe.txt ;;
     ab_shapes)
       : > gpurun_out/ab_shapes.txt

@@ -678,23 +678,84 @@ class SGPTModel:
         _lib.check(self.ctx.handle, st, "sgpt_lm_logprobs")
         return (out, greedy) if return_greedy else out
 
+    def _num_cus(self) -> int:
+        try:
+            return int(torch.cuda.get_device_properties(self.device).multi_processor_count) // 8 * 8 or 256
+        except Exception:      # noqa: BLE001 -- host-only callers (tests of the planner)
+            return 256
+
+    def call_budgets(self, total_rows: int, ncu: Optional[int] = None) -> List[int]:
+        """Token-row budgets of the sgpt_encode calls that cover `total_rows` packed rows (round 5).
+        The persistent 256x256 GEMM runs `ceil(MT * NT / CUs)` rounds of tiles per launch (MT = rows / 256, NT = N / 256): a call
+        whose tile counts stop just past a multiple of the CU count pays a whole extra round on every launch of every block -- three
+        equal calls of 99 k rows (a 4096-document step of U{16..128}-token documents, 298 k rows) run 4.55 / 13.6 / 18.2 rounds:
+        9 % / 3 % / 4 % idle.  Budgets are chosen from the sizes whose N = d launches end on a round boundary
+        (MT = floor(j * CUs / (d / 256)): 85, 170, 256, 341, 426, 512 row tiles at d = 768 on 256 CUs -- the wider launches are
+        multiples of that one) by a small search that minimises the modelled rounds x K of the four projections plus a term linear
+        in rows (LayerNorm / attention / epilogue bytes); the call count stays at ceil(total / max_tokens_per_call) or one more.
+        Pure function of (total_rows, model shape, CU count): every rank computes the same plan."""
+        ncu = ncu or self._num_cus()
+        d, ffn = self.cfg.hidden_size, self.cfg.intermediate_size
+        nt_d = max(1, d // TOKEN_TILE)
+        mt_max = max(1, self.max_tokens_per_call // TOKEN_TILE)
+        mt_tot = -(-int(total_rows) // TOKEN_TILE)
+        if mt_tot <= mt_max:
+            return [mt_tot * TOKEN_TILE]
+        launches = [(3 * d // TOKEN_TILE, d), (nt_d, d), (max(1, ffn // TOKEN_TILE), d), (nt_d, ffn)]     # (column tiles, K): QKV, out, fc1, fc2
+        per_row = 0.35 * sum(nt * k for nt, k in launches) / ncu        # HBM-bound phases: ~35 % of a full call's GEMM time at d = 768
+
+        def cost(mt):
+            return sum(-(-mt * nt // ncu) * k for nt, k in launches) + per_row * mt
+
+        good = sorted({min(mt_max, j * ncu // nt_d) for j in range(1, mt_max * nt_d // ncu + 2)} | {mt_max})
+        good = [g for g in good if g >= 1]
+        n_min = -(-mt_tot // mt_max)
+        best, cands = None, []
+        # all calls but the last three at the maximum (a whole number of rounds by construction when mt_max is a good size);
+        # the last <= 3 (or 4) are searched: good sizes for all but one, which takes what is left
+        for n_calls in (n_min, n_min + 1):
+            n_free = min(n_calls, 3 if n_calls == n_min else 4)
+            fixed = n_calls - n_free
+            rem = mt_tot - fixed * mt_max
+            if rem <= 0:
+                continue
+            import itertools
+            for combo in itertools.combinations_with_replacement(good, n_free - 1):
+                last = rem - sum(combo)
+                if last <= 0 or last > mt_max:
+                    continue
+                c = fixed * cost(mt_max) + sum(cost(g) for g in combo) + cost(last)
+                cands.append((c, [mt_max] * fixed + sorted(list(combo) + [last], reverse=True)))
+        if cands:
+            # plans within 0.3 % of the cheapest are equal as far as the model can tell: take the most balanced one (a short
+            # last call runs its few rounds at a lower rate than the model's per-round cost -- ramp and tail of every launch)
+            c_min = min(c for c, _ in cands)
+            best = max((pl for c, pl in cands if c <= c_min * 1.003), key=lambda pl: (min(pl), -len(pl)))
+        if best is None:
+            best = [mt_max] * (n_min - 1) + [mt_tot - (n_min - 1) * mt_max]
+        return [b * TOKEN_TILE for b in best]
+
     def plan_batches(self, lens: np.ndarray, max_sentences: Optional[int] = None) -> List[np.ndarray]:
         """Length-sorted (longest first, SentenceTransformer.py:148-149 / exact_search.py:66-71)
         contiguous slices bounded by a token budget instead of a padded [B,S] rectangle."""
         order = np.argsort(-lens, kind="stable")
         alloc = (lens[order] + ALIGN - 1) // ALIGN * ALIGN
-        # EQUAL token budgets: filling every call to max_tokens_per_call leaves a short last call (294 k token rows = 131 k +
-        # 131 k + 32 k), and a mid-size call runs the projections at ~0.6 of the bulk rate (a lone round of 256x256 tiles, DESIGN 3);
-        # three calls of 98 k rows lose ~3 % each instead.  The budget stays a multiple of the GEMM's token tile.
+        # Budgets per call from call_budgets(): sizes whose GEMM launches end on whole rounds of the chip (round 4 cut equal
+        # budgets -- better than 131 k + 131 k + 32 k, but a 99 k-row call idles 3-9 % of every launch in its last round).
         total = int(alloc.sum())
-        n_calls = max(1, -(-total // self.max_tokens_per_call))
-        budget = min(self.max_tokens_per_call, (-(-total // n_calls) + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE + int(alloc.max()))
-        out, start, tok = [], 0, 0
+        if getattr(self, "round_aware_calls", True):
+            budgets = self.call_budgets(total)
+        else:       # round 4's rule (A/B: bench.py --equal-calls): equal budgets, a multiple of the GEMM's token tile
+            n_calls = max(1, -(-total // self.max_tokens_per_call))
+            budgets = [min(self.max_tokens_per_call, (-(-total // n_calls) + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE + int(alloc.max()))]
+        out, start, tok, bi = [], 0, 0, 0
         for i, a in enumerate(alloc):
+            budget = min(self.max_tokens_per_call, budgets[min(bi, len(budgets) - 1)])
             full = tok + a > budget or (max_sentences and i - start >= max_sentences)
             if full and i > start:
                 out.append(order[start:i])
                 start, tok = i, 0
+                bi += 1
             tok += int(a)
         out.append(order[start:])
         return out

@@ -244,6 +244,35 @@ def test_library_is_not_older_than_its_sources():
     assert not stale, f"libsgpt_hip.so is older than {stale}: run `python -m sgpt_amd.build`"
 
 
+def test_round_aware_call_budgets():
+    """SGPTModel.call_budgets (round 5): the token-row budgets of the sgpt_encode calls of a chunk cover it, stay inside
+    max_tokens_per_call, use at most one call more than the minimum, are a pure function of (rows, shape, CUs), and never cost
+    more modelled tile-rounds than round 4's equal budgets; plan_batches cuts the length-sorted list by them."""
+    from sgpt_amd.model import SGPTConfig, SGPTModel, TOKEN_TILE
+    m = object.__new__(SGPTModel)
+    m.cfg, m.max_tokens_per_call, m.device = SGPTConfig(), 131072, "cpu"
+
+    def rounds(plan, ncu=256, d=768):
+        nts = ((3 * d // 256, d), (d // 256, d), (4 * d // 256, d), (d // 256, 4 * d))
+        return sum(-(-(t // 256) * nt // ncu) * k for t in plan for nt, k in nts)
+    rng = np.random.default_rng(0)
+    for total in [1, 255, 131072, 131073, 298000, 262144, 400000, 3_599_944] + rng.integers(1000, 2_000_000, size=40).tolist():
+        b = m.call_budgets(int(total), 256)
+        n_min = -(-(-(-int(total) // TOKEN_TILE)) // 512)
+        assert sum(b) >= total and all(0 < x <= 131072 and x % TOKEN_TILE == 0 for x in b) and n_min <= len(b) <= n_min + 1, (total, b)
+        assert b == m.call_budgets(int(total), 256)
+        eq = [-(-(-(-int(total) // len(b))) // 256) * 256] * len(b) if len(b) > 1 else b
+        assert rounds(b) <= rounds(eq) * 1.0001 or len(b) == 1, (total, b, rounds(b), rounds(eq))
+    assert [x // 256 for x in m.call_budgets(298000, 256)] == [483, 341, 341]       # the bench's variable-length step: equal thirds ran 4.55 rounds per N = 768 launch
+    lens = rng.integers(16, 129, size=4096).astype(np.int64)
+    m.round_aware_calls = True
+    plan = m.plan_batches(lens)
+    assert sorted(np.concatenate(plan).tolist()) == list(range(4096))
+    rows = [int(((lens[p] + 1) // 2 * 2).sum()) for p in plan]
+    bud = m.call_budgets(int(((lens + 1) // 2 * 2).sum()), 256)
+    assert len(plan) == len(bud) and all(r <= b_ for r, b_ in zip(rows, bud)) and all(b_ - r < 130 for r, b_ in zip(rows[:-1], bud))
+
+
 def test_native_result_assembly_equals_the_python_construction():
     """csrc/host_assemble.c (the k = 1001 result dict in C) against beir.assemble_results' Python form, which is
     exact_search.py:109-132 as arrays: same keys, same floats, same insertion order; padding positions (< 0) skipped, a duplicate
