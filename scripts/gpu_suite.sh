@@ -79,6 +79,14 @@ PY
         v=$( timeout 600 python bench.py --steps 9 --warmup 2 --no-cpu-baseline --no-1m --no-modes $mode 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); v=d['varlen']; print(v['sentences_per_s'], 'sent/s', v['end_to_end_frac_of_mfma_roofline'], v['rows_per_call'], '| fixed-128', d['value'])" )
         echo "round $rnd calls ${mode:-round-aware}: $v" | tee -a gpurun_out/ab_varlen.txt
       done; done ;;
+    varlen_prof)
+      for L in var fixed; do
+        rm -rf gpurun_out/vprof_$L; mkdir -p gpurun_out/vprof_$L
+        ( cd /tmp && LENS=$L timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/vprof_$L -o trace -- python $R/scripts/varlen_profile.py ) > gpurun_out/vprof_$L.log 2>&1
+        grep "LENS=" gpurun_out/vprof_$L.log
+        python scripts/prof_summary.py gpurun_out/vprof_$L/trace_results.db 14 > gpurun_out/varlen_prof_$L.csv; rm -rf gpurun_out/vprof_$L
+        head -14 gpurun_out/varlen_prof_$L.csv | cut -c1-160
+      done ;;
     probe) ( python scripts/score_shape_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_shape_probe.txt ;;
     ab_shapes)
       : > gpurun_out/ab_shapes.txt
