@@ -622,10 +622,10 @@ def main():
             traffic_source = f"profiles/{tname} (replayed from the committed rocprofv3 --pmc passes of this command, not measured in this run)"
             break
     roofline = {"bound": "mfma",
-                "kernel": "gemm256 (16-bit operands, 256x256x64 persistent LDS-DMA GEMM, asymmetric 3+2-slot LDS ring; the 5 projection launches per block)"
+                "kernel": "gemm256 (16-bit operands, 256x256x64 persistent LDS-DMA GEMM, asymmetric 3+2-slot LDS ring; the 4 projection launches per block: QKV in one, out-proj, fc1, fc2)"
                           if args.dtype != "fp32" else "gemm_kernel<float> (exact fp32 MFMA 128x128x32)",
                 "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, avg over the 5 GEMM launch shapes)",
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, avg over the GEMM launch shapes of a block)",
                 "traffic_source": traffic_source,
                 "mfma_busy": mfma_busy, "effective_clock_ghz": eff_clock,
                 "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) and GRBM_GUI_ACTIVE / 8 / kernel duration, time-weighted "

@@ -346,6 +346,25 @@ sgpt_status sgpt_score_topk(sgpt_ctx* ctx, const void* q, const void* corpus, in
                             float* run_val, int64_t* run_idx, int32_t n_run, int32_t* n_out,
                             void* stream);
 
+/* sgpt_score_topk_refined (ABI v7): the reference's fp32 scoring + top-k (`torch.mm(a, b.T)`, util.py:41-43,63; `torch.topk`,
+ * exact_search.py:96-108) -- fp32 scores of the returned documents, the fp32 top-k set -- at the speed of the 16-bit scorer.
+ *   q         device fp32 [nq, d]; corpus32 device fp32 [N, d]; corpus16 device 16-bit [N, d] = corpus32 rounded (sgpt_f32_to_16
+ *             or sgpt_l2_normalize with a 16-bit output); dtype16 SGPT_F16 | SGPT_BF16
+ *   stage 1   the filtered 16-bit scorer (sgpt_score_topk on 16-bit copies) takes k' = k + head-room candidates per query;
+ *   stage 2   every candidate is re-scored in exact fp32 from corpus32, merged with the running list, top-k (ties: ascending index).
+ *   margin    the caller's bound 2 eps on |s16 - s32| for its rows: 2.5e-3 for L2-normalised rows with SGPT_F16 copies (two
+ *             roundings of relative 2^-11, Cauchy-Schwarz; subnormal flushes and both fp32 accumulations inside the slack); scale by
+ *             max|q| max|d| for un-normalised rows.  When the (k')-th best 16-bit score of a query is not more than `margin` below
+ *             its k-th best, outsiders could still reach the fp32 top-k: a device flag is raised and the call's exact-fp32
+ *             materialise-and-select pass, every launch predicated on that flag, redoes the chunk -- exact either way, and
+ *             asynchronous on `stream` unless fallback_flag_out (host int32*, may be NULL) is given: then the call synchronises and
+ *             reports 1 if the exact pass ran, 0 if not, -1 if the call went straight to the exact pass (k' would not fit).
+ *   run_val / run_idx / n_run / n_out as sgpt_score_topk (fp32 scores throughout). */
+sgpt_status sgpt_score_topk_refined(sgpt_ctx* ctx, const float* q, const float* corpus32, const void* corpus16, int32_t dtype16,
+                                    int32_t nq, int64_t N, int32_t d, int32_t k, int64_t idx_base, float margin,
+                                    float* run_val, int64_t* run_idx, int32_t n_run, int32_t* n_out, int32_t* fallback_flag_out,
+                                    void* stream);
+
 /* k best of m candidate (score, index) pairs per query: the cross-rank / cross-chunk merge
  * (exact_search.py:121-132 heapq.nlargest).  Candidates with idx < 0 are ignored, and so is
  * the candidate whose idx == exclude_idx[q] (the `corpus_id != query_id` rule of :118;

@@ -18,7 +18,8 @@ SPECS = ["125m f16", "125m bf16", "125m fp8mfma", "125m f16-x3", "1.3b f16", "1.
 parity = {}
 for ln in open(sys.argv[1]):
     d = json.loads(ln)
-    parity[(d["case"], d["dtype"])] = d
+    if "dtype" in d:                 # (the default-mode search() lines carry score_function / scorer instead)
+        parity[(d["case"], d["dtype"])] = d
 with open(sys.argv[2], "w") as out:
     for spec in SPECS:
         model, dtype = spec.split()

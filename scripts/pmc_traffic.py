@@ -50,8 +50,8 @@ def pick(table, key, n, phase=None, period=1):
 
 
 shapes = [  # name, kernel-name key, launches to take, (phase, period), algorithmic bytes
-    ("qk_proj  [T,1536]x768 store 16-bit", "0", LAUNCHES, None, T * D * 2 + T * 2 * D * 2 + 2 * D * D * 2),
-    ("v_proj   [T,768]x768  V^T 16-bit", "4", LAUNCHES, None, T * D * 2 + T * D * 2 + D * D * 2),
+    # round 5: q | k | V^T leave ONE launch (EPI_QKV = 7); rounds 1-4 had "0" (Q|K store) + "4" (V^T)
+    ("qkv_proj [T,2304]x768 q|k row-major + V^T 16-bit", "7", LAUNCHES, None, T * D * 2 + T * 3 * D * 2 + 3 * D * D * 2),
     ("out_proj [T,768]x768  +bias+resid fp32", "2", 2 * LAUNCHES, (0, 2), T * D * 2 + 2 * T * D * 4 + D * D * 2),
     ("fc1      [T,3072]x768 +bias+gelu 16-bit", "1", LAUNCHES, None, T * D * 2 + T * FFN * 2 + D * FFN * 2),
     ("fc2      [T,768]x3072 +bias+resid fp32", "2", 2 * LAUNCHES, (1, 2), T * FFN * 2 + 2 * T * D * 4 + D * FFN * 2),

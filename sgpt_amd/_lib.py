@@ -67,6 +67,9 @@ SIGNATURES = {
     "sgpt_score_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                   C.c_void_p]),
+    "sgpt_score_topk_refined": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                                           C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     "sgpt_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgpt_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64,

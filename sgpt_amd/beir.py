@@ -150,7 +150,7 @@ class DenseRetrievalExactSearch:
 
     def __init__(self, model, batch_size: int = 128, corpus_chunk_size: int = 50000, score_dtype=torch.float32,
                  prefetch_tokenize: bool = True, ctx=None, group=None, distributed: Optional[bool] = None,
-                 score_split: Optional[bool] = None, **kwargs):
+                 score_split: Optional[bool] = None, exact_scorer: str = "refined", **kwargs):
         self.model = model
         self.prefetch_tokenize = prefetch_tokenize
         self.batch_size = batch_size
@@ -158,7 +158,16 @@ class DenseRetrievalExactSearch:
         self.corpus_chunk_size = corpus_chunk_size
         self.show_progress_bar = True
         self.convert_to_tensor = True
-        self.score_dtype = score_dtype          # torch.float32: exact-fp32 MFMA; torch.float16 / bfloat16: 16-bit corpus in HBM
+        self.score_dtype = score_dtype          # torch.float32: fp32 scores (below); torch.float16 / bfloat16: 16-bit corpus in HBM
+        # score_dtype=torch.float32 (the default: what the reference computes, util.py:41-43 in fp32), how:
+        #   "refined" (default, cos_sim): the 16-bit filtered scorer proposes k + head-room candidates per query, every candidate is
+        #             re-scored in exact fp32, and a device-side check (|s16 - s32| <= 1.1e-3 for unit rows) proves the fp32 top-k is
+        #             among them -- else the chunk is redone by the exact pass, predicated on the device flag (sgpt_score_topk_refined);
+        #   "brute":  the exact-fp32 MFMA scorer over every pair (1/16 of the 16-bit rate) -- also what `dot` takes (its error bound
+        #             scales with the row norms, which the host does not know without a sync).
+        if exact_scorer not in ("refined", "brute"):
+            raise ValueError("exact_scorer must be 'refined' or 'brute'")
+        self.exact_scorer = exact_scorer
         self.ctx = ctx                          # device context (default: the model's GPU)
         self.group = group                      # torch.distributed process group of a multi-GPU search (default: WORLD)
         self.distributed = distributed          # None: sharded search iff the group has more than one rank; True: whenever a
@@ -290,11 +299,16 @@ class DenseRetrievalExactSearch:
                                                    show_progress_bar=self.show_progress_bar,
                                                    convert_to_tensor=self.convert_to_tensor, batch_num=tag(batch_num))
                 sub = self._to_dev(ctx, sub)
+                kk = min(top_k + 1, end - start)                                      # :104
+                refined = (self.score_dtype == torch.float32 and self.exact_scorer == "refined" and score_function == "cos_sim"
+                           and hasattr(ctx, "score_topk_refined") and sub.shape[1] % 8 == 0)
                 if score_function == "cos_sim":
                     sub = (ctx.split16(ctx.l2_normalize(sub), "doc", self.score_dtype) if split
                            else ctx.l2_normalize(sub, out_dtype=self.score_dtype))    # util.py:42
-                kk = min(top_k + 1, end - start)                                      # :104
-                val, idx, _ = ctx.score_topk(q_op, sub, kk, idx_base=lo + start, dtype=self.score_dtype)   # :96-108 (NaN -> -1)
+                if refined:     # fp32 scores of the fp32 top-k, found through f16 copies of the rows (:96-108, NaN -> -1)
+                    val, idx, _ = ctx.score_topk_refined(q_op, sub, None, kk, idx_base=lo + start)
+                else:
+                    val, idx, _ = ctx.score_topk(q_op, sub, kk, idx_base=lo + start, dtype=self.score_dtype)   # :96-108 (NaN -> -1)
                 if run_val is None:
                     cand_v, cand_i = val, idx
                 else:

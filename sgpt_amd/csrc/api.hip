@@ -162,6 +162,7 @@ void sgpt_ctx_destroy(sgpt_ctx* c) {
     if (c->ws2) (void)hipFree(c->ws2);
     (void)sgpt_comm_destroy(c);
     if (c->ws3) (void)hipFree(c->ws3);
+    if (c->ws4) (void)hipFree(c->ws4);
     if (c->range_flag) (void)hipFree(c->range_flag);
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c;
@@ -916,9 +917,12 @@ sgpt_status sgpt_scores(sgpt_ctx* c, const void* a, const void* b, int32_t dtype
     return SGPT_OK;
 }
 
-sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int32_t dtype, int32_t nq, int64_t N,
-                            int32_t d, int32_t k, int64_t idx_base, float* run_val, int64_t* run_idx, int32_t n_run,
-                            int32_t* n_out, void* stream) {
+// in_val / in_idx: the running list going in (n_run entries per row, row stride k); run_val / run_idx: the list coming out (they
+// may be the same buffers -- the public entry point).  pred_all (device flag or null): every launch of the call is predicated on
+// it and the call takes the materialise-and-select path -- the sync-free fallback of sgpt_score_topk_refined.
+static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpus, int32_t dtype, int32_t nq, int64_t N,
+                                   int32_t d, int32_t k, int64_t idx_base, const float* in_val, const int64_t* in_idx,
+                                   float* run_val, int64_t* run_idx, int32_t n_run, int32_t* n_out, void* stream, const int* pred_all) {
     if (!c || !q || !corpus || !run_val || !run_idx || nq <= 0 || N <= 0 || k <= 0 || n_run < 0 || n_run > k)
         return fail(c, SGPT_ERR_INVALID, "sgpt_score_topk: bad arguments");
     sgpt_status st = check_score_dims(c, dtype, d);
@@ -980,7 +984,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
     //            survivors per query and chunk through the epilogue's append path: the filtered GEMM went from 1.45 to 1.58 ms
     //            per pass (nq = 1000), and a drift at 10 % of the corpus from 2.2 to 3.5 ms (profiles/r03_score_schedule.txt).
     const int growth = 1;
-    const bool filt = fast && !classic_only && k <= 1024 && chunk % 256 == 0 && N >= 2 * chunk;
+    const bool filt = fast && !classic_only && k <= 1024 && chunk % 256 == 0 && N >= 2 * chunk && pred_all == nullptr;
     const bool sampled = filt && sampled_k;
     const double ratio = (double)cap / ((double)k * (1.0 + 6.0 / std::sqrt((double)k)));   // documents per threshold document
     const long n256_all = N / 256 * 256;
@@ -1122,10 +1126,10 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         }
     };
 
-    const float* pv0 = n_run > 0 ? run_val : nullptr;
-    const int64_t* pi0 = n_run > 0 ? run_idx : nullptr;
+    const float* pv0 = n_run > 0 ? in_val : nullptr;
+    const int64_t* pi0 = n_run > 0 ? in_idx : nullptr;
     if (!filt) {
-        st = classic(0, N, pv0, pi0, n_run, run_val, run_idx, nullptr, chunk);
+        st = classic(0, N, pv0, pi0, n_run, run_val, run_idx, pred_all, chunk);
         if (st != SGPT_OK) return st;
     } else {
         static const bool no_fallback = exp_env("SGPT_SCORE_NOFALLBACK") != nullptr;   // timing experiments ONLY: unsafe
@@ -1136,7 +1140,7 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
         if (sampled) {
             // running best going in: tv[0] / ti[0] = the caller's list padded to k columns, or empty (idx -1 everywhere)
             if (n_run > 0) {
-                launch_topk_select(run_val, k, 0, 0, run_val, run_idx, n_run, k, nq, k, 0, nullptr, tv[0], ti[0], s);
+                launch_topk_select(in_val, k, 0, 0, in_val, in_idx, n_run, k, nq, k, 0, nullptr, tv[0], ti[0], s);
             }   // (n_run == 0: the prologue marked tv[0] / ti[0] empty -- idx -1, whatever the values say)
             // thresholds: the k-th best of {running best} U {S documents at stride s_stride across the shard}; only the VALUES
             // of this selection are used (its indices are sample positions) -- the filtered chunks below re-score the sampled
@@ -1206,6 +1210,83 @@ sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int3
             st = classic(seen, N, tv[cur], ti[cur], k, run_val, run_idx, nullptr, chunk);
             if (st != SGPT_OK) return st;
         }
+    }
+    if (n_out) { const int64_t tot = (int64_t)n_run + N; *n_out = (int32_t)(tot < k ? tot : k); }
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
+sgpt_status sgpt_score_topk(sgpt_ctx* c, const void* q, const void* corpus, int32_t dtype, int32_t nq, int64_t N,
+                            int32_t d, int32_t k, int64_t idx_base, float* run_val, int64_t* run_idx, int32_t n_run,
+                            int32_t* n_out, void* stream) {
+    return score_topk_impl(c, q, corpus, dtype, nq, N, d, k, idx_base, run_val, run_idx, run_val, run_idx, n_run, n_out, stream, nullptr);
+}
+
+// The exact-fp32 top-k at the 16-bit scorer's speed (round 5): what `torch.mm(q, c.T)` + `torch.topk` of the reference compute in
+// fp32 (util.py:41-43, exact_search.py:96-108), found in two stages.
+//   1. the 16-bit filtered scorer over f16 copies of the rows takes the k' = k + M best per query (M: head-room, k' <= 64 keeps
+//      the sampled schedule);
+//   2. every candidate is re-scored in exact fp32 from the fp32 rows (rescore_kernel), merged with the running list, top-k.
+// Guarantee: rows L2-normalised (or any rows with |q| |d| <= 1): |s16 - s32| <= eps = 2^-10 (two roundings of relative 2^-11,
+// Cauchy-Schwarz) + 2^-25 (|q|_1 + |d|_1) (subnormal flushes) + the two fp32 accumulations ~ 1.1e-3.  A document outside the k'
+// candidates has s16 <= u = the k'-th best; if u < t - 2 eps (t = the k-th best s16) its fp32 score is below t - eps, which k
+// candidates reach or exceed: it cannot be in the fp32 top-k.  `margin` >= 2 eps is the caller's statement of that bound for its
+// rows (2.5e-3 for unit rows; scale by max |q| max |d| for raw dot products).  Queries for which the check fails (masses of
+// near-equal scores: duplicated documents) raise a device flag, and the chunk is redone by the exact-fp32 materialise-and-select
+// pass, every launch predicated on that flag -- sync-free, exact either way; `refined_fallbacks` counts nothing on the host.
+sgpt_status sgpt_score_topk_refined(sgpt_ctx* c, const float* q, const float* corpus32, const void* corpus16, int32_t dtype16,
+                                    int32_t nq, int64_t N, int32_t d, int32_t k, int64_t idx_base, float margin,
+                                    float* run_val, int64_t* run_idx, int32_t n_run, int32_t* n_out, int32_t* fallback_flag_out,
+                                    void* stream) {
+    if (!c || !q || !corpus32 || !corpus16 || !run_val || !run_idx || nq <= 0 || N <= 0 || k <= 0 || n_run < 0 || n_run > k ||
+        !(margin > 0.f) || (dtype16 != SGPT_F16 && dtype16 != SGPT_BF16) || d % 8)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_score_topk_refined: bad arguments (16-bit stage-1 rows, d % 8 == 0, margin > 0)");
+    HIPC(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // head-room: as many extra candidates as the sampled schedule allows (k' <= 64), at least 8; deep lists (k > 56) take k / 8
+    int kp = k <= 56 ? 64 : k + (k / 8 > 8 ? k / 8 : 8);
+    if (kp > 1024 && k <= 1024) kp = 1024;
+    if ((int64_t)kp > N) kp = (int)N;
+    if (kp <= k || kp > 1024) {       // nothing to filter with (k >= N) or lists beyond the filtered scorer: the exact pass itself
+        if (fallback_flag_out) *fallback_flag_out = -1;
+        return score_topk_impl(c, q, corpus32, SGPT_F32, nq, N, d, k, idx_base, run_val, run_idx, run_val, run_idx, n_run, n_out, stream, nullptr);
+    }
+    const int ldc = kp + k;
+    const size_t q16_b = align_up((size_t)nq * d * 2, 256), lv_b = align_up((size_t)nq * kp * 4, 256), li_b = align_up((size_t)nq * kp * 8, 256);
+    const size_t cv_b = align_up((size_t)nq * ldc * 4, 256), ci_b = align_up((size_t)nq * ldc * 8, 256);
+    const size_t sv_b = align_up((size_t)nq * k * 4, 256), si_b = align_up((size_t)nq * k * 8, 256);
+    sgpt_status st = ensure(c, &c->ws4, &c->ws4_bytes, q16_b + lv_b + li_b + cv_b + ci_b + sv_b + si_b + 256);
+    if (st != SGPT_OK) return st;
+    char* b = (char*)c->ws4;
+    void* q16 = b; b += q16_b;
+    float* lv = (float*)b; b += lv_b;
+    int64_t* li = (int64_t*)b; b += li_b;
+    float* cv = (float*)b; b += cv_b;
+    int64_t* ci = (int64_t*)b; b += ci_b;
+    float* sv = (float*)b; b += sv_b;
+    int64_t* si = (int64_t*)b; b += si_b;
+    int* flag = (int*)b;
+    HIPC(c, hipMemsetAsync(flag, 0, 4, s));
+    launch_f32_to_16(q, (int64_t)nq * d, q16, dtype16, s);
+    // stage 1: the k' best by 16-bit score (fresh list)
+    int32_t n1 = 0;
+    st = score_topk_impl(c, q16, corpus16, dtype16, nq, N, d, kp, idx_base, lv, li, lv, li, 0, &n1, stream, nullptr);
+    if (st != SGPT_OK) return st;
+    launch_refine_check(lv, k, kp, margin, nq, flag, s);
+    // stage 2: exact fp32 scores of the candidates | the running list -> top-k
+    if (n_run > 0) {      // (kept for the fallback: it starts from the list as it was before this chunk)
+        HIPC(c, hipMemcpy2DAsync(sv, (size_t)k * 4, run_val, (size_t)k * 4, (size_t)n_run * 4, nq, hipMemcpyDeviceToDevice, s));
+        HIPC(c, hipMemcpy2DAsync(si, (size_t)k * 8, run_idx, (size_t)k * 8, (size_t)n_run * 8, nq, hipMemcpyDeviceToDevice, s));
+    }
+    launch_rescore(q, corpus32, li, kp, nq, kp, d, idx_base, N, cv, ci, ldc, s);
+    launch_list_append(run_val, run_idx, k, n_run, nq, cv, ci, ldc, kp, s);
+    launch_topk_select(cv, ldc, 0, 0, cv, ci, kp + n_run, ldc, nq, k, 0, nullptr, run_val, run_idx, s);
+    // the predicated exact pass (no-op launches unless a query failed the check)
+    st = score_topk_impl(c, q, corpus32, SGPT_F32, nq, N, d, k, idx_base, sv, si, run_val, run_idx, n_run, nullptr, stream, flag);
+    if (st != SGPT_OK) return st;
+    if (fallback_flag_out) {     // optional, host-synchronising: did the exact pass run? (tests / diagnostics; pass NULL to stay asynchronous)
+        HIPC(c, hipMemcpyAsync(fallback_flag_out, flag, 4, hipMemcpyDeviceToHost, s));
+        HIPC(c, hipStreamSynchronize(s));
     }
     if (n_out) { const int64_t tot = (int64_t)n_run + N; *n_out = (int32_t)(tot < k ? tot : k); }
     HIPC(c, hipGetLastError());

@@ -346,6 +346,12 @@ void launch_topk_select(const float* scores, long ld, long n, long idx_base, con
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
                         const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s,
                         const int* pred = nullptr, float* thr_out = nullptr);   // thr_out[q] = the k-th best, one ulp lower (or null)
+// refined scorer (sgpt_score_topk_refined): exact fp32 scores of stage-1 candidates, the guarantee check, list concatenation
+void launch_rescore(const float* q, const float* corpus, const int64_t* idx, long ld_idx, int nq, int m, int d, long idx_base,
+                    long n_docs, float* out_val, int64_t* out_idx, long ld_out, hipStream_t s);
+void launch_refine_check(const float* v16, int k, int kp, float margin, int nq, int* flag, hipStream_t s);
+void launch_list_append(const float* in_val, const int64_t* in_idx, long ld_in, int n_run, int nq, float* out_val, int64_t* out_idx,
+                        long ld_out, int col0, hipStream_t s);
 // scorer pass prologue in one launch: q -> zero-padded qpad (byte counts, multiples of 16), counters[n] = 0, idx_list[n] = -1
 void launch_score_prep(const void* q, void* qpad, long q_bytes, long qpad_bytes, int* counters, long n_counters, long long* idx_list,
                        long n_idx, hipStream_t s);

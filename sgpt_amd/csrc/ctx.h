@@ -13,6 +13,7 @@ struct sgpt_ctx {
     void* ws = nullptr; size_t ws_bytes = 0;        // encoder activations
     void* ws2 = nullptr; size_t ws2_bytes = 0;      // scorer: score chunk + ping-pong top-k
     void* ws3 = nullptr; size_t ws3_bytes = 0;      // multi-GPU exchange staging (comm.hip)
+    void* ws4 = nullptr; size_t ws4_bytes = 0;      // refined scorer: 16-bit queries, stage-1 lists, candidate list, saved running list, flag
     void* comm = nullptr;                           // ncclComm_t of this ctx (sgpt_comm_init), one per process / GPU
     int comm_rank = 0, comm_world = 0;
     // bumped whenever a library-owned buffer that launched kernels point into is re-allocated (workspace growth,

@@ -503,7 +503,79 @@ __global__ __launch_bounds__(256) void score_prep_kernel(const uint4* __restrict
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_idx; i += stride) idx_list[i] = -1;
 }
 
+// Stage 2 of the refined scorer (sgpt_score_topk_refined): the EXACT fp32 score of every stage-1 candidate.  One wave per
+// (query, candidate): lane l sums the float4 chunks l, l + 64, ... of the two rows, the wave adds its 64 partial sums in a fixed
+// butterfly -- deterministic, independent of nq / m / the launch shape.  idx < 0 (an unused slot) -> (-inf, -1); NaN -> -1
+// (exact_search.py:99).  Values and indices land in the first m columns of a [nq, ld_out] list that the caller completes with
+// the running list and hands to topk_select_kernel.
+__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ q, const float* __restrict__ corpus,
+                                                      const int64_t* __restrict__ idx, long ld_idx, int m, int d, long idx_base,
+                                                      long n_docs, float* __restrict__ out_val, int64_t* __restrict__ out_idx, long ld_out) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), qi = blockIdx.y, lane = threadIdx.x & 63;
+    if (j >= m) return;
+    const int64_t id = idx[(long)qi * ld_idx + j];
+    const long row = (long)(id - idx_base);
+    float v = -INFINITY;
+    if (id >= 0 && row >= 0 && row < n_docs) {
+        const float4* a = reinterpret_cast<const float4*>(q + (long)qi * d);
+        const float4* b = reinterpret_cast<const float4*>(corpus + row * d);
+        float acc = 0.f;
+        for (int c = lane; c < d / 4; c += 64) {
+            const float4 x = a[c], y = b[c];
+            acc = __builtin_fmaf(x.x, y.x, acc); acc = __builtin_fmaf(x.y, y.y, acc);
+            acc = __builtin_fmaf(x.z, y.z, acc); acc = __builtin_fmaf(x.w, y.w, acc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        v = acc != acc ? -1.0f : acc;
+    }
+    if (lane == 0) {
+        out_val[(long)qi * ld_out + j] = v;
+        out_idx[(long)qi * ld_out + j] = v > -INFINITY ? id : (int64_t)-1;
+    }
+}
+
+// The guarantee of the refined scorer, checked per query on the stage-1 (16-bit) scores, sorted descending: every document
+// outside the kp candidates scores at most v16[kp-1]; if that is more than `margin` = 2 eps below the k-th best 16-bit score,
+// no outsider can reach the fp32 top-k (|s16 - s32| <= eps for every pair).  A query for which it does not hold -- a mass of
+// near-equal scores: duplicated documents -- raises the flag that switches the predicated exact pass on.
+__global__ __launch_bounds__(256) void refine_check_kernel(const float* __restrict__ v16, int k, int kp, float margin, int nq,
+                                                           int* __restrict__ flag) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    const float t = v16[(long)qi * kp + (k - 1)], u = v16[(long)qi * kp + (kp - 1)];
+    if (u > -INFINITY && !(u < t - margin)) atomicOr(flag, 1);
+}
+
+// running list [nq, n_run] (row stride ld_in) -> columns [col0, col0 + n_run) of a [nq, ld_out] list
+__global__ __launch_bounds__(256) void list_append_kernel(const float* __restrict__ in_val, const int64_t* __restrict__ in_idx, long ld_in,
+                                                          int n_run, int nq, float* __restrict__ out_val, int64_t* __restrict__ out_idx,
+                                                          long ld_out, int col0) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)nq * n_run) return;
+    const long qi = i / n_run, j = i - qi * n_run;
+    out_val[qi * ld_out + col0 + j] = in_val[qi * ld_in + j];
+    out_idx[qi * ld_out + col0 + j] = in_idx[qi * ld_in + j];
+}
+
 }  // namespace
+
+void launch_rescore(const float* q, const float* corpus, const int64_t* idx, long ld_idx, int nq, int m, int d, long idx_base,
+                    long n_docs, float* out_val, int64_t* out_idx, long ld_out, hipStream_t s) {
+    hipLaunchKernelGGL(rescore_kernel, dim3((m + 3) / 4, nq), dim3(256), 0, s, q, corpus, idx, ld_idx, m, d, idx_base, n_docs,
+                       out_val, out_idx, ld_out);
+}
+
+void launch_refine_check(const float* v16, int k, int kp, float margin, int nq, int* flag, hipStream_t s) {
+    hipLaunchKernelGGL(refine_check_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, v16, k, kp, margin, nq, flag);
+}
+
+void launch_list_append(const float* in_val, const int64_t* in_idx, long ld_in, int n_run, int nq, float* out_val, int64_t* out_idx,
+                        long ld_out, int col0, hipStream_t s) {
+    if (n_run <= 0) return;
+    hipLaunchKernelGGL(list_append_kernel, dim3((unsigned)(((long)nq * n_run + 255) / 256)), dim3(256), 0, s, in_val, in_idx, ld_in,
+                       n_run, nq, out_val, out_idx, ld_out, col0);
+}
 
 void launch_score_prep(const void* q, void* qpad, long q_bytes, long qpad_bytes, int* counters, long n_counters, long long* idx_list,
                        long n_idx, hipStream_t s) {

@@ -298,6 +298,38 @@ class Context:
                                            _stream_ptr(self.device)), "sgpt_score_topk")
         return val, idx, int(n_out.value)
 
+    REFINE_MARGIN_UNIT_F16 = 2.5e-3      # 2 eps for L2-normalised rows with IEEE-half stage-1 copies (include/sgpt_hip.h)
+
+    def score_topk_refined(self, q: torch.Tensor, corpus32: torch.Tensor, corpus16: Optional[torch.Tensor], k: int,
+                           idx_base: int = 0, run: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
+                           margin: Optional[float] = None, report: bool = False):
+        """The fp32 top-k (fp32 scores, the fp32 set) at the 16-bit scorer's speed: sgpt_score_topk_refined.  q, corpus32: fp32
+        rows (L2-normalised for the default margin); corpus16: their f16 rounding (None: made here).  report=True synchronises
+        and returns a fourth value: 1 if the exact fallback pass ran, 0 if not, -1 if the call was the exact pass outright."""
+        q = q.to(device=self.device, dtype=torch.float32).contiguous()
+        corpus32 = corpus32.to(device=self.device, dtype=torch.float32).contiguous()
+        if corpus16 is None:
+            corpus16 = self.to_16(corpus32, torch.float16)
+        if corpus16.dtype not in (torch.float16, torch.bfloat16) or corpus16.shape != corpus32.shape or not corpus16.is_contiguous():
+            raise ValueError("corpus16 must be the contiguous 16-bit rounding of corpus32")
+        if margin is None:
+            if corpus16.dtype != torch.float16:
+                raise ValueError("the default margin is the bound for IEEE-half copies of unit rows: pass margin= for bf16 copies")
+            margin = self.REFINE_MARGIN_UNIT_F16
+        nq, d = q.shape
+        N = corpus32.shape[0]
+        if run is None:
+            val = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            idx = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+            n_run = 0
+        else:
+            val, idx, n_run = run
+        n_out, fb = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.sgpt_score_topk_refined(self.handle, _p(q), _p(corpus32), _p(corpus16), DT_CODE[corpus16.dtype], nq, N, d, k,
+                                                   idx_base, float(margin), _p(val), _p(idx), n_run, C.byref(n_out),
+                                                   C.byref(fb) if report else None, _stream_ptr(self.device)), "sgpt_score_topk_refined")
+        return (val, idx, int(n_out.value), int(fb.value)) if report else (val, idx, int(n_out.value))
+
     def topk_merge(self, val: torch.Tensor, idx: torch.Tensor, k: int,
                    exclude_idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         val = val.to(device=self.device, dtype=torch.float32).contiguous()

@@ -505,3 +505,56 @@ def test_score_topk_sampled_schedule_random_shapes(ctx, seed):
         wv, wi, wn = _sliced_classic(ctx, q, c, k, chunk, idx_base=idx_base)
     assert n == wn == k, (nq, N, k, d, kind)
     assert torch.equal(val, wv) and torch.equal(idx, wi), (nq, N, k, d, kind, str(dt))
+
+
+# ---------------------------------------------------------------- refined scorer (round 5) -----
+@pytest.mark.parametrize("case", ["random", "anisotropic", "duplicates", "small", "deep", "running"])
+def test_refined_scorer_returns_the_exact_fp32_topk(ctx, case):
+    """sgpt_score_topk_refined: fp32 scores of the fp32 top-k (what the reference's torch.mm + torch.topk compute, util.py:41-43,
+    exact_search.py:96-108) through f16 candidate proposals + exact re-scoring.  Against an fp64 product of the same fp32 rows: the
+    returned ids are the fp64 top-k except where the fp64 scores of two documents differ by less than fp32 resolution, every
+    returned score is the pair's fp32 dot product (2e-6), sorted descending.  'duplicates': blocks of 200 identical documents put
+    more equal scores around the k-th best than the head-room holds -- the device-side check must send the chunk to the exact
+    pass (report == 1) and the answer stays exact; 'small' (N below k + head-room) is the exact pass outright; 'deep': k = 1001;
+    'running': two chunks through the running list equal one pass."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    nq, N, d, k = 257, 60000, 768, 11
+    base = torch.randn(1, d, generator=g) * (3.0 if case == "anisotropic" else 0.0)
+    c = base + torch.randn(N, d, generator=g)
+    q = base + torch.randn(nq, d, generator=g)
+    if case == "duplicates":
+        c = c[: N // 200].repeat_interleave(200, dim=0)
+    if case == "small":
+        N = 40
+        c = c[:N]
+    if case == "deep":
+        k, nq = 1001, 64
+        q = q[:nq]
+    q = torch.nn.functional.normalize(q, dim=1).cuda()
+    c = torch.nn.functional.normalize(c, dim=1).cuda()
+    kk = min(k, N)
+    if case == "running":
+        h = N // 2 + 17
+        r1 = ctx.score_topk_refined(q, c[:h].contiguous(), None, k, idx_base=0)
+        val, idx, n, fb = ctx.score_topk_refined(q, c[h:].contiguous(), None, k, idx_base=h, run=(r1[0], r1[1], r1[2]), report=True)
+    else:
+        val, idx, n, fb = ctx.score_topk_refined(q, c, None, k, idx_base=7 if case == "random" else 0, report=True)
+    base_i = 7 if case == "random" else 0
+    assert n == kk
+    assert fb == {"duplicates": 1, "small": -1}.get(case, 0), (case, fb)
+    val, idx = val.cpu().numpy()[:, :kk], idx.cpu().numpy()[:, :kk] - base_i
+    full = (q.double() @ c.double().T).cpu().numpy()
+    got = np.take_along_axis(full, idx, 1)
+    assert np.abs(val - got).max() < 2e-6                                # the scores ARE the fp32 dot products of their pairs
+    assert (np.diff(val, axis=1) <= 0).all()
+    kth = -np.sort(-full, axis=1)[:, kk - 1]
+    assert (got >= kth[:, None] - 3e-7).all()                            # nothing below the true k-th best (up to fp32 resolution)
+    for r in range(0, nq, 37):
+        assert len(set(idx[r].tolist())) == kk
+    # and the brute-force exact-fp32 scorer agrees (same ids where scores are distinct; values to fp32 rounding)
+    bv, bi, _ = ctx.score_topk(q, c, k, idx_base=base_i, dtype=torch.float32)
+    bv, bi = bv.cpu().numpy()[:, :kk], bi.cpu().numpy()[:, :kk] - base_i
+    assert np.abs(bv - val).max() < 2e-6
+    if case not in ("duplicates",):
+        same = (bi == idx).mean()
+        assert same > 0.999, same

@@ -77,10 +77,10 @@ def test_pack_host_layout():
 
 
 def test_plan_batches_covers_everything_sorted():
-    from sgpt_amd.model import ALIGN, SGPTModel
+    from sgpt_amd.model import ALIGN, SGPTConfig, SGPTModel
     lens = np.random.default_rng(0).integers(1, 129, size=1000)
     fake = SGPTModel.__new__(SGPTModel)
-    fake.max_tokens_per_call = 4096
+    fake.max_tokens_per_call, fake.cfg, fake.device = 4096, SGPTConfig(), "cpu"
     plan = SGPTModel.plan_batches(fake, lens)
     allidx = np.concatenate(plan)
     assert sorted(allidx.tolist()) == list(range(1000))
