@@ -541,7 +541,11 @@ def test_refined_scorer_returns_the_exact_fp32_topk(ctx, case):
         val, idx, n, fb = ctx.score_topk_refined(q, c, None, k, idx_base=7 if case == "random" else 0, report=True)
     base_i = 7 if case == "random" else 0
     assert n == kk
-    assert fb == {"duplicates": 1, "small": -1}.get(case, 0), (case, fb)
+    # did the predicated exact pass run?  never for well-spread scores; always when blocks of identical documents sit on the k-th best;
+    # concentrated score distributions ('anisotropic': all cosines within +-0.015) and deep lists (k = 1001: 23 slots of head-room)
+    # MAY need it -- the worst-case bound on |s16 - s32| (1.1e-3) is then as wide as the gaps between ranks -- and stay exact
+    assert fb in (0, 1) and (case != "random" or fb == 0) and (case != "duplicates" or fb == 1), (case, fb)
+    print(f"refined scorer [{case}]: exact pass ran = {fb}")
     val, idx = val.cpu().numpy()[:, :kk], idx.cpu().numpy()[:, :kk] - base_i
     full = (q.double() @ c.double().T).cpu().numpy()
     got = np.take_along_axis(full, idx, 1)
