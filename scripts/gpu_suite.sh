@@ -76,7 +76,7 @@ PY
     ab_varlen)
       : > gpurun_out/ab_varlen.txt
       for rnd in 1 2 3; do for mode in "" "--equal-calls"; do
-        v=$( timeout 600 python bench.py --steps 9 --warmup 2 --no-cpu-baseline --no-1m --no-modes $mode 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); v=d['varlen']; print(v['sentences_per_s'], 'sent/s', v['end_to_end_frac_of_mfma_roofline'], v['rows_per_call'], '| fixed-128', d['value'])" )
+        v=$( timeout 600 python bench.py ${VARLEN_BENCH_ARGS:---steps 9 --warmup 2 --no-1m} --no-cpu-baseline --no-modes $mode 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); v=d['varlen']; print(v['sentences_per_s'], 'sent/s', v['end_to_end_frac_of_mfma_roofline'], v['rows_per_call'], '| fixed-128', d['value'])" )
         echo "round $rnd calls ${mode:-round-aware}: $v" | tee -a gpurun_out/ab_varlen.txt
       done; done ;;
     varlen_prof)

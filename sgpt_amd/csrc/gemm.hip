@@ -1058,8 +1058,13 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_QKV) {
         // bulk: the 256x256 kernel with per-tile operand roles (caller checked gemm_qkv_bulk()); else the query-sized form
         if (gemm_qkv_bulk(a.M, a.N, a.K, a.n_split, a.force256 != 0) && a.lda == a.ldw && a.bias == nullptr && a.lo_delta == 0 &&
-            a.lo_delta2 == 0 && a.m_valid == a.M)
-            return launch256d<H, EPI_QKV, H, true>(a, s, true);
+            a.lo_delta2 == 0 && a.m_valid == a.M) {
+            GemmArgs b = a;
+#if defined(SGPT_QKV_GM) && defined(SGPT_QKV_GN)
+            b.gm = SGPT_QKV_GM; b.gn = SGPT_QKV_GN;       // (A/B builds: supertile shape of the nine-column-tile launch)
+#endif
+            return launch256d<H, EPI_QKV, H, true>(b, s, true);
+        }
         return launch<H, EPI_QKV, H, true>(a, s);                   // caller checked gemm_qkv_one_launch()
     }
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
