@@ -87,6 +87,7 @@ PY
         python scripts/prof_summary.py gpurun_out/vprof_$L/trace_results.db 14 > gpurun_out/varlen_prof_$L.csv; rm -rf gpurun_out/vprof_$L
         head -14 gpurun_out/varlen_prof_$L.csv | cut -c1-160
       done ;;
+    graph_probe) ( python scripts/score_graph_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_graph_probe.txt ;;
     probe) ( python scripts/score_shape_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_shape_probe.txt ;;
     ab_shapes)
       : > gpurun_out/ab_shapes.txt
