@@ -621,7 +621,19 @@ def main():
             mfma_busy, eff_clock = tj.get("gemm_mfma_busy_frac"), tj.get("gemm_effective_clock_ghz")
             traffic_source = f"profiles/{tname} (replayed from the committed rocprofv3 --pmc passes of this command, not measured in this run)"
             break
-    roofline = {"bound": "mfma",
+    # the vendor yardstick of the same five launch shapes (committed measurement, same kernels): what hipBLASLt reaches with NO
+    # epilogue, what gemm256d reaches with bias / GELU / residual / transposition fused, and its bare k-loop
+    yardstick = None
+    ypath = os.path.join(ROOT, "profiles", "r05_hipblaslt_yardstick.txt")
+    if os.path.exists(ypath) and args.dtype in ("f16", "bf16"):
+        for ln in open(ypath):
+            if ln.startswith(args.dtype) and "five launches of a block" in ln:
+                cells = [c.split() for c in ln.split("|")[1:]]
+                yardstick = {"vendor_gemm_no_epilogue_frac": float(cells[0][2]), "gemm256d_with_fused_epilogues_frac": float(cells[1][2]),
+                             "gemm256d_bare_k_loop_frac": float(cells[2][2]),
+                             "source": "profiles/r05_hipblaslt_yardstick.txt (scripts/hipblaslt_yardstick.py: torch.matmul -> hipBLASLt vs sgpt_bench_gemm, "
+                                       "five projection shapes at 131 072 rows, interleaved rounds, replayed -- not measured in this run)"}
+    roofline = {"bound": "mfma", "yardstick": yardstick,
                 "kernel": "gemm256 (16-bit operands, 256x256x64 persistent LDS-DMA GEMM, asymmetric 3+2-slot LDS ring; the 4 projection launches per block: QKV in one, out-proj, fc1, fc2)"
                           if args.dtype != "fp32" else "gemm_kernel<float> (exact fp32 MFMA 128x128x32)",
                 "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gemm_tflops / peak, 4),
