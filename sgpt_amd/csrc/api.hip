@@ -970,6 +970,9 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
     // past 1024 entries the appends cost the streaming tile more than the smaller sample returns
     // (re-measured with the LDS-staged appends, nq = 1000: 125 k documents 0.28 / 0.36 / 0.40 ms with 512 / 1024 / 2048 entries,
     //  250 k documents 0.51 / 0.50 / 0.58 -- the short lists stay)
+#ifndef SGPT_SAMPLE_TOP2
+#define SGPT_SAMPLE_TOP2 1      // 0: the materialised sample tile + select of round 4 (A/B builds)
+#endif
 #ifndef SGPT_CAP_SHORT
 #define SGPT_CAP_SHORT 512
 #endif
@@ -1145,8 +1148,19 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
             // thresholds: the k-th best of {running best} U {S documents at stride s_stride across the shard}; only the VALUES
             // of this selection are used (its indices are sample positions) -- the filtered chunks below re-score the sampled
             // documents like any other and find them again
-            score_tile(0, S, S, nullptr, s_stride);
-            launch_topk_select(sc, S, S, 0, tv[0], ti[0], k, k, nq, k, 0, nullptr, th_v, th_i, s, nullptr, thr_dense);   // (+ the inclusive threshold)
+            if (SGPT_SAMPLE_TOP2 && nq_pad >= 256 && S % 256 == 0) {
+                // the sample's scores never leave the GEMM: 8 floats per query row and 256-document tile (the two best of each
+                // wave's 64 documents, EPI_SCORE_TOP2); the k-th best of those and the running list is the threshold
+                const long ld2 = 8 * (S / 256);
+                GemmArgs h{};
+                h.A = qpad; h.lda = d; h.M = nq_pad; h.m_valid = nq; h.K = d;
+                h.W = corpus; h.ldw = (long)d * s_stride; h.N = (int)S; h.out = sc; h.ldo = ld2;
+                gemm(c, dtype, EPI_SCORE_TOP2, SGPT_F32, h, s);
+                launch_topk_select(sc, ld2, ld2, 0, tv[0], ti[0], k, k, nq, k, 0, nullptr, th_v, th_i, s, nullptr, thr_dense);
+            } else {
+                score_tile(0, S, S, nullptr, s_stride);
+                launch_topk_select(sc, S, S, 0, tv[0], ti[0], k, k, nq, k, 0, nullptr, th_v, th_i, s, nullptr, thr_dense);   // (+ the inclusive threshold)
+            }
             eff = S;
         } else {
             // first chunk: materialise + select -> the initial thresholds.  One whole wave of tiles is enough (the

@@ -199,6 +199,8 @@ enum GemmEpi {
     EPI_NONE = 5,         // micro-benchmark only: no stores (accumulators kept live)
     EPI_SCORE_FILTER = 6, // scorer, chunks after the first: append (score, index) of every score > thr[m] to a
                           // per-query candidate list instead of materialising the score tile
+    EPI_SCORE_TOP2 = 8,   // scorer's threshold sample (round 5): per query row and (document tile, wave) the two best scores of the wave's
+                          // 64 documents -> out[m][8 * (n0 / 256) + 2 * wn + {0, 1}]; nothing else leaves the registers (256x256 kernel only)
     EPI_QKV = 7,          // fused QKV projection: columns < n_split -> out[m][n] (q | k, row-major), the rest -> out2[n - n_split][m]
                           // (V^T); one launch for query-sized batches, split into EPI_STORE + EPI_VT launches otherwise
 };

@@ -1039,7 +1039,7 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     // leaves most of the 256 CUs idle; the register-staged kernel's 128x128 / 64x64 tiles fill the chip instead.
     // Bit-identical results (see gemm_kernel), so the embeddings stay batch-invariant.  SGPT_NO_SMALL_TILE=1: A/B.
     static const bool small_tiles = exp_env("SGPT_NO_SMALL_TILE") == nullptr;
-    const bool scorer = epi == EPI_SCORE || epi == EPI_SCORE_FILTER;
+    const bool scorer = epi == EPI_SCORE || epi == EPI_SCORE_FILTER || epi == EPI_SCORE_TOP2;
     // a.force256 (per ctx, sgpt_ctx_set_tile_policy): keep 256x256 tiles for problems the small-tile rule would hand to
     // the register-staged kernel -- kernel-level tests of single-tile shapes
     // (the GELU launch -- N = 4 d, a VALU-heavy epilogue -- wants a whole round of 256x256 tiles before the LDS-DMA kernel pays:
@@ -1082,6 +1082,7 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
         }
         if (epi == EPI_SCORE) return launch256d<H, EPI_SCORE, float, true>(a, s, deep_a);
         if (epi == EPI_SCORE_FILTER) return launch256d<H, EPI_SCORE_FILTER, float, true>(a, s, deep_a);
+        if (epi == EPI_SCORE_TOP2) return launch256d<H, EPI_SCORE_TOP2, float, true>(a, s, deep_a);
         if (epi == EPI_STORE && o16) return launch256d<H, EPI_STORE, H, true>(a, s, deep_a);
         if (epi == EPI_VT) return launch256d<H, EPI_VT, H, false>(a, s, deep_a);
         if (epi == EPI_BIAS_GELU) return launch256d<H, EPI_BIAS_GELU, H, true>(a, s, deep_a);

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
             if (in_lds) { s_val[i] = v; s_idx[i] = id; } else { ov[i] = v; oi[i] = id; }
         }
         done = true;
-    } else if (k <= TK_FAST_KMAX && total <= 1024 && in_lds) {
+    } else if (k <= TK_FAST_KMAX && total <= TK_SORT_MAX && in_lds) {
         // ---------------- short rows (cross-chunk / cross-rank merges: 2 k ... world * k candidates): everything into LDS,
         // the k best by k rounds of a wave-wide arg-max -- ~2 us where the radix path below (4 histogram passes + tie
         // handling, built for rows of 10^4 ... 10^6 scores) took ~25: the fold of 8 ranks' lists, the chunk-loop merge ----
