@@ -87,6 +87,13 @@ PY
         python scripts/prof_summary.py gpurun_out/vprof_$L/trace_results.db 14 > gpurun_out/varlen_prof_$L.csv; rm -rf gpurun_out/vprof_$L
         head -14 gpurun_out/varlen_prof_$L.csv | cut -c1-160
       done ;;
+    ab_score_prof)
+      for tag in default ${LIBS}; do
+        L=$(libpath $tag); rm -rf gpurun_out/sprof_$tag; mkdir -p gpurun_out/sprof_$tag
+        ( cd /tmp && SGPT_HIP_LIB=$L N=${SPROF_N:-125000} REPS=20 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/sprof_$tag -o trace -- python $R/scripts/score_bench.py ) > gpurun_out/sprof_$tag.log 2>&1
+        echo "--- lib $tag: $(grep 'per pass' gpurun_out/sprof_$tag.log)"
+        python scripts/prof_summary.py gpurun_out/sprof_$tag/trace_results.db 12 | cut -c1-170 | tee gpurun_out/score_prof_$tag.csv; rm -rf gpurun_out/sprof_$tag
+      done ;;
     graph_probe) ( python scripts/score_graph_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_graph_probe.txt ;;
     probe) ( python scripts/score_shape_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_shape_probe.txt ;;
     ab_shapes)

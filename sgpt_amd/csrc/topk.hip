@@ -63,6 +63,47 @@ __device__ __forceinline__ bool sorts_before(float va, int64_t ia, float vb, int
     return va > vb || (va == vb && ia < ib);
 }
 
+// Wave-wide arg-max of (value, index, position) triples under sorts_before (ties -> lower index; a total order, so the result does
+// not depend on the pairing), every lane ending with the winner.  Round 5: the butterfly runs on the VALU -- DPP quad permutes
+// (lane ^ 1, lane ^ 2), row_half_mirror / row_mirror (the other four lanes, the other eight of a row of 16) and gfx950's
+// v_permlane16_swap / v_permlane32_swap (the other rows) -- instead of `__shfl_xor`, i.e. ds_bpermute round trips through the LDS
+// queue: four dependent ~100-cycle trips per step, 6 steps, k rounds on ONE wave were 16 of the 20 us of the sample's select and
+// most of cand_merge's 18 us.  `valid` (pos >= 0) lets empty lanes lose every comparison.
+template <int CTRL>
+__device__ __forceinline__ void argmax_step_dpp(float& bv, int64_t& bi, int& bp) {
+    const float ov = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(bv), CTRL, 0xf, 0xf, false));
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)bi & 0xffffffffull), CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)bi >> 32), CTRL, 0xf, 0xf, false);
+    const int op = __builtin_amdgcn_update_dpp(0, bp, CTRL, 0xf, 0xf, false);
+    const int64_t oi = (int64_t)(((unsigned long long)hi << 32) | lo);
+    if (op >= 0 && (bp < 0 || sorts_before(ov, oi, bv, bi))) { bv = ov; bi = oi; bp = op; }
+}
+template <bool ROW32>
+__device__ __forceinline__ void argmax_step_rows(float& bv, int64_t& bi, int& bp) {
+    auto other = [](unsigned x) -> unsigned {
+        // the swap hands every lane the partner row's value in ONE of the two results (the other one is its own): pick the one that differs
+        // in position by construction -- results r[0] / r[1] hold (own, partner) for one half of the lanes and (partner, own) for the other
+        const auto r = ROW32 ? __builtin_amdgcn_permlane32_swap(x, x, false, false) : __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const bool upper = ROW32 ? (lane & 32u) != 0 : (lane & 16u) != 0;
+        return upper ? r[0] : r[1];
+    };
+    const float ov = __uint_as_float(other(__float_as_uint(bv)));
+    const unsigned lo = other((unsigned)((unsigned long long)bi & 0xffffffffull));
+    const unsigned hi = other((unsigned)((unsigned long long)bi >> 32));
+    const int op = (int)other((unsigned)bp);
+    const int64_t oi = (int64_t)(((unsigned long long)hi << 32) | lo);
+    if (op >= 0 && (bp < 0 || sorts_before(ov, oi, bv, bi))) { bv = ov; bi = oi; bp = op; }
+}
+__device__ __forceinline__ void wave_argmax(float& bv, int64_t& bi, int& bp) {
+    argmax_step_dpp<0xB1>(bv, bi, bp);      // quad_perm [1,0,3,2]: lane ^ 1
+    argmax_step_dpp<0x4E>(bv, bi, bp);      // quad_perm [2,3,0,1]: lane ^ 2
+    argmax_step_dpp<0x141>(bv, bi, bp);     // row_half_mirror: lane i <-> 7 - i (the other quad of the eight)
+    argmax_step_dpp<0x140>(bv, bi, bp);     // row_mirror: lane i <-> 15 - i (the other eight of the row)
+    argmax_step_rows<false>(bv, bi, bp);    // the neighbouring row of 16
+    argmax_step_rows<true>(bv, bi, bp);     // the other half of the wave
+}
+
 // in-LDS bitonic sort of np2 (power of two) entries: descending value, ascending index
 template <bool WITH_IDX>
 __device__ __forceinline__ void bitonic_desc(float* s_val, int64_t* s_idx, int np2, int t) {
@@ -158,13 +199,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                     const float v = s_val[c0]; const int64_t id = s_idx[c0];
                     if (id >= 0 && (bp < 0 || sorts_before(v, id, bv, bi))) { bv = v; bi = id; bp = c0; }
                 }
-#pragma unroll
-                for (int sd = 32; sd > 0; sd >>= 1) {
-                    const float ov_ = __shfl_xor(bv, sd, 64);
-                    const long long oi_ = __shfl_xor((long long)bi, sd, 64);
-                    const int op_ = __shfl_xor(bp, sd, 64);
-                    if (op_ >= 0 && (bp < 0 || sorts_before(ov_, (int64_t)oi_, bv, bi))) { bv = ov_; bi = (int64_t)oi_; bp = op_; }
-                }
+                wave_argmax(bv, bi, bp);
                 if (lane == 0) {
                     const bool ok = bp >= 0 && bv > -INFINITY;          // (-inf: an empty / excluded slot -> (-inf, -1) like every path)
                     ov[round] = ok ? bv : -INFINITY; oi[round] = ok ? bi : -1;
@@ -247,13 +282,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                             const float v = s_val[c0]; const int64_t id = s_idx[c0];
                             if (sorts_before(v, id, bv, bi)) { bv = v; bi = id; bp = (int)c0; }
                         }
-#pragma unroll
-                        for (int sd = 32; sd > 0; sd >>= 1) {
-                            const float ov_ = __shfl_xor(bv, sd, 64);
-                            const long long oi_ = __shfl_xor((long long)bi, sd, 64);
-                            const int op_ = __shfl_xor(bp, sd, 64);
-                            if (sorts_before(ov_, (int64_t)oi_, bv, bi)) { bv = ov_; bi = (int64_t)oi_; bp = op_; }
-                        }
+                        wave_argmax(bv, bi, bp);
                         if (lane == 0) {
                             ov[round] = bv; oi[round] = bi; s_val[bp] = -INFINITY; s_idx[bp] = 0x7fffffffffffffffLL;
                             if (thr_out && round == k - 1) thr_out[qrow] = thr_below(bv);
@@ -451,13 +480,7 @@ __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __r
                     const float v = s_val[c0]; const int64_t id = s_idx[c0];
                     if (sorts_before(v, id, bv, bi)) { bv = v; bi = id; bp = c0; }
                 }
-#pragma unroll
-                for (int sd = 32; sd > 0; sd >>= 1) {
-                    const float ov_ = __shfl_xor(bv, sd, 64);
-                    const long long oi_ = __shfl_xor((long long)bi, sd, 64);
-                    const int op_ = __shfl_xor(bp, sd, 64);
-                    if (sorts_before(ov_, (int64_t)oi_, bv, bi)) { bv = ov_; bi = (int64_t)oi_; bp = op_; }
-                }
+                wave_argmax(bv, bi, bp);
                 if (t == 0) { tv_[round] = bv; ti_[round] = bi; if (bp >= 0) { s_val[bp] = -INFINITY; s_idx[bp] = 0x7fffffffffffffffLL; } }
             }
         }
