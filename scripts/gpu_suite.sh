@@ -94,6 +94,7 @@ PY
         echo "--- lib $tag: $(grep 'per pass' gpurun_out/sprof_$tag.log)"
         python scripts/prof_summary.py gpurun_out/sprof_$tag/trace_results.db 12 | cut -c1-170 | tee gpurun_out/score_prof_$tag.csv; rm -rf gpurun_out/sprof_$tag
       done ;;
+    select_probe) ( python scripts/select_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/select_probe.txt ;;
     graph_probe) ( python scripts/score_graph_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_graph_probe.txt ;;
     probe) ( python scripts/score_shape_probe.py ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/score_shape_probe.txt ;;
     ab_shapes)

@@ -104,6 +104,80 @@ __device__ __forceinline__ void wave_argmax(float& bv, int64_t& bi, int& bp) {
     argmax_step_rows<true>(bv, bi, bp);     // the other half of the wave
 }
 
+// The k best of <= 64 * SLOTS candidates held in LDS, by k rounds of a wave-wide maximum over REGISTER-resident 64-bit keys
+// (round 5).  key = f2key(value) << 32 | (0xffffffff - index): one unsigned 64-bit compare is the whole comparator (higher score
+// first, ties -> lower index), keys are unique per row (indices are), 0 = an empty slot.  A round is a lane-local maximum over the
+// lane's SLOTS keys, a six-step VALU butterfly on two dwords, and the owner clearing its key -- no LDS access and no 64-bit index
+// plumbing inside the loop.  (The LDS-scanning rounds this replaces cost ~0.8 us + 0.5 us per 256 candidates EACH -- two dependent
+// LDS loads per 64 candidates, four-dword shuffles -- 17 us of launch for the k = 11 best of 251, scripts/select_probe.py.)
+// Needs indices < 2^32 - 1 (the caller checks, block-uniformly, and keeps the generic rounds otherwise); -0.0 is folded into +0.0
+// so that equal scores tie on the index as they do under the float comparator.  emit(round, value, index, valid) runs on lane 0.
+__device__ __forceinline__ unsigned long long u64_dpp_max_step(unsigned long long x, unsigned long long o) { return o > x ? o : x; }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long u64_dpp(unsigned long long x) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x & 0xffffffffull), CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), CTRL, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <bool ROW32>
+__device__ __forceinline__ unsigned long long u64_rows(unsigned long long x, bool upper) {
+    const unsigned xl = (unsigned)(x & 0xffffffffull), xh = (unsigned)(x >> 32);
+    const auto rl = ROW32 ? __builtin_amdgcn_permlane32_swap(xl, xl, false, false) : __builtin_amdgcn_permlane16_swap(xl, xl, false, false);
+    const auto rh = ROW32 ? __builtin_amdgcn_permlane32_swap(xh, xh, false, false) : __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
+    return ((unsigned long long)(upper ? rh[0] : rh[1]) << 32) | (upper ? rl[0] : rl[1]);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long x, int lane) {
+    x = u64_dpp_max_step(x, u64_dpp<0xB1>(x));
+    x = u64_dpp_max_step(x, u64_dpp<0x4E>(x));
+    x = u64_dpp_max_step(x, u64_dpp<0x141>(x));
+    x = u64_dpp_max_step(x, u64_dpp<0x140>(x));
+    x = u64_dpp_max_step(x, u64_rows<false>(x, (lane & 16) != 0));
+    x = u64_dpp_max_step(x, u64_rows<true>(x, (lane & 32) != 0));
+    return x;
+}
+template <int SLOTS, typename Emit>
+__device__ __forceinline__ void wave_topk_keys(const float* s_val, const int64_t* s_idx, int cnt, int rounds, int lane, bool skip_negative_idx,
+                                               Emit emit) {
+    unsigned long long key[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int c = lane + 64 * u;
+        unsigned long long kk_ = 0;
+        if (c < cnt) {
+            const float v = s_val[c] + 0.0f;
+            const int64_t id = s_idx[c];
+            if (!(skip_negative_idx && id < 0)) kk_ = ((unsigned long long)f2key(v) << 32) | (0xffffffffu - (unsigned)id);
+        }
+        key[u] = kk_;
+    }
+    for (int round = 0; round < rounds; ++round) {
+        unsigned long long best = key[0];
+#pragma unroll
+        for (int u = 1; u < SLOTS; ++u) best = key[u] > best ? key[u] : best;
+        best = wave_max_u64(best, lane);
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) key[u] = key[u] == best ? 0ull : key[u];
+        if (lane == 0) {
+            const uint32_t kv = (uint32_t)(best >> 32);
+            const float v = __uint_as_float((kv & 0x80000000u) ? (kv & 0x7fffffffu) : ~kv);
+            emit(round, v, (int64_t)(0xffffffffu - (unsigned)(best & 0xffffffffull)), best != 0ull);
+        }
+    }
+}
+template <typename Emit>
+__device__ __forceinline__ void wave_topk_keys_any(const float* s_val, const int64_t* s_idx, int cnt, int rounds, int lane,
+                                                   bool skip_negative_idx, Emit emit) {
+    if (cnt <= 256) wave_topk_keys<4>(s_val, s_idx, cnt, rounds, lane, skip_negative_idx, emit);
+    else if (cnt <= 1024) wave_topk_keys<16>(s_val, s_idx, cnt, rounds, lane, skip_negative_idx, emit);
+    else wave_topk_keys<32>(s_val, s_idx, cnt, rounds, lane, skip_negative_idx, emit);
+}
+// block-uniform: does every (valid) index of s_idx[0, cnt) fit the 32-bit key field?  (ends with a barrier)
+__device__ __forceinline__ bool idx_fit_keys(const int64_t* s_idx, int cnt, int t, int nthreads) {
+    int big = 0;
+    for (int i = t; i < cnt; i += nthreads) big |= (s_idx[i] >= 0xffffffffLL) ? 1 : 0;
+    return __syncthreads_or(big) == 0;
+}
+
 // in-LDS bitonic sort of np2 (power of two) entries: descending value, ascending index
 template <bool WITH_IDX>
 __device__ __forceinline__ void bitonic_desc(float* s_val, int64_t* s_idx, int np2, int t) {
@@ -191,7 +265,16 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
         // handling, built for rows of 10^4 ... 10^6 scores) took ~25: the fold of 8 ranks' lists, the chunk-loop merge ----
         for (long i = t; i < total; i += TK_THREADS) { s_val[i] = r.val(i); s_idx[i] = r.idx(i); }
         __syncthreads();
-        if (t < 64) {
+        const bool keys_ok = idx_fit_keys(s_idx, (int)total, t, TK_THREADS);
+        if (t < 64 && keys_ok) {
+            wave_topk_keys_any(s_val, s_idx, (int)total, kk, lane, true, [&](int round, float bv, int64_t bi, bool valid) {
+                const bool ok = valid && bv > -INFINITY;                // (-inf: an empty / excluded slot -> (-inf, -1) like every path)
+                ov[round] = ok ? bv : -INFINITY; oi[round] = ok ? bi : -1;
+                if (thr_out && round == k - 1) thr_out[qrow] = thr_below(ok ? bv : -INFINITY);
+            });
+            for (int i = kk + lane; i < k; i += 64) { ov[i] = -INFINITY; oi[i] = -1; }
+            if (thr_out && kk < k && lane == 0) thr_out[qrow] = -INFINITY;
+        } else if (t < 64) {
             const int cnt = (int)total;
             for (int round = 0; round < kk; ++round) {
                 float bv = -INFINITY; int64_t bi = 0x7fffffffffffffffLL; int bp = -1;
@@ -275,7 +358,15 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
             const unsigned cnt = sh_cnt;          // cnt >= k always: k sampled elements are >= tau
             if (cnt <= 1024 && in_lds) {
                 // k best of the candidates by k rounds of wave-wide arg-max (wave 0; sorted, ties -> lower index)
-                if (t < 64) {
+                const bool keys_ok = idx_fit_keys(s_idx, (int)cnt, t, TK_THREADS);
+                if (t < 64 && keys_ok) {
+                    wave_topk_keys_any(s_val, s_idx, (int)cnt, kk, lane, false, [&](int round, float bv, int64_t bi, bool) {
+                        ov[round] = bv; oi[round] = bi;
+                        if (thr_out && round == k - 1) thr_out[qrow] = thr_below(bv);
+                    });
+                    for (int i = kk + lane; i < k; i += 64) { ov[i] = -INFINITY; oi[i] = -1; }
+                    if (thr_out && kk < k && lane == 0) thr_out[qrow] = -INFINITY;
+                } else if (t < 64) {
                     for (int round = 0; round < kk; ++round) {
                         float bv = -INFINITY; int64_t bi = 0x7fffffffffffffffLL; int bp = -1;
                         for (unsigned c0 = lane; c0 < cnt; c0 += 64) {
@@ -473,7 +564,12 @@ __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __r
     if (k <= TK_FAST_KMAX && cnt > 2 * k) {
         float* tv_ = r_val + TK_MERGE_KMAX / 2;          // (k <= 64: the upper half of the running-list arrays is free)
         int64_t* ti_ = r_idx + TK_MERGE_KMAX / 2;
-        if (t < 64) {
+        const bool keys_ok = idx_fit_keys(s_idx, cnt, t, TK_THREADS);
+        if (t < 64 && keys_ok) {
+            wave_topk_keys_any(s_val, s_idx, cnt, k, t, false, [&](int round, float bv, int64_t bi, bool valid) {
+                tv_[round] = valid ? bv : -INFINITY; ti_[round] = valid ? bi : 0x7fffffffffffffffLL;
+            });
+        } else if (t < 64) {
             for (int round = 0; round < k; ++round) {
                 float bv = -INFINITY; int64_t bi = 0x7fffffffffffffffLL; int bp = -1;
                 for (int c0 = t; c0 < cnt; c0 += 64) {
