@@ -970,6 +970,9 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
     // past 1024 entries the appends cost the streaming tile more than the smaller sample returns
     // (re-measured with the LDS-staged appends, nq = 1000: 125 k documents 0.28 / 0.36 / 0.40 ms with 512 / 1024 / 2048 entries,
     //  250 k documents 0.51 / 0.50 / 0.58 -- the short lists stay)
+#ifndef SGPT_FOLD_TAIL
+#define SGPT_FOLD_TAIL 1        // 0: the trailing < 256 documents of a shard in a small-tile launch of their own (A/B builds)
+#endif
 #ifndef SGPT_SAMPLE_TOP2
 #define SGPT_SAMPLE_TOP2 1      // 0: the materialised sample tile + select of round 4 (A/B builds)
 #endif
@@ -1192,9 +1195,15 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
             if (sampled) { g.thr = thr_dense; g.thr_ld = 1; }
             else { g.thr = tv[cur] + (k - 1); g.thr_ld = k; }
             g.cand_val = cand_v; g.cand_idx = cand_i; g.cand_cnt = cand_cnt; g.cand_cap = cap; g.idx_base = idx_base + seen;
+            // the < 256 trailing documents ride in the last chunk's launch (the 256x256 kernel clamps their rows and masks their
+            // columns, GemmArgs.n_valid) when documents are its streamed operand; the 64-row tile keeps its own tail launch
+            const bool fold_tail = SGPT_FOLD_TAIL && seen + len == n256 && N > n256 && nq_pad >= 256 && (long)nq_pad < len + 256;
+            if (fold_tail) { g.N = (int)(len + 256); g.n_valid = (int)(len + (N - n256)); }
             gemm(c, dtype, EPI_SCORE_FILTER, SGPT_F32, g, s);
+            g.n_valid = 0;
             const long c_lo = seen;
             seen += len;
+            if (fold_tail) seen = N;
             eff = seen;                                         // the thresholds now stand for every document of [0, seen)
             if (seen == n256 && seen < N) {
                 // ragged tail (< 256 documents): filtered against the same thresholds by the small-tile kernel, its

@@ -248,6 +248,9 @@ struct GemmArgs {
     void* out2;         // V^T [N - n_split][ldo2]
     long ldo2;
     int n_split;        // multiple of 128
+    // EPI_SCORE_FILTER on the 256x256 kernel (round 5): documents [n_valid, N) of the last column tile do not exist -- their
+    // rows are fetched from the last valid one and their scores masked, so that a ragged shard needs no second launch.  0 = N.
+    int n_valid;
     // fp8 operands (gemm256q.hip): C = (A8 . W8^T) * a_scale[m] * a_scalar * w_scale[n]
     const float* a_scale;   // [M] per-row scale of the A codes, or null (1)
     const float* w_scale;   // [N] per-output-channel scale of the W codes

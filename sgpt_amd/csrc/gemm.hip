@@ -35,6 +35,9 @@ constexpr bool RESID_NT = SGPT_RESID_NT != 0;
 #define SGPT_RESID_LD_NT 0
 #endif
 constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
+#ifndef SGPT_FOLD_TAIL
+#define SGPT_FOLD_TAIL 1     // 0: A/B builds without the ragged-tail handling of the filtered scorer launch (api.hip has the same switch)
+#endif
 #ifndef SGPT_THV_UNCOND
 #define SGPT_THV_UNCOND 1
 #endif
@@ -587,6 +590,33 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     const unsigned dloff = DEEP_A ? a_loff : w_loff, sloff = DEEP_A ? w_loff : a_loff;
     int sd = 0, ss = 0;      // ring slots of the k-step about to be computed
     int dbg_tile = 0;
+    // Ragged document count (EPI_SCORE_FILTER, documents = the streamed W operand): the last column tile holds p.n_valid - tail_n0
+    // real rows.  Its DMA pieces read CLAMPED rows (per-lane byte offsets from the tile's row 0, computed once; the normal tiles
+    // use the same form so that the k-loop carries one uniform select per deep piece and no branch) and the epilogue masks the
+    // columns that do not exist.  The separate small-tile launch for the < 256 trailing documents (9 us of a 0.27 ms shard pass,
+    // plus a second no-op launch in the fallback) is gone.
+    constexpr bool TAIL = SGPT_FOLD_TAIL != 0 && EPI == EPI_SCORE_FILTER && !DEEP_A;
+    const bool has_tail = TAIL && p.n_valid > 0 && p.n_valid < N;
+    const int tail_n0 = N - TN, tail_rows = has_tail ? p.n_valid - tail_n0 : TN;
+    unsigned wnorm_off[TAIL ? 4 : 1], wtail_off[TAIL ? 4 : 1];
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave * 32 + q * 8 + (lane >> 3);
+            const int crow = row < tail_rows ? row : tail_rows - 1;
+            wnorm_off[q] = (unsigned)((row * p.ldw + lchunk * 8) * 2);
+            wtail_off[q] = (unsigned)((crow * p.ldw + lchunk * 8) * 2);
+        }
+    }
+    auto dpiece = [&](const bf16_t* src, bool tail, int kt, unsigned slot_off, int q) {
+        if constexpr (TAIL) {
+            const unsigned row_off = (unsigned)((wave_u * 32 + q * 8) * CH * 16);
+            dma16(reinterpret_cast<const char*>(src + kt * 64), tail ? wtail_off[q] : wnorm_off[q], lds_base + slot_off + row_off);
+        } else {
+            (void)tail;
+            piece(src, dld, dloff, kt, slot_off, q);
+        }
+    };
     typename OutRange<OutT>::type range;
 #ifdef SGPT_EXPERIMENTS
 #define STAMP(k)                                                                                   \
@@ -608,12 +638,13 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     {   // prologue: deep(0), shallow(0), deep(1) -- in the order the waits assume
         const bf16_t* dsrc = DEEP_A ? asrc : wsrc;
         const bf16_t* ssrc = DEEP_A ? wsrc : asrc;
+        const bool t0 = has_tail && n0 == tail_n0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) piece(dsrc, dld, dloff, 0, deep_off(0), q);
+        for (int q = 0; q < 4; ++q) dpiece(dsrc, t0, 0, deep_off(0), q);
 #pragma unroll
         for (int q = 0; q < 4; ++q) piece(ssrc, sld, sloff, 0, shal_off(0), q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) piece(dsrc, dld, dloff, 1, deep_off(1), q);
+        for (int q = 0; q < 4; ++q) dpiece(dsrc, t0, 1, deep_off(1), q);
     }
     // Late-barrier pipeline: the k-step's barrier sits in front of its LAST row pair, and the first fragments of the
     // next k-step are read behind it, under that pair's MFMAs -- no ds_read latency is left between a barrier and the
@@ -649,6 +680,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
         if (has_next) tile_src(nm0, nn0, nasrc, nwsrc);
         const bf16_t* d_cur = DEEP_A ? asrc : wsrc, *d_nxt = DEEP_A ? nasrc : nwsrc;
         const bf16_t* s_cur = DEEP_A ? wsrc : asrc, *s_nxt = DEEP_A ? nwsrc : nasrc;
+        const bool tail_cur = has_tail && n0 == tail_n0, tail_nxt = has_tail && has_next && nn0 == tail_n0;
         for (int kt = 0; kt < nk; ++kt) {
 #ifdef SGPT_EXPERIMENTS
             if (p.dbg && blockIdx.x == 0 && t == 0 && dbg_tile < 4 && kt < 12)
@@ -692,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
                     for (int j = 0; j < 4; ++j) mma<T, SWAP>(acc[i][j], af[q & 1][h], wf[ks][j]);
                     if (ks == 0) {   // one 1-KiB piece behind every 4 MFMAs: shallow x4 first, then deep x4
                         if (i < 4) piece(sp, sld, sloff, skt, s_dst, i);
-                        else piece(dp, dld, dloff, dkt, d_dst, i - 4);
+                        else dpiece(dp, d_in ? tail_cur : tail_nxt, dkt, d_dst, i - 4);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

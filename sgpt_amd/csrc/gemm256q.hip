@@ -252,6 +252,8 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(const GemmArgs p) {
                 typename OutRange<OutT>::type range;
                 constexpr bool LO = false;                 // (split-precision outputs: 16-bit operand kernels only)
                 const float thv_pre[8] = {};               // (the scorer's filtered epilogue is never instantiated here)
+                constexpr bool has_tail = false;
+                constexpr int tail_n0 = 0, tail_rows = 0;
 #include "gemm256_epilogue.inc"
                 range.finish(p.range_flag);
             } else {
