@@ -970,6 +970,9 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
     // past 1024 entries the appends cost the streaming tile more than the smaller sample returns
     // (re-measured with the LDS-staged appends, nq = 1000: 125 k documents 0.28 / 0.36 / 0.40 ms with 512 / 1024 / 2048 entries,
     //  250 k documents 0.51 / 0.50 / 0.58 -- the short lists stay)
+#ifndef SGPT_SAMPLE_MULT
+#define SGPT_SAMPLE_MULT 1.0    // the sample as a multiple of the size the list capacity asks for (A/B builds: the sample is cheap since
+#endif                          // its scores stay in the GEMM -- more sampled documents, tighter thresholds, fewer appended survivors)
 #ifndef SGPT_FOLD_TAIL
 #define SGPT_FOLD_TAIL 1        // 0: the trailing < 256 documents of a shard in a small-tile launch of their own (A/B builds)
 #endif
@@ -999,7 +1002,7 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
         // S = N / ratio: the survivors of the WHOLE shard fit the lists even if no chunk ever raises the thresholds (a corpus
         // whose best documents all come last).  Bounded by a 512 MiB score tile (131 072 documents at nq = 1000; 1 M documents
         // need 60 k): behind that the schedule relies on the merges raising the thresholds, like the doubling one did.
-        S = ((long)((double)N / ratio) + 255) / 256 * 256;     // rounded UP: ratio * S covers the shard
+        S = ((long)((double)N / ratio * SGPT_SAMPLE_MULT) + 255) / 256 * 256;     // rounded UP: ratio * S covers the shard
         if (S < 2048) S = 2048;
         const long s_max = (long)(((size_t)512 << 20) / ((size_t)nq * 4)) / 256 * 256;
         if (S > s_max) S = s_max > 2048 ? s_max : 2048;
