@@ -1084,10 +1084,7 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
         g.A = q; g.lda = d; g.M = nq; g.m_valid = nq; g.K = d; g.pred = pred;
         g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = (long)d * row_stride; g.N = (int)nc;   // row_stride > 1: a strided sample
         g.out = sc; g.ldo = ld;
-        // documents the 256-document tile kernels take.  A predicated piece of the SAMPLED schedule (its fallback: an overflow needs an
-        // adversarial mass of near-equal scores) goes to the register-staged kernel whole -- one no-op launch per piece instead of two
-        // (aligned part + ragged tail); same bits, and the rare pass that does run pays the smaller tiles
-        const long na = (fast && !(pred != nullptr && sampled && nc % 256 != 0 && nq_pad >= 256)) ? nc / 256 * 256 : 0;
+        const long na = fast ? nc / 256 * 256 : 0;      // documents the 256-document tile kernels take
         if (na > 0) {
             GemmArgs h = g;
             h.A = qpad; h.M = nq_pad; h.N = (int)na;
