@@ -1085,6 +1085,9 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
         g.W = (const char*)corpus + (size_t)c0 * d * esz; g.ldw = (long)d * row_stride; g.N = (int)nc;   // row_stride > 1: a strided sample
         g.out = sc; g.ldo = ld;
         const long na = fast ? nc / 256 * 256 : 0;      // documents the 256-document tile kernels take
+        // (round 5, measured and reverted: handing a predicated fallback piece to the register-staged kernel whole -- one no-op launch
+        //  instead of two -- made the shard pass 12 % SLOWER: a no-op launch of the persistent 256x256 kernel is 256 workgroups that
+        //  exit, one of the small-tile kernel for 125 k documents x 1000 queries is ~8 000.)
         if (na > 0) {
             GemmArgs h = g;
             h.A = qpad; h.M = nq_pad; h.N = (int)na;
