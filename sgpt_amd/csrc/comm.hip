@@ -223,16 +223,13 @@ static sgpt_status fold_gathered(sgpt_ctx* c, const float* gv, const long long* 
     const size_t nw = (size_t)nq * k * world;
     const float* mv = gv;
     const long long* mi = gi;
-    if (world > 1) {
-        const long total = (long)nw;
-        const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-        hipLaunchKernelGGL(gather_to_rows_kernel, dim3(grid), dim3(256), 0, s, gv, gi, rv, ri, world, nq, k);
-        mv = rv; mi = ri;
-    }
     // the k_out best of the world * k candidates per query; idx < 0 and idx == exclude_idx[q] are skipped
-    // (exact_search.py:118, 121-132); ties -> lowest index: identical on every rank
+    // (exact_search.py:118, 121-132); ties -> lowest index: identical on every rank.  The rank-major -> row-major regrouping is done
+    // by the select's own loads (round 5: its "gathered" previous leg; the permute kernel of round 3 was a launch of its own)
     const int mcand = world * k;
-    launch_topk_select(mv, mcand, 0, 0, mv, (const int64_t*)mi, mcand, mcand, nq, k_out, 0, exclude_idx, out_val, out_idx, s);
+    (void)rv; (void)ri; (void)nw;
+    launch_topk_select(mv, mcand, 0, 0, mv, (const int64_t*)mi, mcand, mcand, nq, k_out, 0, exclude_idx, out_val, out_idx, s,
+                       nullptr, nullptr, world > 1 ? k : 0);
     HIPC(c, hipGetLastError());
     return SGPT_OK;
 }

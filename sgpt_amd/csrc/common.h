@@ -350,7 +350,8 @@ void launch_fill_rand(void* p, long n, int dtype, unsigned seed, float scale, hi
 void launch_topk_select(const float* scores, long ld, long n, long idx_base, const float* prev_val,
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
                         const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s,
-                        const int* pred = nullptr, float* thr_out = nullptr);   // thr_out[q] = the k-th best, one ulp lower (or null)
+                        const int* pred = nullptr, float* thr_out = nullptr,    // thr_out[q] = the k-th best, one ulp lower (or null)
+                        int gather_k = 0);   // > 0: prev_val / prev_idx are a [world][nq][gather_k] stack of per-rank lists (n_prev = world * gather_k)
 // refined scorer (sgpt_score_topk_refined): exact fp32 scores of stage-1 candidates, the guarantee check, list concatenation
 void launch_rescore(const float* q, const float* corpus, const int64_t* idx, long ld_idx, int nq, int m, int d, long idx_base,
                     long n_docs, float* out_val, int64_t* out_idx, long ld_out, hipStream_t s);

@@ -36,7 +36,12 @@ constexpr long TK_FAST_MIN_ROW = 4096;
 struct Row {
     const float* sc; long n; long idx_base;
     const float* pv; const int64_t* pi; int n_prev; int nan_to_m1; int64_t excl;
+    // gk > 0 ("gathered" previous leg, round 5): pv / pi point at a [world][nq][gk] stack of per-rank lists as ncclAllGather
+    // delivers them (NOT at this row); entry j of the row is list j / gk, column j % gk -- the rank-major -> row-major permute of
+    // the cross-rank fold done by the select's own loads instead of a kernel of its own
+    int gk; long gstride;           // gstride = nq * gk elements between two ranks' lists
     __device__ __forceinline__ long total() const { return n + n_prev; }
+    __device__ __forceinline__ long paddr(long j) const { return gk > 0 ? (j / gk) * gstride + (j % gk) : j; }
     // Both legs are always addressed in-bounds (clamped index, never-null base): hipcc may hoist /
     // speculate these loads out of their guards (seen: pi[i-n] issued for i < n with pi == nullptr).
     __device__ __forceinline__ float val(long i) const {
@@ -44,8 +49,9 @@ struct Row {
         const long j = isp ? i - n : 0;
         float v;
         if (isp) {
-            const int64_t id = pi[j];
-            v = (id < 0 || id == excl) ? -INFINITY : pv[j];   // empty slot / excluded (self) id
+            const long a = paddr(j);
+            const int64_t id = pi[a];
+            v = (id < 0 || id == excl) ? -INFINITY : pv[a];   // empty slot / excluded (self) id
         } else {
             v = sc[i];
         }
@@ -54,7 +60,7 @@ struct Row {
     }
     __device__ __forceinline__ int64_t idx(long i) const {
         if (i < n) return idx_base + i;
-        const int64_t id = pi[i - n];
+        const int64_t id = pi[paddr(i - n)];
         return id == excl ? -1 : id;
     }
 };
@@ -229,7 +235,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                                                                 const float* prev_val, const int64_t* prev_idx,
                                                                 int n_prev, long prev_ld, int k, int nan_to_m1,
                                                                 const int64_t* exclude_idx, float* out_val,
-                                                                int64_t* out_idx, const int* pred, float* thr_out) {
+                                                                int64_t* out_idx, const int* pred, float* thr_out, int gather_k,
+                                                                int gather_nq) {
     if (pred && *pred == 0) return;   // predicated fallback launch that is not needed
     __shared__ unsigned hist[256];
     __shared__ unsigned sh_prefix, sh_krem, sh_cnt, sh_cnt2;
@@ -239,10 +246,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
     const int qrow = blockIdx.x, t = threadIdx.x, lane = t & 63;
     // no previous list: alias the prev pointers to valid memory (n_prev = 0, never selected)
     const bool has_prev = prev_val != nullptr && prev_idx != nullptr && n_prev > 0;
+    const bool gath = has_prev && gather_k > 0;
     Row r{scores + (long)qrow * ld, n, idx_base,
-          has_prev ? prev_val + (long)qrow * prev_ld : scores,
-          has_prev ? prev_idx + (long)qrow * prev_ld : reinterpret_cast<const int64_t*>(out_idx),
-          has_prev ? n_prev : 0, nan_to_m1, exclude_idx ? exclude_idx[qrow] : (int64_t)-1};
+          has_prev ? prev_val + (long)qrow * (gath ? gather_k : prev_ld) : scores,
+          has_prev ? prev_idx + (long)qrow * (gath ? gather_k : prev_ld) : reinterpret_cast<const int64_t*>(out_idx),
+          has_prev ? n_prev : 0, nan_to_m1, exclude_idx ? exclude_idx[qrow] : (int64_t)-1,
+          gath ? gather_k : 0, gath ? (long)gather_nq * gather_k : 0};
     const long total = r.total();
     float* ov = out_val + (long)qrow * k;
     int64_t* oi = out_idx + (long)qrow * k;
@@ -713,9 +722,9 @@ void launch_thr_below(const float* list, int k, int nq, float* thr, hipStream_t 
 void launch_topk_select(const float* scores, long ld, long n, long idx_base, const float* prev_val,
                         const int64_t* prev_idx, int n_prev, long prev_ld, int nq, int k, int nan_to_m1,
                         const int64_t* exclude_idx, float* out_val, int64_t* out_idx, hipStream_t s, const int* pred,
-                        float* thr_out) {
+                        float* thr_out, int gather_k) {
     hipLaunchKernelGGL(topk_select_kernel, dim3(nq), dim3(TK_THREADS), 0, s, scores, ld, n, idx_base, prev_val,
-                       prev_idx, n_prev, prev_ld, k, nan_to_m1, exclude_idx, out_val, out_idx, pred, thr_out);
+                       prev_idx, n_prev, prev_ld, k, nan_to_m1, exclude_idx, out_val, out_idx, pred, thr_out, gather_k, nq);
 }
 
 void launch_cand_merge(const float* run_val, const int64_t* run_idx, const float* cand_val, const int64_t* cand_idx,
