@@ -79,12 +79,19 @@ PY
         v=$( timeout 600 python bench.py ${VARLEN_BENCH_ARGS:---steps 9 --warmup 2 --no-1m} --no-cpu-baseline --no-modes $mode 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); v=d['varlen']; print(v['sentences_per_s'], 'sent/s', v['end_to_end_frac_of_mfma_roofline'], v['rows_per_call'], '| fixed-128', d['value'])" )
         echo "round $rnd calls ${mode:-round-aware}: $v" | tee -a gpurun_out/ab_varlen.txt
       done; done ;;
+    ab_varlen_lib)
+      : > gpurun_out/ab_varlen_lib.txt
+      for rnd in 1 2 3; do for tag in default ${LIBS}; do
+        v=$( SGPT_HIP_LIB=$(libpath $tag) timeout 600 python bench.py ${VARLEN_BENCH_ARGS:---steps 9 --warmup 2 --no-1m} --no-cpu-baseline --no-modes 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); v=d['varlen']; print(v['sentences_per_s'], 'sent/s', v['end_to_end_frac_of_mfma_roofline'], v['rows_per_call'], '| fixed-128', d['value'])" )
+        echo "round $rnd lib $tag: $v" | tee -a gpurun_out/ab_varlen_lib.txt
+      done; done ;;
     varlen_prof)
-      for L in var fixed; do
+      for L in ${VPROF_LENS:-var fixed}; do
         rm -rf gpurun_out/vprof_$L; mkdir -p gpurun_out/vprof_$L
         ( cd /tmp && LENS=$L timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/vprof_$L -o trace -- python $R/scripts/varlen_profile.py ) > gpurun_out/vprof_$L.log 2>&1
         grep "LENS=" gpurun_out/vprof_$L.log
-        python scripts/prof_summary.py gpurun_out/vprof_$L/trace_results.db 14 > gpurun_out/varlen_prof_$L.csv; rm -rf gpurun_out/vprof_$L
+        python scripts/prof_summary.py gpurun_out/vprof_$L/trace_results.db 14 > gpurun_out/varlen_prof_$L.csv
+        python scripts/prof_by_grid.py gpurun_out/vprof_$L/trace_results.db attn16 | tee gpurun_out/varlen_attn_by_call_$L.csv; rm -rf gpurun_out/vprof_$L
         head -14 gpurun_out/varlen_prof_$L.csv | cut -c1-160
       done ;;
     ab_score_prof)

@@ -449,6 +449,31 @@ def test_long_sequences_attention_block_shapes_agree_and_match_the_oracle(dtype)
     assert np.abs(got - ref).max() < tol, np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_short_call_attention_block_shapes_agree_for_every_call_length(dtype):
+    """head_dim 64, calls whose longest sequence has 1..8 sixteen-query fragments (a length-sorted corpus produces every one
+    of them): attn.hip::launch_attn_bf16 picks 2-wave blocks up to 32 rows, 4-wave blocks up to 64, 8-wave blocks above.  A
+    sequence's embedding must not depend on the call it rides in (bit-identical across all shapes), and every call length
+    must match the fp32 oracle."""
+    kw = dict(vocab_size=311, max_position_embeddings=256, hidden_size=128, num_layers=3, num_heads=2, window_size=64)
+    m = build_model(kw, 9, 0.06, dtype)
+    rng = np.random.default_rng(23)
+    mk = lambda n: rng.integers(0, 311, size=n).tolist()  # noqa: E731
+    enc = lambda seqs: m.encode_ids(seqs, normalize=True).cpu().numpy()  # noqa: E731
+    probe = [mk(n) for n in (3, 16, 17, 30)]
+    alone = enc(probe)                                                    # longest 30: 2-wave blocks
+    longest = [40, 48, 49, 64, 66, 80, 81, 96, 97, 112, 113, 128]         # 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8 fragments
+    cfg = O.NeoConfig(**kw)
+    w = O.synth_weights(cfg, seed=9, std=0.06)
+    tol = 5e-3 if dtype == "f16" else 3e-2
+    for n in longest:
+        seqs = [mk(n), mk(max(1, n - 15)), mk(n // 2)] + probe
+        got = enc(seqs)
+        assert np.array_equal(got[3:], alone), n
+        ref = O.encode(w, cfg, seqs[:3], normalize_embeddings=True)
+        assert np.abs(got[:3] - ref).max() < tol, (n, np.abs(got[:3] - ref).max())
+
+
 def test_encode_graph_capture_and_replay():
     """sgpt_encode is stream-pure (no hidden sync / allocation once the workspace is sized), so one call captures
     into a hipGraph; replay on new ids of the same layout bucket equals the eager call bit for bit."""
