@@ -973,6 +973,9 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
 #ifndef SGPT_SAMPLE_MULT
 #define SGPT_SAMPLE_MULT 1.0    // the sample as a multiple of the size the list capacity asks for (A/B builds: the sample is cheap since
 #endif                          // its scores stay in the GEMM -- more sampled documents, tighter thresholds, fewer appended survivors)
+#ifndef SGPT_FOLD_TAIL_SCORE
+#define SGPT_FOLD_TAIL_SCORE 1  // 0: A/B builds -- the materialise-and-select pieces keep their small-tile tail launch
+#endif
 #ifndef SGPT_FOLD_TAIL
 #define SGPT_FOLD_TAIL 1        // 0: the trailing < 256 documents of a shard in a small-tile launch of their own (A/B builds)
 #endif
@@ -1088,12 +1091,17 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
         // (round 5, measured and reverted: handing a predicated fallback piece to the register-staged kernel whole -- one no-op launch
         //  instead of two -- made the shard pass 12 % SLOWER: a no-op launch of the persistent 256x256 kernel is 256 workgroups that
         //  exit, one of the small-tile kernel for 125 k documents x 1000 queries is ~8 000.)
+        // the < 256 trailing documents ride in the 256x256 launch (clamped rows, GemmArgs.n_valid; their missing columns land in the
+        // padding of the score row, which the select does not read): one launch less per piece -- a no-op one in the predicated
+        // fallback of every filtered chunk
+        const bool fold = SGPT_FOLD_TAIL && SGPT_FOLD_TAIL_SCORE && na > 0 && na < nc && row_stride == 1 && nq_pad >= 256 &&
+                          (long)nq_pad < na + 256 && na + 256 <= ld;
         if (na > 0) {
             GemmArgs h = g;
-            h.A = qpad; h.M = nq_pad; h.N = (int)na;
+            h.A = qpad; h.M = nq_pad; h.N = (int)(fold ? na + 256 : na); h.n_valid = fold ? (int)nc : 0;
             gemm(c, dtype, EPI_SCORE, SGPT_F32, h, s);
         }
-        if (na < nc) {                                  // fp32, or the ragged tail (< 256 documents): register-staged kernel
+        if (na < nc && !fold) {                         // fp32, or the ragged tail (< 256 documents): register-staged kernel
             g.W = (const char*)corpus + (size_t)(c0 + na) * d * esz; g.N = (int)(nc - na); g.out = sc + na;
             gemm(c, dtype, EPI_SCORE, SGPT_F32, g, s);
         }

@@ -35,6 +35,9 @@ constexpr bool RESID_NT = SGPT_RESID_NT != 0;
 #define SGPT_RESID_LD_NT 0
 #endif
 constexpr bool RESID_LD_NT = SGPT_RESID_LD_NT != 0;
+#ifndef SGPT_FOLD_TAIL_SCORE
+#define SGPT_FOLD_TAIL_SCORE 1   // the same for the materialised-score launch (api.hip has the same switch)
+#endif
 #ifndef SGPT_FOLD_TAIL
 #define SGPT_FOLD_TAIL 1     // 0: A/B builds without the ragged-tail handling of the filtered scorer launch (api.hip has the same switch)
 #endif
@@ -595,7 +598,9 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(const GemmArgs p) {
     // use the same form so that the k-loop carries one uniform select per deep piece and no branch) and the epilogue masks the
     // columns that do not exist.  The separate small-tile launch for the < 256 trailing documents (9 us of a 0.27 ms shard pass,
     // plus a second no-op launch in the fallback) is gone.
-    constexpr bool TAIL = SGPT_FOLD_TAIL != 0 && EPI == EPI_SCORE_FILTER && !DEEP_A;
+    // (EPI_SCORE, the materialise-and-select pieces: same clamped rows, and the columns that do not exist are stored as copies of
+    // the last real document's score into the padding of the score tile's row -- the select reads n_valid columns)
+    constexpr bool TAIL = SGPT_FOLD_TAIL != 0 && (EPI == EPI_SCORE_FILTER || (SGPT_FOLD_TAIL_SCORE != 0 && EPI == EPI_SCORE)) && !DEEP_A;
     const bool has_tail = TAIL && p.n_valid > 0 && p.n_valid < N;
     const int tail_n0 = N - TN, tail_rows = has_tail ? p.n_valid - tail_n0 : TN;
     unsigned wnorm_off[TAIL ? 4 : 1], wtail_off[TAIL ? 4 : 1];
@@ -1099,6 +1104,7 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
         }
         return launch<H, EPI_QKV, H, true>(a, s);                   // caller checked gemm_qkv_one_launch()
     }
+    if (a.n_valid > 0 && !(use256 && shape256 && scorer && a.M < a.N)) abort();   // a folded ragged tail exists in the 256x256 scorer launches only
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
 #ifdef SGPT_EXPERIMENTS
