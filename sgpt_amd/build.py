@@ -12,7 +12,7 @@ LIBDIR = os.path.join(HERE, "lib")
 # the slower 32x32x16-MFMA re-tiling (gemm256w.hip) compiled in.  The product library has none of them.
 EXPERIMENTS = os.environ.get("SGPT_EXPERIMENTS") == "1"
 LIB = os.path.join(LIBDIR, "libsgpt_hip_exp.so" if EXPERIMENTS else "libsgpt_hip.so")
-SOURCES = ["gemm.hip", "gemm256q.hip", "attn.hip", "elementwise.hip", "topk.hip", "comm.hip", "api.hip"]
+SOURCES = ["gemm.hip", "qgemm.hip", "gemm256q.hip", "attn.hip", "elementwise.hip", "topk.hip", "comm.hip", "api.hip"]
 # the slower 32x32x16-MFMA re-tiling lives with the measurement scripts (scripts/micro/gemm256w.hip): experiment build only
 EXTRA_SOURCES = [os.path.join(HERE, "..", "scripts", "micro", "gemm256w.hip")] if EXPERIMENTS else []
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

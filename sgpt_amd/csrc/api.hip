@@ -132,6 +132,12 @@ void gemm(sgpt_ctx* c, int dtype, int epi, int out_dtype, const GemmArgs& a0, hi
     launch_gemm(dtype, epi, out_dtype, a, s);
 }
 
+// query-sized projection (qgemm.hip); false = not served, the caller launches gemm()
+bool qgemm(sgpt_ctx* c, int dtype, int epi, int out_dtype, const QGemmArgs& a, hipStream_t s) {
+    Prof p(c, s, 2.0 * (double)a.g.m_valid * a.g.N * a.g.K);
+    return launch_qgemm(dtype, epi, out_dtype, a, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -471,8 +477,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
                                float* out, float* hidden_out, float* layer_out, float* layer_mean, void* stream) {
     if (!m) return SGPT_ERR_INVALID;
     sgpt_ctx* c = m->ctx;
-    if (!ids || !pos || !seq_off || !seq_len || B <= 0 || T <= 0 || T % 128 || max_alloc <= 0 || max_alloc % 2)
-        return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad token layout (T_pad % 128, max_alloc_len % 2)");
+    if (!ids || !pos || !seq_off || !seq_len || B <= 0 || T <= 0 || T % 32 || max_alloc <= 0 || max_alloc % 2)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad token layout (T_pad % 32, max_alloc_len % 2)");
     if (n_layers_run < 0 || n_layers_run > m->d.n_layers) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: n_layers_run out of range");
     if (pool_mode < 0 || pool_mode > 3) return fail(c, SGPT_ERR_INVALID, "sgpt_encode: bad pool_mode");
     if (pool_mode == SGPT_POOL_LEARNTMEAN && (out || layer_out || layer_mean)) {
@@ -524,6 +530,14 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         for (int li = 0; li < n_layers_run; ++li)
             if (!(m->act_scale[li] > 0.f) || !(m->act_scale[m->d.n_layers + li] > 0.f))
                 return fail(c, SGPT_ERR_INVALID, "SGPT_FP8M: activation scales are not set (sgpt_model_calibrate_begin / _end, or sgpt_model_set_act_scales)");
+    // Query-sized batches (round 6; qgemm.hip): at most QGEMM_MAX_ROWS token rows, plain 16-bit operands, no probe / calibration
+    // pass riding on the forward.  Every projection takes the LDS-DMA ring kernel; at d <= 1024 the two LayerNorms of a
+    // sequential block (GPT-Neo, BLOOM) run inside the prologues of the projections they feed: five launches per block instead
+    // of seven.  Same arithmetic per element as the bulk path (identical bits); sgpt_ctx_set_tile_policy(1) keeps the bulk kernels.
+    const bool qpath = bf && !fp8 && !split && !(m->probing && m->crest_dev) && !m->calibrating && !c->force256 && T <= QGEMM_MAX_ROWS &&
+                       qgemm_shape_ok(T, 3 * dm, dm, EPI_QKV, 2 * dm) && qgemm_shape_ok(T, dm, dm, EPI_BIAS_RESID, 0) &&
+                       qgemm_shape_ok(T, ffn, dm, EPI_BIAS_GELU, 0) && qgemm_shape_ok(T, dm, ffn, EPI_BIAS_RESID, 0);
+    const bool qln = qpath && !gptj && qgemm_ln_ok(T, 3 * dm, dm, EPI_QKV, 2 * dm) && qgemm_ln_ok(T, ffn, dm, EPI_BIAS_GELU, 0);
     const size_t o_a8 = mlp8 ? carve((size_t)T * dm) : 0;                // FP8M: LayerNorm output as e4m3 codes
     const size_t o_sa = mlp8 ? carve((size_t)T * 4) : 0;                 //       + one scale per row
     const size_t o_lp = (layer_mean && !layer_out) ? carve((size_t)(m->d.n_layers + 1) * B * dm * 4) : 0;
@@ -553,7 +567,8 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     } else {
         HIPC(c, hipMemsetAsync((float*)qkv + (size_t)T * 3 * dm, 0, SLACK * 3 * dm * esz, s));
     }
-    if (gptj || mlp8 || split) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz * (any_ctx ? 3 : 1), s));   // (fp8: stale bytes would decode to NaN codes)
+    // (query path with the LayerNorm inside the projections: no LayerNorm launch fills the buffer the context shares with it)
+    if (gptj || mlp8 || split || qln) HIPC(c, hipMemsetAsync(ctx, 0, (size_t)T * dm * esz * (any_ctx ? 3 : 1), s));   // (fp8: stale bytes would decode to NaN codes)
     launch_embed(ids, pos, m->wte, m->wpe, x, T, dm, m->d.vocab, m->d.max_pos, s);
     if (m->emb_ln_g) launch_layernorm(x, m->emb_ln_g, m->emb_ln_b, x, SGPT_F32, T, dm, m->d.ln_eps, s);   // BLOOM :499
     for (int li = 0; li < n_layers_run; ++li) {
@@ -592,6 +607,39 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
         at.max_alloc_len = max_alloc; at.ctx = ctx; at.ldo = dm; at.alibi = m->alibi;
         GemmArgs q{};      // fp8 projections
         q.M = T; q.m_valid = T; q.range_flag = (int*)m->range_dev;
+        if (qpath) {
+            // ---- query-sized block: [LN1 +] QKV -> (rope) -> attention -> out-proj + residual -> [LN2 +] fc1 + GELU -> fc2 + residual ----
+            QGemmArgs qa{};
+            qa.g = g; qa.eps = m->d.ln_eps;
+            if (qln) { qa.x = x; qa.ln_g = l.ln1_g; qa.ln_b = l.ln1_b; qa.ln_mul = pow2f(-k_ln1); }
+            else launch_layernorm(x, l.ln1_g, l.ln1_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln1));
+            qa.g.W = l.w_qkv; qa.g.N = 3 * dm; qa.g.n_split = 2 * dm; qa.g.out = qkv; qa.g.ldo = 2 * dm; qa.g.out2 = vt; qa.g.ldo2 = T;
+            qa.g.bias = l.b_qkv;
+            qa.g.in_mul = pow2f(k_ln1); qa.g.out_mul = qa.g.out_mul2 = pow2f(-k_qkv); qa.g.range_amax = f16m ? slots + RS_QKV : nullptr;
+            if (!qgemm(c, dt, EPI_QKV, dt, qa, s)) return fail(c, SGPT_ERR_INVALID, "query path: QKV projection not served");
+            if (gptj) launch_rope(qkv, dt, 2 * dm, dm, pos, m->rot_sin, m->rot_cos, T, H, dh, m->d.rotary_dim, s);
+            at.q = qkv; at.k = (bf16_t*)qkv + dm; at.v = vt; at.ldq = 2 * dm; at.ldvt = T;
+            launch_attn_bf16(at, s);
+            QGemmArgs qo{};
+            qo.g = g;
+            qo.g.A = ctx; qo.g.W = l.w_o; qo.g.N = dm; qo.g.out = x; qo.g.ldo = dm; qo.g.bias = l.b_o; qo.g.resid = x;
+            qo.g.in_mul = pow2f(k_qkv); qo.g.out_mul = qo.g.out_mul2 = 1.0f;
+            if (!qgemm(c, dt, EPI_BIAS_RESID, SGPT_F32, qo, s)) return fail(c, SGPT_ERR_INVALID, "query path: out-projection not served");
+            QGemmArgs qf{};
+            qf.g = g; qf.eps = m->d.ln_eps;
+            if (qln) { qf.x = x; qf.ln_g = l.ln2_g; qf.ln_b = l.ln2_b; qf.ln_mul = pow2f(-k_ln2); }
+            else if (!gptj) launch_layernorm(x, l.ln2_g, l.ln2_b, a, dt, T, dm, m->d.ln_eps, s, pow2f(-k_ln2));
+            qf.g.W = l.w_fc; qf.g.N = ffn; qf.g.out = h; qf.g.ldo = ffn; qf.g.bias = l.b_fc;
+            qf.g.in_mul = pow2f(k_ln2); qf.g.out_mul = pow2f(-k_h); qf.g.range_amax = f16m ? slots + RS_H : nullptr;
+            if (!qgemm(c, dt, EPI_BIAS_GELU, dt, qf, s)) return fail(c, SGPT_ERR_INVALID, "query path: fc1 not served");
+            QGemmArgs qp{};
+            qp.g = g;
+            qp.g.A = h; qp.g.lda = ffn; qp.g.W = l.w_proj; qp.g.N = dm; qp.g.K = ffn; qp.g.ldw = ffn; qp.g.out = x; qp.g.ldo = dm;
+            qp.g.bias = l.b_proj; qp.g.resid = x;
+            qp.g.in_mul = pow2f(k_h); qp.g.out_mul = qp.g.out_mul2 = 1.0f;
+            if (!qgemm(c, dt, EPI_BIAS_RESID, SGPT_F32, qp, s)) return fail(c, SGPT_ERR_INVALID, "query path: fc2 not served");
+            continue;
+        }
         if (mlp8) {
             // ---- attention projections on the fp8 MFMA: a8 = e4m3(LN1(x) / sa[row]) feeds Q, K (row-major bf16) and V^T ----
             launch_layernorm_q8(x, l.ln1_g, l.ln1_b, base + o_a8, (float*)(base + o_sa), nullptr, dt, T, dm, m->d.ln_eps, s);

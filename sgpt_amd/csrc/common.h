@@ -148,6 +148,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// wave_sum with the partner values fetched by VALU lane exchanges (DPP quad permutes / row rotate, v_permlane16/32_swap) instead
+// of six ds_bpermute round trips through the LDS crossbar: the SAME butterfly (partners lane ^ 32, 16, 8, 4, 2, 1 in that order),
+// and a + b == b + a bit for bit, so the result equals wave_sum's on every lane.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_valu(float v) {
+    { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }                         // lane ^ 32
+    { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }                         // lane ^ 16
+    v += dpp_mov<0x128>(v);                                                         // row_ror:8 = lane ^ 8 within the 16-lane row
+    v += dpp_mov<0x1B>(dpp_mov<0x141>(v));                                          // row_half_mirror then quad reverse = lane ^ 4
+    v += dpp_mov<0x4E>(v);                                                          // quad_perm [2,3,0,1] = lane ^ 2
+    v += dpp_mov<0xB1>(v);                                                          // quad_perm [1,0,3,2] = lane ^ 1
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -259,6 +276,24 @@ struct GemmArgs {
 };
 
 void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream_t s);
+// qgemm.hip: the query-sized projections (at most QGEMM_MAX_ROWS token rows, M % 32 == 0, K % 128 == 0): LDS-DMA ring with the
+// whole reach in flight, optional LayerNorm prologue (x != null: A = LayerNorm(x) * ln_mul rounded to the operand format, K = d).
+// Same k-ascending MFMA chain and epilogue arithmetic as the other GEMM kernels: identical bits.
+constexpr int QGEMM_MAX_ROWS = 512;
+struct QGemmArgs {
+    GemmArgs g;
+    const float* x;        // LayerNorm prologue: fp32 [M][K] residual stream (g.A unused), or null
+    const float* ln_g;
+    const float* ln_b;
+    float eps, ln_mul;     // ln_mul: power-of-two range shift of the normalised rows (0 is read as 1)
+    int ns;                // ring stages (set by the launcher)
+    int group;             // LayerNorm prologue: column tiles per workgroup (set by the launcher)
+};
+bool qgemm_shape_ok(int M, int N, int K, int epi, int n_split);
+bool qgemm_ln_ok(int M, int N, int d, int epi, int n_split);
+// false = shape / options not served (nothing launched): the caller takes launch_gemm
+bool launch_qgemm(int dtype, int epi, int out_dtype, const QGemmArgs& a, hipStream_t s);
+
 bool gemm_qkv_one_launch(int M, int n_split, bool force256);   // 16-bit operands: does EPI_QKV apply (query-sized batch)?
 bool gemm_qkv_bulk(int M, int N, int K, int n_split, bool force256);   // 16-bit operands: EPI_QKV on the 256x256 kernel (bulk batch)?
 #ifdef SGPT_EXPERIMENTS        // A/B knobs of the measurement scripts (libsgpt_hip_exp.so only)

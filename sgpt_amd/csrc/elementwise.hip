@@ -3,12 +3,8 @@
 // All are one-wave-per-row (64 lanes x float4 = 1 KiB per instruction, coalesced) with
 // wavefront-shuffle reductions; no LDS except the cross-wave combine of the pool.
 #include "common.h"
+#include "rowln.h"
 
-#ifndef SGPT_LN_NT_LOAD
-#define SGPT_LN_NT_LOAD 1   // LayerNorm / ln_f+pool read the residual stream with non-temporal loads: x is not needed again
-                            // before the next residual epilogue, and leaving the caches to `a` (the next GEMM's operand) is
-                            // +2.9 % end to end (36.07 k -> 37.11 k sentences/s, A/B on one box)
-#endif
 
 namespace {
 
@@ -35,52 +31,6 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ ids,
         o[c] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
     }
 }
-
-// row statistics + normalise in registers: nn.LayerNorm(eps) (HF:gpt_neo:317-319,385,492)
-template <int NV>
-struct RowLN {
-    float4 v[NV];
-    __device__ __forceinline__ void load(const float* __restrict__ xr, int d, int lane) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * 4;
-#if SGPT_LN_NT_LOAD
-            v[i] = c < d ? ldg16<true>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-#else
-            v[i] = c < d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-        }
-    }
-    __device__ __forceinline__ void normalize(const float* __restrict__ g, const float* __restrict__ b, int d,
-                                              float eps, int lane) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        const float mean = wave_sum(s) / (float)d;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < d) {
-                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
-                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            }
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < d) {
-                const float4 gg = *reinterpret_cast<const float4*>(g + c);
-                const float4 bb = *reinterpret_cast<const float4*>(b + c);
-                v[i].x = (v[i].x - mean) * rstd * gg.x + bb.x;
-                v[i].y = (v[i].y - mean) * rstd * gg.y + bb.y;
-                v[i].z = (v[i].z - mean) * rstd * gg.z + bb.z;
-                v[i].w = (v[i].w - mean) * rstd * gg.w + bb.w;
-            }
-        }
-    }
-};
 
 // out_mul: power-of-two range shift of an f16 output (the consuming GEMMs multiply their accumulators by 1 / out_mul);
 // 1 for every other format and for models without shifts (v * 1 == v: the default path keeps its bits)

@@ -34,6 +34,16 @@ PROBE_MAX_ROWS = 8192   # token rows of the probe forward (a bounded sample of t
 # U{16..128} 62.8 / 63.4 / 63.9 k sentences/s; bit-identical embeddings per sequence (a sequence's arithmetic does not see its offset).
 ALIGN = 2
 TOKEN_TILE = 256   # GEMM M tile (256x256 LDS-DMA kernel)
+# Query-sized batches (round 6, csrc/qgemm.hip): a layout of at most QUERY_ROWS token rows is padded to QUERY_TILE-row tiles
+# only -- its projections run on 32-row tiles, and one 18-token query no longer pays for 256 rows.
+QUERY_ROWS = 512
+QUERY_TILE = 32
+
+
+def pad_rows(total: int) -> int:
+    """Token rows of a packed layout holding `total` allocated rows (include/sgpt_hip.h: T_pad % 32 == 0)."""
+    tile = QUERY_TILE if total <= QUERY_ROWS else TOKEN_TILE
+    return (int(total) + tile - 1) // tile * tile
 
 
 @dataclass
@@ -138,15 +148,16 @@ def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None, bucket: Optional
     max_pos = int((lens + pl.astype(np.int64)).max()) - 1
     if bucket is not None:
         B_cap, T_cap, A_cap = bucket
-        if B_cap < B or T_cap % TOKEN_TILE or A_cap % ALIGN:
-            raise ValueError(f"bucket {bucket} cannot hold {B} sequences (T_cap % {TOKEN_TILE}, A_cap % {ALIGN})")
+        if B_cap < B or T_cap != pad_rows(T_cap) or A_cap % ALIGN:
+            raise ValueError(f"bucket {bucket} cannot hold {B} sequences (T_cap % {TOKEN_TILE}, or % {QUERY_TILE} up to "
+                             f"{QUERY_ROWS} rows; A_cap % {ALIGN})")
         lens = np.concatenate([lens, np.ones(B_cap - B, dtype=np.int64)])
         pl = np.concatenate([pl, np.zeros(B_cap - B, dtype=np.int32)])
         B = B_cap
     alloc = (lens + ALIGN - 1) // ALIGN * ALIGN
     off = np.zeros(B + 1, dtype=np.int64)
     np.cumsum(alloc, out=off[1:])
-    T_pad = (int(off[-1]) + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE
+    T_pad = pad_rows(int(off[-1]))
     max_alloc = int(alloc.max())
     if bucket is not None:
         if T_pad > bucket[1] or max_alloc > bucket[2]:

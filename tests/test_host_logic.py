@@ -61,11 +61,13 @@ def test_synthetic_weights_match_oracle_stream():
 
 
 def test_pack_host_layout():
-    from sgpt_amd.model import pack_host, ALIGN
+    from sgpt_amd.model import pack_host, pad_rows, ALIGN
     seqs = [[5, 6, 7], list(range(1, 18)), [9] * 16, [1]]
     h = pack_host(seqs, pad_left=[2, 0, 0, 7])
     up = lambda n: (n + ALIGN - 1) // ALIGN * ALIGN  # noqa: E731
-    assert h["B"] == 4 and h["T_pad"] % 256 == 0 and h["max_alloc"] == up(17) and h["n_tokens"] == 37
+    # query-sized layouts (<= 512 rows) pad to 32-row tiles, larger ones to the 256-row GEMM tile (include/sgpt_hip.h)
+    assert [pad_rows(n) for n in (1, 32, 33, 512, 513, 4096, 4097)] == [32, 32, 64, 512, 768, 4096, 4352]
+    assert h["B"] == 4 and h["T_pad"] == 64 and h["max_alloc"] == up(17) and h["n_tokens"] == 37
     off = h["seq_off"]
     assert off.tolist() == [0, up(3), up(3) + up(17), up(3) + up(17) + 16, up(3) + up(17) + 16 + up(1)] and all(o % ALIGN == 0 for o in off)
     for b, s in enumerate(seqs):
@@ -345,13 +347,13 @@ def test_bucketed_layout_keeps_the_real_rows_and_appends_one_token_fillers():
 def test_pack_arena_equals_reference_layout_for_every_input_form():
     """One-buffer packed layout (ids | pos | seq_off | seq_len | pad_left): lists, lists of ndarrays and a rectangular
     ndarray give the same image; rows land at seq_off[b] + t, positions are pad_left[b] + t, filler stays 0."""
-    from sgpt_amd.model import ALIGN, TOKEN_TILE, arena_ints, fill_arena, pack_host, pack_layout
+    from sgpt_amd.model import ALIGN, arena_ints, fill_arena, pack_host, pack_layout, pad_rows
     rng = np.random.default_rng(4)
     lens = [1, 16, 17, 40, 5, 128]
     seqs = [rng.integers(1, 1000, size=n).tolist() for n in lens]
     pl = [3, 0, 7, 0, 0, 1]
     h = pack_host(seqs, pl)
-    assert h["T_pad"] % TOKEN_TILE == 0 and h["arena"].shape[0] == arena_ints(pack_layout(seqs, pl))
+    assert h["T_pad"] == pad_rows(h["T_pad"]) and h["T_pad"] % 32 == 0 and h["arena"].shape[0] == arena_ints(pack_layout(seqs, pl))
     off = h["seq_off"]
     assert (off % ALIGN == 0).all() and off[0] == 0
     for b, s in enumerate(seqs):
