@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPT_ABI_VERSION 7
+#define SGPT_ABI_VERSION 8
 
 typedef int sgpt_status;
 #define SGPT_OK 0
@@ -219,6 +219,13 @@ sgpt_status sgpt_pool_learnt(sgpt_ctx* ctx, const void* hidden, int32_t hidden_d
  * (sentence_transformers/util.py:41-42, 66-70).  out may alias in when out_dtype == SGPT_F32. */
 sgpt_status sgpt_l2_normalize(sgpt_ctx* ctx, const float* in, int64_t n, int32_t d,
                               void* out, int32_t out_dtype, void* stream);
+
+/* Row-wise scores of two [n, d] fp32 matrices (ABI v8): out[i] = dot(a[i], b[i]) -- util.pairwise_dot_score,
+ * sentence_transformers/util.py:66-76 -- or, cosine != 0, the same sum over rows normalised as sgpt_l2_normalize does --
+ * util.pairwise_cos_sim, util.py:79-91 (`pairwise_dot_score(normalize_embeddings(a), normalize_embeddings(b))`).
+ * The reference's own cases: tests/test_util.py:69-76. */
+sgpt_status sgpt_pairwise_scores(sgpt_ctx* ctx, const float* a, const float* b, int64_t n, int32_t d, int32_t cosine,
+                                 float* out, void* stream);
 
 /* fp32 -> bf16 / f16 (RNE) element-wise; used to keep a corpus shard in HBM in the scorer's 16-bit operand format
  * (out_dtype SGPT_BF16 | SGPT_F16; normalised embeddings are in [-1, 1], inside either range). */

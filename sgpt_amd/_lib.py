@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGPT_HIP_LIB") or os.path.join(HERE, "lib", "libsgpt_hip.so")   # env: A/B builds of the same ABI
 
 SGPT_F32, SGPT_BF16, SGPT_FP8W, SGPT_F16, SGPT_FP8M = 0, 1, 2, 3, 4
-SGPT_ABI_VERSION = 7
+SGPT_ABI_VERSION = 8
 SGPT_PREC_CLASSES = 5                      # precision-plan classes per block: LN1, ATT, CTX, LN2, H (include/sgpt_hip.h)
 PC_LN1, PC_ATT, PC_CTX, PC_LN2, PC_H = 0, 1, 2, 3, 4
 SGPT_ERR_RANGE = -5
@@ -57,6 +57,7 @@ SIGNATURES = {
     "sgpt_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                             C.c_int32, C.c_void_p, C.c_void_p]),
     "sgpt_l2_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sgpt_pairwise_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sgpt_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "sgpt_f32_to_16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "sgpt_range_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]),

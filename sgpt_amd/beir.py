@@ -351,7 +351,7 @@ def _host_ext():
                 mod = importlib.util.module_from_spec(spec)
                 spec.loader.exec_module(mod)
                 _HOST_EXT = mod
-            except ImportError as e:        # built for another interpreter: the Python form below gives the same dict
+            except Exception as e:          # built for another interpreter / not loadable: the Python form below gives the same dict
                 logger.warning("host extension %s not loadable (%s): result dicts are assembled in Python", path, e)
     return _HOST_EXT or None
 

@@ -84,7 +84,11 @@ def build(force=False, verbose=False):
         # librccl.so.1 -- and checking its NCCL major version against the header it was compiled with).  A single-GPU user
         # needs no RCCL to build or load the library; rccl.h (types only) comes from the ROCm include directory.
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
-    build_host(force=force, verbose=verbose)
+    try:
+        build_host(force=force, verbose=verbose)
+    except Exception as e:       # optional helper (the k = 1001 result dict in C): its failure must not fail the GPU library's build
+        import warnings
+        warnings.warn(f"host extension not built ({str(e).splitlines()[0]} ...): beir.assemble_results uses its Python form")
     return LIB
 
 

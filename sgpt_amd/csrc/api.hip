@@ -930,6 +930,15 @@ sgpt_status sgpt_l2_normalize(sgpt_ctx* c, const float* in, int64_t n, int32_t d
     return SGPT_OK;
 }
 
+sgpt_status sgpt_pairwise_scores(sgpt_ctx* c, const float* a, const float* b, int64_t n, int32_t d, int32_t cosine, float* out,
+                                 void* stream) {
+    if (!c || !a || !b || !out || n <= 0 || d <= 0) return fail(c, SGPT_ERR_INVALID, "sgpt_pairwise_scores: bad arguments");
+    HIPC(c, hipSetDevice(c->device));
+    launch_pairwise(a, b, n, d, cosine != 0, out, (hipStream_t)stream);
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
 sgpt_status sgpt_f32_to_16(sgpt_ctx* c, const float* in, int64_t numel, void* out, int32_t out_dtype, void* stream) {
     if (!c || !in || !out || numel <= 0 || (out_dtype != SGPT_BF16 && out_dtype != SGPT_F16))
         return fail(c, SGPT_ERR_INVALID, "sgpt_f32_to_16: bad arguments");
@@ -1142,8 +1151,8 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
         // the < 256 trailing documents ride in the 256x256 launch (clamped rows, GemmArgs.n_valid; their missing columns land in the
         // padding of the score row, which the select does not read): one launch less per piece -- a no-op one in the predicated
         // fallback of every filtered chunk
-        const bool fold = SGPT_FOLD_TAIL && SGPT_FOLD_TAIL_SCORE && na > 0 && na < nc && row_stride == 1 && nq_pad >= 256 &&
-                          (long)nq_pad < na + 256 && na + 256 <= ld;
+        const bool fold = SGPT_FOLD_TAIL && SGPT_FOLD_TAIL_SCORE && na > 0 && na < nc && row_stride == 1 && na + 256 <= ld &&
+                          gemm_score_tail_foldable(nq_pad, na + 256, d);
         if (na > 0) {
             GemmArgs h = g;
             h.A = qpad; h.M = nq_pad; h.N = (int)(fold ? na + 256 : na); h.n_valid = fold ? (int)nc : 0;
@@ -1259,7 +1268,7 @@ static sgpt_status score_topk_impl(sgpt_ctx* c, const void* q, const void* corpu
             g.cand_val = cand_v; g.cand_idx = cand_i; g.cand_cnt = cand_cnt; g.cand_cap = cap; g.idx_base = idx_base + seen;
             // the < 256 trailing documents ride in the last chunk's launch (the 256x256 kernel clamps their rows and masks their
             // columns, GemmArgs.n_valid) when documents are its streamed operand; the 64-row tile keeps its own tail launch
-            const bool fold_tail = SGPT_FOLD_TAIL && seen + len == n256 && N > n256 && nq_pad >= 256 && (long)nq_pad < len + 256;
+            const bool fold_tail = SGPT_FOLD_TAIL && seen + len == n256 && N > n256 && gemm_score_tail_foldable(nq_pad, len + 256, d);
             if (fold_tail) { g.N = (int)(len + 256); g.n_valid = (int)(len + (N - n256)); }
             gemm(c, dtype, EPI_SCORE_FILTER, SGPT_F32, g, s);
             g.n_valid = 0;

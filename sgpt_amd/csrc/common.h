@@ -295,6 +295,7 @@ bool qgemm_ln_ok(int M, int N, int d, int epi, int n_split);
 bool launch_qgemm(int dtype, int epi, int out_dtype, const QGemmArgs& a, hipStream_t s);
 
 bool gemm_qkv_one_launch(int M, int n_split, bool force256);   // 16-bit operands: does EPI_QKV apply (query-sized batch)?
+bool gemm_score_tail_foldable(int M, long N, int K);   // scorer: may the < 256 trailing documents ride in the 256x256 launch (GemmArgs.n_valid)?
 bool gemm_qkv_bulk(int M, int N, int K, int n_split, bool force256);   // 16-bit operands: EPI_QKV on the 256x256 kernel (bulk batch)?
 #ifdef SGPT_EXPERIMENTS        // A/B knobs of the measurement scripts (libsgpt_hip_exp.so only)
 int set_gemm_skew(int cycles);  // start-up stagger of the persistent 256^2 kernel (shader cycles per phase); returns the previous value
@@ -363,6 +364,7 @@ void launch_fp8_quant_rows(const float* w, long rows, long cols, void* q, float*
 void launch_fp8_dequant_rows(const void* q, const float* scale, long rows, long cols, void* out, int out_dtype,
                              hipStream_t s);
 void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s);
+void launch_pairwise(const float* a, const float* b, long n, int d, bool cosine, float* out, hipStream_t s);
 // cross-encoder scoring (sgptce.py): gather hidden rows; log_softmax + gather target + argmax per logits row
 void launch_gather_rows(const float* src, const int* row_idx, int n, int d, float* dst, hipStream_t s);
 void launch_logprob_rows(const float* logits, long ld, int V, const int* targets, int n, float* out_lp, int* out_arg,

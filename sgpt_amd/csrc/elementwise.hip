@@ -281,6 +281,35 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ i
     }
 }
 
+// ---- row-wise scores of two equally shaped matrices: util.pairwise_dot_score / pairwise_cos_sim (util.py:66-91) ----
+// out[i] = sum_j a[i][j] b[i][j]            (COS = false: `(a * b).sum(dim=-1)`)
+//        = sum_j (a[i][j] / max(|a[i]|, 1e-12)) (b[i][j] / max(|b[i]|, 1e-12))   (COS = true: both sides through
+//          normalize_embeddings first, then the same product sum -- the reference's order of operations, not dot / (|a| |b|)).
+// One wave per row pair, float4 loads where the row allows, wavefront butterflies for the three sums.
+template <bool COS>
+__global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, int d,
+                                                       float* __restrict__ out) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float* ar = a + row * d;
+    const float* br = b + row * d;
+    float na = 1.f, nb = 1.f;
+    if constexpr (COS) {
+        float sa = 0.f, sb = 0.f;
+        for (int c = lane; c < d; c += 64) { const float x = ar[c], y = br[c]; sa += x * x; sb += y * y; }
+        na = fmaxf(sqrtf(wave_sum(sa)), 1e-12f);
+        nb = fmaxf(sqrtf(wave_sum(sb)), 1e-12f);
+    }
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float x = COS ? ar[c] / na : ar[c], y = COS ? br[c] / nb : br[c];
+        s += x * y;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
 // ---- GPT-J rotary position embedding (HF:gptj/modeling_gptj.py:57-67,190-210) ----
 // For every token, head and pair i < rotary_dim/2 of the head's leading dims:
 //   (x[2i], x[2i+1]) <- (x[2i] cos - x[2i+1] sin, x[2i+1] cos + x[2i] sin),  angle = pos * inv_freq[i]
@@ -678,6 +707,12 @@ void launch_logprob_rows(const float* logits, long ld, int V, const int* targets
 
 void launch_mean_over_axis0(const float* in, int n0, long n, float* out, hipStream_t s) {
     hipLaunchKernelGGL(mean_axis0_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n0, n, out);
+}
+
+void launch_pairwise(const float* a, const float* b, long n, int d, bool cosine, float* out, hipStream_t s) {
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    if (cosine) hipLaunchKernelGGL(pairwise_kernel<true>, dim3(grid), dim3(256), 0, s, a, b, n, d, out);
+    else hipLaunchKernelGGL(pairwise_kernel<false>, dim3(grid), dim3(256), 0, s, a, b, n, d, out);
 }
 
 void launch_l2norm(const float* in, long n, int d, void* out, int out_dtype, hipStream_t s) {

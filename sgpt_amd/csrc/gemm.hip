@@ -1072,6 +1072,25 @@ void launch(const GemmArgs& a, hipStream_t s) {
 template <typename H>
 void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
     const bool o16 = dt_is16(out_dtype);
+    // A folded ragged document tail (n_valid > 0: N = whole 256-document tiles + 256, the last tile's rows clamped / columns masked)
+    // exists in the 256x256 scorer launches only.  The callers ask gemm_score_tail_foldable() -- the one predicate -- before they
+    // fold; a launch that arrives here folded without satisfying it (an experiment build's switches, a future edit) is split into
+    // the two launches the fold replaced instead of reaching a kernel that ignores n_valid (round 6, ADVICE r05: was abort()).
+    if (a.n_valid > 0) {
+        const bool scorer_ = epi == EPI_SCORE || epi == EPI_SCORE_FILTER || epi == EPI_SCORE_TOP2;
+        if (!(scorer_ && gemm_score_tail_foldable(a.M, a.N, a.K))) {
+            const int whole = a.N - 256;
+            GemmArgs b = a;
+            b.N = whole; b.n_valid = 0;
+            if (whole > 0) launch_gemm16<H>(epi, out_dtype, b, s);
+            GemmArgs t = a;
+            t.W = static_cast<const char*>(a.W) + (size_t)whole * a.ldw * 2; t.N = a.n_valid - whole; t.n_valid = 0;
+            if (a.out != nullptr) t.out = static_cast<float*>(a.out) + whole;
+            t.idx_base = a.idx_base + whole;
+            if (t.N > 0) launch_gemm16<H>(epi, out_dtype, t, s);
+            return;
+        }
+    }
     // Small problems (short query batches, USEB's 21-32 sentence calls): fewer than half a wave of 256x256 tiles
     // leaves most of the 256 CUs idle; the register-staged kernel's 128x128 / 64x64 tiles fill the chip instead.
     // Bit-identical results (see gemm_kernel), so the embeddings stay batch-invariant.  SGPT_NO_SMALL_TILE=1: A/B.
@@ -1104,7 +1123,6 @@ void launch_gemm16(int epi, int out_dtype, const GemmArgs& a, hipStream_t s) {
         }
         return launch<H, EPI_QKV, H, true>(a, s);                   // caller checked gemm_qkv_one_launch()
     }
-    if (a.n_valid > 0 && !(use256 && shape256 && scorer && a.M < a.N)) abort();   // a folded ragged tail exists in the 256x256 scorer launches only
     if (use256 && shape256 && (scorer || (!few && a.m_valid == a.M))) {
         const bool deep_a = a.M >= a.N;          // the longer axis is the streamed operand (tokens / documents)
 #ifdef SGPT_EXPERIMENTS
@@ -1157,6 +1175,13 @@ bool gemm_qkv_bulk(int M, int N, int K, int n_split, bool force256) {
     if (!SGPT_QKV_BULK || exp_env("SGPT_QKV_TWO") != nullptr || exp_env("SGPT_GEMM128") != nullptr) return false;
     return M % 256 == 0 && N % 256 == 0 && n_split % 256 == 0 && n_split < N && K % 64 == 0 && K >= 128 &&
            (long)(M / 256) * (n_split / 256) > SGPT_FEW_TILES;
+}
+// THE predicate of the folded ragged tail (api.hip asks it before folding; launch_gemm16 re-checks it): a scorer launch of M padded
+// query rows against N = (whole 256-document tiles + 256) documents of width K takes the 256x256 kernel with the documents as its
+// streamed operand -- the only kernel that honours GemmArgs.n_valid.
+bool gemm_score_tail_foldable(int M, long N, int K) {
+    if (exp_env("SGPT_GEMM128") != nullptr) return false;
+    return M >= 256 && M != 64 && M % 256 == 0 && N % 256 == 0 && N >= 512 && K % 64 == 0 && K >= 128 && (long)M < N;
 }
 #ifdef SGPT_EXPERIMENTS
 int set_gemm_skew(int cycles) { const int old = g_skew; g_skew = cycles; return old; }

@@ -10,6 +10,16 @@
 #include <Python.h>
 #include <stdint.h>
 
+/* Pre-sized dicts are a private CPython call: used where it is known to exist with this signature (CPython 3.8 - 3.12, the GIL
+ * build); anywhere else -- newer, free-threaded or non-CPython interpreters -- the public constructor (the dict then grows by
+ * rehashing: slower, same contents).  List items are read through the public macro. */
+#if defined(Py_GIL_DISABLED) || !defined(PY_VERSION_HEX) || PY_VERSION_HEX < 0x03080000 || PY_VERSION_HEX >= 0x030D0000 || \
+    defined(PYPY_VERSION) || defined(Py_LIMITED_API)
+#define SGPT_DICT_NEW(n) PyDict_New()
+#else
+#define SGPT_DICT_NEW(n) _PyDict_NewPresized(n)
+#endif
+
 /* assemble(query_ids: list, corpus_ids: list, vals: C-contiguous float32[nq, k], idxs: C-contiguous int64[nq, k]) -> dict
  * Entries with idx < 0 are padding (a shard with fewer than k documents) and are skipped, exact_search.py:117-120. */
 static PyObject* assemble(PyObject* self, PyObject* args) {
@@ -29,18 +39,17 @@ static PyObject* assemble(PyObject* self, PyObject* args) {
         const Py_ssize_t k = vb.len / 4 / nq;
         const float* v = (const float*)vb.buf;
         const int64_t* ix = (const int64_t*)ib.buf;
-        PyObject** items = ((PyListObject*)cids)->ob_item;
-        out = _PyDict_NewPresized(nq);
+        out = SGPT_DICT_NEW(nq);
         if (!out) goto done;
         for (Py_ssize_t q = 0; q < nq; ++q) {
-            PyObject* d = _PyDict_NewPresized(k);
+            PyObject* d = SGPT_DICT_NEW(k);
             if (!d) { Py_CLEAR(out); goto done; }
             const float* vr = v + q * k;
             const int64_t* ir = ix + q * k;
             for (Py_ssize_t j = 0; j < k; ++j) {
                 if (j + 16 < k) {
                     const int64_t pn = ir[j + 16];
-                    if (pn >= 0 && pn < nc) __builtin_prefetch(items[pn]);
+                    if (pn >= 0 && pn < nc) __builtin_prefetch(PyList_GET_ITEM(cids, pn));
                 }
                 const int64_t p = ir[j];
                 if (p < 0) continue;
@@ -49,7 +58,7 @@ static PyObject* assemble(PyObject* self, PyObject* args) {
                     Py_DECREF(d); Py_CLEAR(out); goto done;
                 }
                 PyObject* f = PyFloat_FromDouble((double)vr[j]);
-                if (!f || PyDict_SetItem(d, items[p], f) < 0) { Py_XDECREF(f); Py_DECREF(d); Py_CLEAR(out); goto done; }
+                if (!f || PyDict_SetItem(d, PyList_GET_ITEM(cids, p), f) < 0) { Py_XDECREF(f); Py_DECREF(d); Py_CLEAR(out); goto done; }
                 Py_DECREF(f);
             }
             if (PyDict_SetItem(out, PyList_GET_ITEM(qids, q), d) < 0) { Py_DECREF(d); Py_CLEAR(out); goto done; }

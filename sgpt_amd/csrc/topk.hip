@@ -65,8 +65,14 @@ struct Row {
     }
 };
 
+// The order of every path of this file (round 6: ONE order -- ADVICE r05).  Higher score first, ties -> lower index.  It is
+// taken on the order-preserving integer image of the score, so it is total over NaNs too: a positive NaN ranks above +inf and a
+// negative one below -inf (torch.topk's convention for the former), exactly as the register-key rounds (wave_topk_keys) and
+// the radix path rank them; -0.0 is folded into +0.0 (equal scores tie on the index).  For every other pair of floats this is
+// `va > vb || (va == vb && ia < ib)`.
 __device__ __forceinline__ bool sorts_before(float va, int64_t ia, float vb, int64_t ib) {
-    return va > vb || (va == vb && ia < ib);
+    const uint32_t ka = f2key(va + 0.0f), kb = f2key(vb + 0.0f);
+    return ka > kb || (ka == kb && ia < ib);
 }
 
 // Wave-wide arg-max of (value, index, position) triples under sorts_before (ties -> lower index; a total order, so the result does
@@ -114,7 +120,10 @@ __device__ __forceinline__ void wave_argmax(float& bv, int64_t& bi, int& bp) {
 // (round 5).  key = f2key(value) << 32 | (0xffffffff - index): one unsigned 64-bit compare is the whole comparator (higher score
 // first, ties -> lower index), keys are unique per row (indices are), 0 = an empty slot.  A round is a lane-local maximum over the
 // lane's SLOTS keys, a six-step VALU butterfly on two dwords, and the owner clearing its key -- no LDS access and no 64-bit index
-// plumbing inside the loop.  (The LDS-scanning rounds this replaces cost ~0.8 us + 0.5 us per 256 candidates EACH -- two dependent
+// plumbing inside the loop.  Equal (score, index) pairs (a caller's lists handed to sgpt_topk_merge may repeat an id) are all
+// emitted, one per round: only ONE slot -- lowest lane, lowest slot -- is cleared per round (round 6; clearing every key equal to
+// the round's best collapsed such pairs into one output and left the last slot empty).  A negative index is an empty slot on
+// every path (it would decode to 2^32 - 1 + id).  (The LDS-scanning rounds this replaces cost ~0.8 us + 0.5 us per 256 candidates EACH -- two dependent
 // LDS loads per 64 candidates, four-dword shuffles -- 17 us of launch for the k = 11 best of 251, scripts/select_probe.py.)
 // Needs indices < 2^32 - 1 (the caller checks, block-uniformly, and keeps the generic rounds otherwise); -0.0 is folded into +0.0
 // so that equal scores tie on the index as they do under the float comparator.  emit(round, value, index, valid) runs on lane 0.
@@ -142,8 +151,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long x,
     return x;
 }
 template <int SLOTS, typename Emit>
-__device__ __forceinline__ void wave_topk_keys(const float* s_val, const int64_t* s_idx, int cnt, int rounds, int lane, bool skip_negative_idx,
-                                               Emit emit) {
+__device__ __forceinline__ void wave_topk_keys(const float* s_val, const int64_t* s_idx, int cnt, int rounds, int lane, Emit emit) {
     unsigned long long key[SLOTS];
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
@@ -152,7 +160,7 @@ __device__ __forceinline__ void wave_topk_keys(const float* s_val, const int64_t
         if (c < cnt) {
             const float v = s_val[c] + 0.0f;
             const int64_t id = s_idx[c];
-            if (!(skip_negative_idx && id < 0)) kk_ = ((unsigned long long)f2key(v) << 32) | (0xffffffffu - (unsigned)id);
+            if (id >= 0) kk_ = ((unsigned long long)f2key(v) << 32) | (0xffffffffu - (unsigned)id);
         }
         key[u] = kk_;
     }
@@ -161,8 +169,19 @@ __device__ __forceinline__ void wave_topk_keys(const float* s_val, const int64_t
 #pragma unroll
         for (int u = 1; u < SLOTS; ++u) best = key[u] > best ? key[u] : best;
         best = wave_max_u64(best, lane);
+        bool mine = false;
 #pragma unroll
-        for (int u = 0; u < SLOTS; ++u) key[u] = key[u] == best ? 0ull : key[u];
+        for (int u = 0; u < SLOTS; ++u) mine |= key[u] == best;
+        const int owner = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(mine)) - 1);   // (best == 0: every lane; harmless)
+        if (lane == owner) {
+            bool cleared = false;
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) {
+                const bool hit = !cleared && key[u] == best;
+                key[u] = hit ? 0ull : key[u];
+                cleared |= hit;
+            }
+        }
         if (lane == 0) {
             const uint32_t kv = (uint32_t)(best >> 32);
             const float v = __uint_as_float((kv & 0x80000000u) ? (kv & 0x7fffffffu) : ~kv);
@@ -171,11 +190,10 @@ __device__ __forceinline__ void wave_topk_keys(const float* s_val, const int64_t
     }
 }
 template <typename Emit>
-__device__ __forceinline__ void wave_topk_keys_any(const float* s_val, const int64_t* s_idx, int cnt, int rounds, int lane,
-                                                   bool skip_negative_idx, Emit emit) {
-    if (cnt <= 256) wave_topk_keys<4>(s_val, s_idx, cnt, rounds, lane, skip_negative_idx, emit);
-    else if (cnt <= 1024) wave_topk_keys<16>(s_val, s_idx, cnt, rounds, lane, skip_negative_idx, emit);
-    else wave_topk_keys<32>(s_val, s_idx, cnt, rounds, lane, skip_negative_idx, emit);
+__device__ __forceinline__ void wave_topk_keys_any(const float* s_val, const int64_t* s_idx, int cnt, int rounds, int lane, Emit emit) {
+    if (cnt <= 256) wave_topk_keys<4>(s_val, s_idx, cnt, rounds, lane, emit);
+    else if (cnt <= 1024) wave_topk_keys<16>(s_val, s_idx, cnt, rounds, lane, emit);
+    else wave_topk_keys<32>(s_val, s_idx, cnt, rounds, lane, emit);
 }
 // block-uniform: does every (valid) index of s_idx[0, cnt) fit the 32-bit key field?  (ends with a barrier)
 __device__ __forceinline__ bool idx_fit_keys(const int64_t* s_idx, int cnt, int t, int nthreads) {
@@ -276,8 +294,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
         __syncthreads();
         const bool keys_ok = idx_fit_keys(s_idx, (int)total, t, TK_THREADS);
         if (t < 64 && keys_ok) {
-            wave_topk_keys_any(s_val, s_idx, (int)total, kk, lane, true, [&](int round, float bv, int64_t bi, bool valid) {
-                const bool ok = valid && bv > -INFINITY;                // (-inf: an empty / excluded slot -> (-inf, -1) like every path)
+            wave_topk_keys_any(s_val, s_idx, (int)total, kk, lane, [&](int round, float bv, int64_t bi, bool valid) {
+                const bool ok = valid && (bv > -INFINITY || bv != bv);                // (-inf: an empty / excluded slot -> (-inf, -1) like every path)
                 ov[round] = ok ? bv : -INFINITY; oi[round] = ok ? bi : -1;
                 if (thr_out && round == k - 1) thr_out[qrow] = thr_below(ok ? bv : -INFINITY);
             });
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                 }
                 wave_argmax(bv, bi, bp);
                 if (lane == 0) {
-                    const bool ok = bp >= 0 && bv > -INFINITY;          // (-inf: an empty / excluded slot -> (-inf, -1) like every path)
+                    const bool ok = bp >= 0 && (bv > -INFINITY || bv != bv);          // (-inf: an empty / excluded slot -> (-inf, -1) like every path)
                     ov[round] = ok ? bv : -INFINITY; oi[round] = ok ? bi : -1;
                     if (thr_out && round == k - 1) thr_out[qrow] = thr_below(ok ? bv : -INFINITY);
                     if (bp >= 0) s_idx[bp] = -1;
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(const float* sc
                 // k best of the candidates by k rounds of wave-wide arg-max (wave 0; sorted, ties -> lower index)
                 const bool keys_ok = idx_fit_keys(s_idx, (int)cnt, t, TK_THREADS);
                 if (t < 64 && keys_ok) {
-                    wave_topk_keys_any(s_val, s_idx, (int)cnt, kk, lane, false, [&](int round, float bv, int64_t bi, bool) {
+                    wave_topk_keys_any(s_val, s_idx, (int)cnt, kk, lane, [&](int round, float bv, int64_t bi, bool) {
                         ov[round] = bv; oi[round] = bi;
                         if (thr_out && round == k - 1) thr_out[qrow] = thr_below(bv);
                     });
@@ -575,7 +593,7 @@ __global__ __launch_bounds__(TK_THREADS) void cand_merge_kernel(const float* __r
         int64_t* ti_ = r_idx + TK_MERGE_KMAX / 2;
         const bool keys_ok = idx_fit_keys(s_idx, cnt, t, TK_THREADS);
         if (t < 64 && keys_ok) {
-            wave_topk_keys_any(s_val, s_idx, cnt, k, t, false, [&](int round, float bv, int64_t bi, bool valid) {
+            wave_topk_keys_any(s_val, s_idx, cnt, k, t, [&](int round, float bv, int64_t bi, bool valid) {
                 tv_[round] = valid ? bv : -INFINITY; ti_[round] = valid ? bi : 0x7fffffffffffffffLL;
             });
         } else if (t < 64) {

@@ -40,9 +40,11 @@ QUERY_ROWS = 512
 QUERY_TILE = 32
 
 
-def pad_rows(total: int) -> int:
-    """Token rows of a packed layout holding `total` allocated rows (include/sgpt_hip.h: T_pad % 32 == 0)."""
-    tile = QUERY_TILE if total <= QUERY_ROWS else TOKEN_TILE
+def pad_rows(total: int, row_tile: Optional[int] = None) -> int:
+    """Token rows of a packed layout holding `total` allocated rows (include/sgpt_hip.h: T_pad % 32 == 0).
+    row_tile: a fixed tile instead (dtype='fp8mfma' keeps 256: its MFMA kernels only take 256-row tiles, and a layout they do not
+    fit would silently run the fp8-storage arithmetic)."""
+    tile = row_tile or (QUERY_TILE if total <= QUERY_ROWS else TOKEN_TILE)
     return (int(total) + tile - 1) // tile * tile
 
 
@@ -131,7 +133,8 @@ def _to_i32(a: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None, bucket: Optional[Tuple[int, int, int]] = None) -> dict:
+def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None, bucket: Optional[Tuple[int, int, int]] = None,
+                row_tile: Optional[int] = None) -> dict:
     """Sizes and offsets of the packed layout (no token data yet).
     bucket = (B_cap, T_cap, A_cap): pad the layout to that capacity -- B_cap - B one-token filler sequences behind the real
     ones, T_pad = T_cap, max_alloc = A_cap -- so that every batch of the bucket launches the same grids (hipGraph replay).
@@ -148,7 +151,7 @@ def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None, bucket: Optional
     max_pos = int((lens + pl.astype(np.int64)).max()) - 1
     if bucket is not None:
         B_cap, T_cap, A_cap = bucket
-        if B_cap < B or T_cap != pad_rows(T_cap) or A_cap % ALIGN:
+        if B_cap < B or T_cap != pad_rows(T_cap, row_tile) or A_cap % ALIGN:
             raise ValueError(f"bucket {bucket} cannot hold {B} sequences (T_cap % {TOKEN_TILE}, or % {QUERY_TILE} up to "
                              f"{QUERY_ROWS} rows; A_cap % {ALIGN})")
         lens = np.concatenate([lens, np.ones(B_cap - B, dtype=np.int64)])
@@ -157,7 +160,7 @@ def pack_layout(seqs, pad_left: Optional[Sequence[int]] = None, bucket: Optional
     alloc = (lens + ALIGN - 1) // ALIGN * ALIGN
     off = np.zeros(B + 1, dtype=np.int64)
     np.cumsum(alloc, out=off[1:])
-    T_pad = pad_rows(int(off[-1]))
+    T_pad = pad_rows(int(off[-1]), row_tile)
     max_alloc = int(alloc.max())
     if bucket is not None:
         if T_pad > bucket[1] or max_alloc > bucket[2]:
@@ -326,6 +329,7 @@ class SGPTModel:
         self.ctx = ctx or get_context(device)
         self.device = self.ctx.device
         self.dtype = dtype
+        self.row_tile = TOKEN_TILE if dtype == "fp8mfma" else None      # pack(): rows per layout tile (pad_rows)
         # token rows per sgpt_encode call: 131 072 = 6 / 12 / 24 full rounds of 256x256 tiles on 256 CUs for the 125M
         # projections (measured: 1000 TFLOP/s there, 864-890 at 49 k rows, 754 at 25 k); activations ~2.5 GB (125M) to
         # ~13 GB (bloom-7b1) of the 288 GB
@@ -482,19 +486,30 @@ class SGPTModel:
         if self.precision not in ("auto", "auto-class") or self.dtype not in ("f16", "bf16"):
             return
         L = self.cfg.num_layers
-        flags = np.zeros(L * 4 + 2, dtype=np.int32)
+        flags = np.zeros(L * 4 + 3, dtype=np.int32)
         crest = None
         if self._plan_pending:
             crest = self.probe_precision(seqs, pad_left)
             flags[: L * 4] = (crest > self._crest_limits()[None, :]).reshape(-1)
             flags[L * 4] = 1
-        flags[L * 4 + 1] = 1 if (self.precision_report or {}).get("decided", "plain") != "plain" else 0   # already escalated here
+        rep = self.precision_report or {}
+        flags[L * 4 + 1] = 1 if rep.get("decided", "plain") != "plain" else 0   # already escalated here
+        # a rank that settled on plain operands in an earlier call has given its [W_hi | W_hi | W_lo] copies back: it cannot follow
+        # an escalation any more.  That must fail on EVERY rank: a one-sided exception would leave the others waiting
+        # in the query all-gather.
+        flags[L * 4 + 2] = 1 if (not self._plan_pending and rep.get("split_weight_bytes_released", 0) > 0) else 0
         tot = np.asarray(reduce(flags.copy()), dtype=np.int32)
         if tot[L * 4] == 0 and tot[L * 4 + 1] == flags[L * 4 + 1]:
             return                                     # nobody was pending, everybody agrees
         hot = tot[: L * 4].reshape(L, 4) > 0
         if tot[L * 4 + 1] and not hot.any():
             hot[:] = True                              # a rank that escalated earlier (its own data): the others follow it
+        if hot.any() and tot[L * 4 + 2]:
+            raise RuntimeError(
+                f"sync_precision: the collective probe asks for split-precision operands ({int(hot.sum())} (block, class) flags over "
+                f"the ranks), but {int(tot[L * 4 + 2])} rank(s) already settled on plain operands in an earlier call and released "
+                "their split weight copies.  Raised on every rank.  Load the models with precision='x3' (or pin one plan with "
+                "set_precision_plan() on every rank) before a multi-process search over this data.")
         self._install_from_flags(hot, crest, probed="first call (collective)")
 
     def _crest_limits(self) -> np.ndarray:
@@ -603,7 +618,7 @@ class SGPTModel:
         """Token lists -> device-resident packed batch: ONE pinned, non-blocking H2D copy of the whole layout.
         bucket: pad the layout to a capacity (pack_layout); into: refill that batch's device arena (same bucket) instead of
         allocating a new one -- the form hipGraph replays use, whose kernels hold the arena's addresses."""
-        lay = pack_layout(seqs, pad_left, bucket)
+        lay = pack_layout(seqs, pad_left, bucket, self.row_tile)
         if lay["max_alloc"] > 2048 or lay["max_pos"] >= self.cfg.max_position_embeddings:
             raise ValueError("sequence longer than max_position_embeddings")
         n_int = arena_ints(lay)
@@ -704,6 +719,8 @@ class SGPTModel:
         (MT = floor(j * CUs / (d / 256)): 85, 170, 256, 341, 426, 512 row tiles at d = 768 on 256 CUs -- the wider launches are
         multiples of that one) by a small search that minimises the modelled rounds x K of the four projections plus a term linear
         in rows (LayerNorm / attention / epilogue bytes); the call count stays at ceil(total / max_tokens_per_call) or one more.
+        The one call whose size is not a round boundary (it takes what the others leave) comes LAST: plan_batches() cuts a call
+        at the last whole sequence inside its budget, and what those cuts leave over lands in that call, not in an extra one.
         Pure function of (total_rows, model shape, CU count): every rank computes the same plan."""
         ncu = ncu or self._num_cus()
         d, ffn = self.cfg.hidden_size, self.cfg.intermediate_size
@@ -736,7 +753,7 @@ class SGPTModel:
                 if last <= 0 or last > mt_max:
                     continue
                 c = fixed * cost(mt_max) + sum(cost(g) for g in combo) + cost(last)
-                cands.append((c, [mt_max] * fixed + sorted(list(combo) + [last], reverse=True)))
+                cands.append((c, [mt_max] * fixed + sorted(combo, reverse=True) + [last]))      # the free call goes last
         if cands:
             # plans within 0.3 % of the cheapest are equal as far as the model can tell: take the most balanced one (a short
             # last call runs its few rounds at a lower rate than the model's per-round cost -- ramp and tail of every launch)
@@ -753,20 +770,29 @@ class SGPTModel:
         alloc = (lens[order] + ALIGN - 1) // ALIGN * ALIGN
         # Budgets per call from call_budgets(): sizes whose GEMM launches end on whole rounds of the chip (round 4 cut equal
         # budgets -- better than 131 k + 131 k + 32 k, but a 99 k-row call idles 3-9 % of every launch in its last round).
+        # A call is cut at the last whole sequence inside its budget, so it leaves up to one sequence over: the plan is taken
+        # again over the rows still to go at every cut (round 6, ADVICE r05: with one plan for the whole list the leftovers of
+        # 4096 documents of U{16..128} tokens ended in an 80-row fourth call -- a whole pass through the layers for 80 rows).
         total = int(alloc.sum())
-        if getattr(self, "round_aware_calls", True):
-            budgets = self.call_budgets(total)
-        else:       # round 4's rule (A/B: bench.py --equal-calls): equal budgets, a multiple of the GEMM's token tile
+        round_aware = getattr(self, "round_aware_calls", True)
+        if not round_aware:       # round 4's rule (A/B: bench.py --equal-calls): equal budgets, a multiple of the GEMM's token tile
             n_calls = max(1, -(-total // self.max_tokens_per_call))
-            budgets = [min(self.max_tokens_per_call, (-(-total // n_calls) + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE + int(alloc.max()))]
-        out, start, tok, bi = [], 0, 0, 0
+            equal = min(self.max_tokens_per_call, (-(-total // n_calls) + TOKEN_TILE - 1) // TOKEN_TILE * TOKEN_TILE + int(alloc.max()))
+
+        def budget_for(remaining: int) -> int:
+            if not round_aware:
+                return equal
+            b = self.call_budgets(remaining)
+            return self.max_tokens_per_call if len(b) == 1 else min(self.max_tokens_per_call, b[0])
+        out, start, tok, done = [], 0, 0, 0
+        budget = budget_for(total)
         for i, a in enumerate(alloc):
-            budget = min(self.max_tokens_per_call, budgets[min(bi, len(budgets) - 1)])
             full = tok + a > budget or (max_sentences and i - start >= max_sentences)
             if full and i > start:
                 out.append(order[start:i])
+                done += tok
                 start, tok = i, 0
-                bi += 1
+                budget = budget_for(total - done)
             tok += int(a)
         out.append(order[start:])
         return out

@@ -101,6 +101,18 @@ class Context:
                                              _stream_ptr(self.device)), "sgpt_l2_normalize")
         return out
 
+    def pairwise_scores(self, a: torch.Tensor, b: torch.Tensor, cosine: bool) -> torch.Tensor:
+        """out[i] = dot(a[i], b[i]) (cosine: of the L2-normalised rows): include/sgpt_hip.h::sgpt_pairwise_scores."""
+        a, b = self._dev_f32(a), self._dev_f32(b)
+        if a.shape != b.shape or a.dim() != 2:
+            raise ValueError(f"pairwise scores need two [n, d] matrices of one shape, got {tuple(a.shape)} and {tuple(b.shape)}")
+        n, d = a.shape
+        out = torch.empty((n,), dtype=torch.float32, device=self.device)
+        if n:
+            self._chk(self.lib.sgpt_pairwise_scores(self.handle, _p(a), _p(b), n, d, 1 if cosine else 0, _p(out),
+                                                    _stream_ptr(self.device)), "sgpt_pairwise_scores")
+        return out
+
     def to_16(self, x: torch.Tensor, dtype=torch.float16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """fp32 -> bf16 / f16 (RNE) on the device: the scorer's 16-bit operand format."""
         x = x.to(device=self.device, dtype=torch.float32).contiguous()

@@ -1,5 +1,5 @@
 """Drop-in for the scoring helpers the reference imports
-(sentence_transformers/util.py:24-63,66-70,197-258 == beir.util.cos_sim/dot_score used at
+(sentence_transformers/util.py:24-91,197-258 == beir.util.cos_sim/dot_score used at
 biencoder/beir/custommodels/exact_search.py:9,27,96-98), computed by the HIP scorer."""
 from typing import Callable, List
 
@@ -24,6 +24,10 @@ def _wrap(a):
     return a
 
 
+def _as_tensor(a):
+    return a if isinstance(a, torch.Tensor) else torch.tensor(np.asarray(a))
+
+
 def normalize_embeddings(embeddings: torch.Tensor) -> torch.Tensor:
     """util.normalize_embeddings (util.py:66-70): rows scaled to unit L2 norm."""
     ctx, home = _ctx_for(embeddings)
@@ -45,6 +49,23 @@ def dot_score(a, b) -> torch.Tensor:
     """util.dot_score (util.py:46-63)."""
     ctx, home = _ctx_for(a, b)
     out = ctx.scores(ctx._dev_f32(_wrap(a)), ctx._dev_f32(_wrap(b)))
+    return out if home.type == "cuda" else out.cpu()
+
+
+def pairwise_dot_score(a, b) -> torch.Tensor:
+    """util.pairwise_dot_score (util.py:66-76): res[i] = dot(a[i], b[i])."""
+    ctx, home = _ctx_for(a, b)
+    a, b = _as_tensor(a), _as_tensor(b)
+    lead = a.shape[:-1]
+    out = ctx.pairwise_scores(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]), cosine=False).reshape(lead)
+    return out if home.type == "cuda" else out.cpu()
+
+
+def pairwise_cos_sim(a, b) -> torch.Tensor:
+    """util.pairwise_cos_sim (util.py:79-91): res[i] = cos_sim(a[i], b[i]) -- the product sum of the normalised rows."""
+    ctx, home = _ctx_for(a, b)
+    a, b = _as_tensor(a), _as_tensor(b)
+    out = ctx.pairwise_scores(a, b, cosine=True)         # (normalize_embeddings is dim=1: matrices, as in the reference)
     return out if home.type == "cuda" else out.cpu()
 
 

@@ -381,6 +381,41 @@ def test_two_rank_precision_decision_is_collective(hot_rank):
             assert np.asarray(plan).all()                       # every class of every block split
 
 
+def _precision_released_worker(rank, world, port, out, hot_rank):
+    _init(rank, world, port)
+    try:
+        from sgpt_amd.beir import DenseRetrievalExactSearch
+        corpus, queries = _text_data(40, 12)
+        tm = _PlanTextModel(hot_rank)
+        m = tm.model
+        if rank == 0:
+            # rank 0 encoded on its own earlier: its probe settled on plain operands and the split weight copies went back
+            m._install_from_flags(np.zeros((3, 4), dtype=bool), None, probed="first call")
+            assert m.precision_report["split_weight_bytes_released"] == 123 and not m._plan_pending
+        err = None
+        try:
+            DenseRetrievalExactSearch(tm, corpus_chunk_size=16, ctx=StubCtx()).search(corpus, queries, 3, "cos_sim")
+        except RuntimeError as e:
+            err = str(e)
+        out.put((rank, err, m.precision_report["decided"] if m.precision_report else None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("hot_rank", [1, -1])
+def test_two_rank_precision_escalation_after_a_release_fails_on_every_rank(hot_rank):
+    """rank 0 has already encoded, settled on plain operands and released its split weight copies; rank 1's
+    probe then flags a class.  Rank 0 cannot install the union plan any more -- the refusal must reach BOTH ranks (one collective
+    decision), not leave rank 1 waiting in the query all-gather.  Clean data on rank 1: the search simply runs."""
+    res = _run(_precision_released_worker, 2, hot_rank)
+    assert len(res) == 2
+    if hot_rank >= 0:
+        assert all(r[1] is not None and "released" in r[1] and "every rank" in r[1] for r in res), res
+    else:
+        assert all(r[1] is None and r[2] == "plain" for r in res), res
+
+
 def test_st_encode_device_and_num_proc_are_honoured_or_refused():
     """SentenceTransformer.encode(device=..., num_proc=...) (SentenceTransformer.py:110-127,180-203): the model's own device and a
     single process are accepted, anything else is refused loudly instead of silently ignored (VERDICT r04 missing-4)."""

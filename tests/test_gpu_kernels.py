@@ -77,6 +77,26 @@ def test_ref_test_util_cos_sim_vs_sklearn(ctx):
     assert np.abs(cosine_similarity(a, b) - util.pytorch_cos_sim(a, b).numpy()).max() < 1e-3
 
 
+def test_ref_test_util_pairwise_scores(ctx):
+    """sentence-transformers/tests/test_util.py:69-76 (pairwise_cos_sim / pairwise_dot_score vs sklearn's paired distances) and the
+    reference outputs of scoring.npz, through sgpt_pairwise_scores."""
+    from sklearn.metrics.pairwise import paired_cosine_distances
+    from sgpt_amd import util
+    rng = np.random.default_rng(3)
+    a, b = rng.standard_normal((50, 100)), rng.standard_normal((50, 100))
+    assert np.allclose(1 - paired_cosine_distances(a, b), util.pairwise_cos_sim(a, b).numpy(), atol=1e-6)
+    assert np.allclose((a * b).sum(-1), util.pairwise_dot_score(a, b).numpy(), atol=1e-4)
+    fx = np.load(f"{GOLDEN}/scoring.npz")
+    assert maxabs(util.pairwise_cos_sim(fx["a"][:37], fx["b"]).numpy(), fx["pcs"]) < 1e-6
+    at, bt = torch.from_numpy(fx["a"][:37]).cuda(), torch.from_numpy(fx["b"]).cuda()
+    out = util.pairwise_dot_score(at, bt)
+    assert out.is_cuda and out.shape == (37,) and maxabs(out.cpu().numpy(), (fx["a"][:37] * fx["b"]).sum(-1)) < 1e-4
+    z = torch.zeros(3, 768)
+    assert torch.equal(util.pairwise_cos_sim(z, z), torch.zeros(3))            # zero rows: x / max(|x|, 1e-12) = 0, no NaN
+    with pytest.raises(ValueError):
+        util.pairwise_cos_sim(torch.zeros(3, 8), torch.zeros(4, 8))
+
+
 def test_ref_test_util_normalize(ctx):
     """tests/test_util.py:9-18."""
     from sgpt_amd import util
@@ -181,6 +201,36 @@ def test_topk_merge_and_exclude(ctx):
         order = np.argsort(-val[r][ok], kind="stable")[:11]
         assert np.array_equal(ov[r], val[r][ok][order])
         assert np.array_equal(oi[r], idx[r][ok][order])
+
+
+def test_topk_merge_duplicate_pairs_and_nan_same_order_on_both_short_row_paths(ctx):
+    """the register-key rounds of the short-row merge (indices < 2^32) and the comparator rounds (one index >= 2^32 in
+    the row) rank the same lists the same way -- repeated (score, id) pairs are each emitted (a caller's lists may repeat an id),
+    a negative id is an empty slot, a positive NaN ranks above +inf (torch.topk's convention), -0.0 ties with +0.0 on the id."""
+    rng = np.random.default_rng(11)
+    nq, m, k = 4, 60, 16
+    val = rng.standard_normal((nq, m)).astype(np.float32)
+    idx = np.stack([rng.permutation(500)[:m] for _ in range(nq)]).astype(np.int64)
+    val[0, 7] = val[0, 3] = 9.0; idx[0, 7] = idx[0, 3] = 77             # the same (score, id) pair twice, at the top
+    val[1, 10] = val[1, 20] = val[1, 30] = float(val[1].max()) + 1.0; idx[1, [10, 20, 30]] = [5, 5, 4]   # a triple tie, one id repeated
+    val[2, 2] = np.nan; val[2, 9] = np.inf                              # NaN above +inf
+    val[3, 4] = -0.0; val[3, 5] = 0.0; idx[3, 4], idx[3, 5] = 9, 8; val[3, 6:] = -np.abs(val[3, 6:]) - 1.0; val[3, :4] = -5.0
+    idx[:, -3:] = -1                                                    # empty slots
+    got = {}
+    for tag, big in (("keys", False), ("comparator", True)):
+        v, i = val.copy(), idx.copy()
+        if big:
+            v = np.concatenate([v, np.full((nq, 1), -1e30, np.float32)], axis=1)       # one far-away index: the whole row leaves the key path
+            i = np.concatenate([i, np.full((nq, 1), (1 << 33) + 5, np.int64)], axis=1)
+        ov, oi = ctx.topk_merge(dev(v), dev(i, torch.int64), k)
+        got[tag] = (ov.cpu().numpy(), oi.cpu().numpy())
+    assert np.array_equal(got["keys"][1], got["comparator"][1])
+    assert np.array_equal(got["keys"][0], got["comparator"][0], equal_nan=True)
+    ov, oi = got["keys"]
+    assert oi[0, :2].tolist() == [77, 77] and ov[0, :2].tolist() == [9.0, 9.0]
+    assert oi[1, :3].tolist() == [4, 5, 5]
+    assert np.isnan(ov[2, 0]) and oi[2, 0] == idx[2, 2] and ov[2, 1] == np.inf
+    assert oi[3, :2].tolist() == [8, 9] and (oi >= 0).all()
 
 
 # ---------------------------------------------------------------- fused score + top-k -----

@@ -265,14 +265,23 @@ def test_round_aware_call_budgets():
         assert b == m.call_budgets(int(total), 256)
         eq = [-(-(-(-int(total) // len(b))) // 256) * 256] * len(b) if len(b) > 1 else b
         assert rounds(b) <= rounds(eq) * 1.0001 or len(b) == 1, (total, b, rounds(b), rounds(eq))
-    assert [x // 256 for x in m.call_budgets(298000, 256)] == [483, 341, 341]       # the bench's variable-length step: equal thirds ran 4.55 rounds per N = 768 launch
-    lens = rng.integers(16, 129, size=4096).astype(np.int64)
+    # the bench's variable-length step (equal thirds ran 4.55 rounds per N = 768 launch); the call that is not a round boundary is last
+    assert [x // 256 for x in m.call_budgets(298000, 256)] == [341, 341, 483]
     m.round_aware_calls = True
-    plan = m.plan_batches(lens)
-    assert sorted(np.concatenate(plan).tolist()) == list(range(4096))
-    rows = [int(((lens[p] + 1) // 2 * 2).sum()) for p in plan]
-    bud = m.call_budgets(int(((lens + 1) // 2 * 2).sum()), 256)
-    assert len(plan) == len(bud) and all(r <= b_ for r, b_ in zip(rows, bud)) and all(b_ - r < 130 for r, b_ in zip(rows[:-1], bud))
+    # a call is cut at the last whole sequence inside its budget; the plan is re-taken over the rest at every cut, so
+    # the leftovers never end in a tiny extra call (4096 documents of U{16..128} used to end in an 80-row fourth call)
+    m._num_cus = lambda: 256
+    for n_docs, lo, hi in [(4096, 16, 129)] * 6 + [(8192, 16, 129), (4096, 100, 513), (20000, 1, 65), (1500, 300, 1025), (4096, 128, 129)]:
+        lens = rng.integers(lo, hi, size=n_docs).astype(np.int64)
+        plan = m.plan_batches(lens)
+        assert sorted(np.concatenate(plan).tolist()) == list(range(n_docs))
+        rows = [int(((lens[p] + 1) // 2 * 2).sum()) for p in plan]
+        bud = m.call_budgets(int(((lens + 1) // 2 * 2).sum()), 256)
+        assert len(bud) <= len(plan) <= len(bud) + 1 and max(rows) <= m.max_tokens_per_call, (rows, bud)
+        assert min(rows) >= 0.4 * max(rows), (rows, bud)
+        good = {341, 426, 512, 256, 170, 85}
+        # all but the last call end on (or at most one sequence short of) a round boundary of the N = d launches
+        assert all(any(0 <= g - -(-r // 256) <= hi // 256 + 1 for g in good) for r in rows[:-1]), rows
 
 
 def test_native_result_assembly_equals_the_python_construction():
