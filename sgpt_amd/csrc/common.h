@@ -279,7 +279,7 @@ void launch_gemm(int dtype, int epi, int out_dtype, const GemmArgs& a, hipStream
 // qgemm.hip: the query-sized projections (at most QGEMM_MAX_ROWS token rows, M % 32 == 0, K % 128 == 0): LDS-DMA ring with the
 // whole reach in flight, optional LayerNorm prologue (x != null: A = LayerNorm(x) * ln_mul rounded to the operand format, K = d).
 // Same k-ascending MFMA chain and epilogue arithmetic as the other GEMM kernels: identical bits.
-constexpr int QGEMM_MAX_ROWS = 512;
+constexpr int QGEMM_MAX_ROWS = 4096;
 struct QGemmArgs {
     GemmArgs g;
     const float* x;        // LayerNorm prologue: fp32 [M][K] residual stream (g.A unused), or null
