@@ -475,7 +475,8 @@ sgpt_status sgpt_prof_read(sgpt_ctx* ctx, int64_t* launches, double* ms, double*
  *   produces identical bits.  Returns the previous setting.
  * sgpt_ctx_set_tile_policy: 0 (default) = problems with less than half a wave of 256x256 tiles take the 128x128 / 64x64
  *   register-staged kernel; 1 = keep the 256x256 LDS-DMA kernel wherever the shape allows (kernel-level tests of
- *   single-tile shapes; identical bits either way).  Returns the previous policy. */
+ *   single-tile shapes; identical bits either way); 2 = layouts small enough for the query- / mid-sized kernels (csrc/qgemm.hip)
+ *   keep the small-tile register-staged kernels of the bulk path (same-box A/Bs, tests; identical bits).  Returns the previous policy. */
  /* sgpt_ctx_set_gemm_cu_cap: n > 0 = the persistent 256x256 projection kernel launches at most n workgroups (rounded down to
  *   a multiple of 8; 0 = one per CU, the default) -- for two contexts that run their calls half a block out of phase on two
  *   streams, so that one pipeline's LayerNorm / attention / embed kernels find free CUs while the other is in its k-loops

@@ -534,7 +534,7 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
     // pass riding on the forward.  Every projection takes the LDS-DMA ring kernel; at d <= 1024 the two LayerNorms of a
     // sequential block (GPT-Neo, BLOOM) run inside the prologues of the projections they feed: five launches per block instead
     // of seven.  Same arithmetic per element as the bulk path (identical bits); sgpt_ctx_set_tile_policy(1) keeps the bulk kernels.
-    const bool qpath = bf && !fp8 && !split && !(m->probing && m->crest_dev) && !m->calibrating && !c->force256 && T <= QGEMM_MAX_ROWS &&
+    const bool qpath = bf && !fp8 && !split && !(m->probing && m->crest_dev) && !m->calibrating && !c->force256 && !c->no_qpath && T <= QGEMM_MAX_ROWS &&
                        qgemm_shape_ok(T, 3 * dm, dm, EPI_QKV, 2 * dm) && qgemm_shape_ok(T, dm, dm, EPI_BIAS_RESID, 0) &&
                        qgemm_shape_ok(T, ffn, dm, EPI_BIAS_GELU, 0) && qgemm_shape_ok(T, dm, ffn, EPI_BIAS_RESID, 0);
     const bool qln = qpath && !gptj && qgemm_ln_ok(T, 3 * dm, dm, EPI_QKV, 2 * dm) && qgemm_ln_ok(T, ffn, dm, EPI_BIAS_GELU, 0);
@@ -1457,8 +1457,9 @@ int32_t sgpt_ctx_set_gemm_cu_cap(sgpt_ctx* c, int32_t n) {
 }
 int32_t sgpt_ctx_set_tile_policy(sgpt_ctx* c, int32_t policy) {
     if (!c) return 0;
-    const int old = c->force256;
+    const int old = c->force256 ? 1 : c->no_qpath ? 2 : 0;
     c->force256 = policy == 1 ? 1 : 0;
+    c->no_qpath = policy == 2 ? 1 : 0;
     return old;
 }
 #ifdef SGPT_EXPERIMENTS

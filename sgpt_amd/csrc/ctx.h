@@ -22,6 +22,7 @@ struct sgpt_ctx {
     int* range_flag = nullptr;                      // device int: an f16 activation left the representable range (ctx-level ops: sgpt_linear*)
     int kgroups = 1;                                // low-latency mode: 2 = k-groups for query-sized launches (sgpt_ctx_set_low_latency)
     int force256 = 0;                               // tile policy: 1 = 256x256 tiles even for small problems (sgpt_ctx_set_tile_policy)
+    int no_qpath = 0;                               // tile policy 2: query- / mid-sized layouts keep the bulk path's small-tile kernels (A/B, tests)
     int cu_cap = 0;                                 // persistent 256x256 GEMM: workgroups per launch at most (0 = one per CU; sgpt_ctx_set_gemm_cu_cap)
     // GEMM profiling (bench.py roofline)
     bool prof = false;

@@ -427,10 +427,13 @@ inline bool q_plan_ln(int M, int N, int d, int epi, int n_split, QLnPlan* out) {
         const int mt = (M + bm - 1) / bm, nt = N / bn;
         int gq = (int)(((long)mt * nt + ncu - 1) / ncu);
         gq = gq < 1 ? 1 : gq;
+        while ((long)mt * ((nt + gq - 1) / gq) > ncu) ++gq;      // ONE round of the chip (44 x 6 = 264 workgroups ran two)
         const long lds = (long)nk * bm * 256 + 2l * bn * 256 + (long)gq * bn * 4;
         if (lds > 160 * 1024) continue;
-        // bytes per workgroup: its rows of x (fp32) + the weight rows of its column tiles
-        const long cost = (long)bm * 2 + (long)gq * bn;
+        // per workgroup: bytes (its rows of x, fp32, + the weight rows of its column tiles, ~60 GB/s per CU) and the serial chain
+        // (one barrier-locked stage per 128 k-elements and column tile, ~0.2 us; a second LayerNorm batch at 64 rows ~1 us), in ns
+        const long bytes = (long)bm * d * 4 + (long)gq * bn * d * 2;
+        const long cost = bytes / 60 + (long)gq * nk * 200 + (bm > 32 ? 1000 : 0);
         if (best.bm == 0 || cost < best_cost) { best = QLnPlan{bm, bn, gq}; best_cost = cost; }
     }
     if (best.bm == 0) return false;

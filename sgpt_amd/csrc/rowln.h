@@ -47,10 +47,13 @@ struct RowLN {
         v[i].z = (v[i].z - mean) * rstd * gg.z + bb.z;
         v[i].w = (v[i].w - mean) * rstd * gg.w + bb.w;
     }
+    // FAST: the statistics' butterflies on the VALU (same partners, same order, same bits) -- for launches whose few waves wait on
+    // the reductions themselves (ln_f + pool of a handful of query sequences)
+    template <bool FAST = false>
     __device__ __forceinline__ void normalize(const float* __restrict__ g, const float* __restrict__ b, int d,
                                               float eps, int lane) {
         float mean, rstd;
-        stats<false>(d, lane, mean, rstd, eps);
+        stats<FAST>(d, lane, mean, rstd, eps);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;

@@ -173,10 +173,11 @@ class Context:
         contexts pipelined on two streams (include/sgpt_hip.h::sgpt_ctx_set_gemm_cu_cap).  Returns the previous value."""
         return int(self.lib.sgpt_ctx_set_gemm_cu_cap(self.handle, int(n)))
 
-    def set_tile_policy(self, force_256: bool) -> bool:
-        """Per context: keep the 256x256 LDS-DMA GEMM tiles even where the small-tile rule would apply (kernel tests of
-        single-tile shapes; identical bits either way).  Returns the previous policy."""
-        return bool(self.lib.sgpt_ctx_set_tile_policy(self.handle, 1 if force_256 else 0))
+    def set_tile_policy(self, force_256) -> int:
+        """Per context: True / 1 = keep the 256x256 LDS-DMA GEMM tiles even where the small-tile rule would apply (kernel tests of
+        single-tile shapes); 2 = no query- / mid-sized kernels (csrc/qgemm.hip): the bulk path's small-tile kernels on every layout
+        (A/Bs); identical bits whatever the policy.  Returns the previous policy (0 | 1 | 2)."""
+        return int(self.lib.sgpt_ctx_set_tile_policy(self.handle, int(force_256)))
 
     def reserve(self, encode_bytes: int = 0, score_bytes: int = 0) -> None:
         self._chk(self.lib.sgpt_ctx_reserve(self.handle, encode_bytes, score_bytes), "sgpt_ctx_reserve")

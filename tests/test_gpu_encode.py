@@ -418,8 +418,8 @@ def test_query_sized_and_bulk_batches_give_identical_bits(dtype):
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_query_path_row_counts_agree_with_the_bulk_kernels(dtype):
-    """Layouts of at most 512 token rows take csrc/qgemm.hip (32-row tiles, LayerNorm inside the QKV / fc1 projections, five
-    launches per block); `set_tile_policy(True)` keeps the bulk kernels on the same layout.  One query
+    """Query- and mid-sized layouts take csrc/qgemm.hip (register-staged deep-prefetch tiles of 32 .. 128 rows, LayerNorm inside
+    the QKV / fc1 projections: five launches per block); `set_tile_policy(1 | 2)` keeps the bulk path's kernels on the same layout.  One query
     (`SentenceTransformer.encode("one query")`, SentenceTransformer.py:143-146), USEB's 21-sentence batches
     (useb/useb/useb/evaluators/askubuntu.py:144-148), layouts on both sides of the 512-row limit: identical bits."""
     from sgpt_amd.model import QUERY_ROWS, pad_rows
@@ -428,17 +428,19 @@ def test_query_path_row_counts_agree_with_the_bulk_kernels(dtype):
     old_kg = m.ctx.set_low_latency(False)
     try:
         rng = np.random.default_rng(5)
-        for lens in ([7], [32], [1, 1, 1], list(rng.integers(4, 33, size=21)), [64] * 8, [100, 28, 128, 128, 127, 1], [128] * 4 + [2]):
+        for lens in ([7], [32], [1, 1, 1], list(rng.integers(4, 33, size=21)), [64] * 8, [100, 28, 128, 128, 127, 1], [128] * 4 + [2],
+                     list(rng.integers(4, 33, size=70)), [128] * 15 + [33], list(rng.integers(8, 129, size=55))):      # mid-sized: 64- / 128-row tiles
             seqs = [rng.integers(0, 50256, size=int(n)).tolist() for n in lens]
             pb = m.pack(seqs)
             assert pb.T_pad == pad_rows(pb.T_pad) and pb.T_pad % (32 if pb.T_pad <= QUERY_ROWS else 256) == 0
             got = m.encode_packed(pb, normalize=True).cpu().numpy()
-            old = m.ctx.set_tile_policy(True)
-            try:
-                want = m.encode_packed(pb, normalize=True).cpu().numpy()
-            finally:
-                m.ctx.set_tile_policy(old)
-            assert np.isfinite(got).all() and np.array_equal(got, want), (lens, pb.T_pad)
+            for policy in (1, 2):            # 256x256 LDS-DMA kernels | the bulk path's small-tile register-staged kernels
+                old = m.ctx.set_tile_policy(policy)
+                try:
+                    want = m.encode_packed(pb, normalize=True).cpu().numpy()
+                finally:
+                    m.ctx.set_tile_policy(old)
+                assert np.isfinite(got).all() and np.array_equal(got, want), (lens, pb.T_pad, policy)
     finally:
         m.ctx.set_low_latency(old_kg)
 
