@@ -113,7 +113,8 @@ __global__ __launch_bounds__(QNT) void qgemm_kernel(const QGemmArgs q) {
 
     // LayerNorm operands first (so that the statistics wait for these loads only), then the first D weight stages
     constexpr int RPW = BM / QNW;                    // LN_A: rows per wave
-    constexpr int RB = RPW > 4 ? 4 : RPW;            //       rows per batch (registers: RB NV float4 in flight)
+    constexpr int RB = RPW > 4 ? 4 : RPW;            //       rows per batch (registers: RB NV float4 in flight; all 8 rows of a 64-row tile at once
+                                                     //       was measured: 12.3 us against 12.0 -- the rows' arithmetic is the cost, not the second round trip)
     float4 gg[LN_A ? NV : 1], bb[LN_A ? NV : 1];
     RowLN<NV, false> rl[LN_A ? RB : 1];
     auto ln_rows_load = [&](int batch) __attribute__((always_inline)) {
@@ -358,6 +359,8 @@ inline int q_ncu() {
 // ---- tile choice (plain kernels): one launch = rounds x (BM + BN) K 2 bytes per workgroup; the fewest wins, ties to the larger tile ----
 struct QTile { int bm, bn, kd; };
 constexpr QTile Q_TILES[] = {{32, 16, 256}, {32, 32, 128}, {32, 64, 128}, {64, 32, 128}, {64, 64, 128}, {128, 64, 128}, {128, 128, 128}};
+// (measured and dropped: 512- / 256-element stages for the 32-row tiles -- fc2 at 32 rows 8.5 us against 8.1: the serial chain of a
+//  tile is its dependent MFMAs and LDS round trips, not its barriers; profiles/r06_qgemm_tile_sweep.txt)
 constexpr int Q_NTILES = sizeof(Q_TILES) / sizeof(Q_TILES[0]);
 
 // depth class of a tile at this K: 6 -> SIX kernels, 4 -> the others, 0 -> not served
@@ -371,11 +374,12 @@ inline int q_class(const QTile& tl, bool ln_a, int K) {
     return ok4 ? 4 : 0;
 }
 
-inline int q_pick_plain(int M, int N, int K, int epi, int n_split) {
+inline int q_pick_plain(int M, int N, int K, int epi, int n_split, int force = 0) {
     const int ncu = q_ncu();
     int best = -1; long best_cost = 0;
     for (int i = 0; i < Q_NTILES; ++i) {
         const QTile& tl = Q_TILES[i];
+        if (force > 0 && i != force - 1) continue;
         if (N % tl.bn || !q_class(tl, false, K)) continue;
         if (epi == EPI_QKV && (n_split % tl.bn || tl.bn < 16)) continue;
         if (tl.bm > 32 && M <= 32) continue;
@@ -396,7 +400,7 @@ bool qrun_plain(const QGemmArgs& a, int cls, hipStream_t s) {
 
 template <typename T, int EPI, typename OutT>
 bool qdispatch_plain(const QGemmArgs& a, int epi, hipStream_t s) {
-    const int i = q_pick_plain(a.g.M, a.g.N, a.g.K, epi, a.g.n_split);
+    const int i = q_pick_plain(a.g.M, a.g.N, a.g.K, epi, a.g.n_split, a.tile);
     if (i < 0) return false;
     const int cls = q_class(Q_TILES[i], false, a.g.K);
     switch (i) {
@@ -413,14 +417,16 @@ bool qdispatch_plain(const QGemmArgs& a, int epi, hipStream_t s) {
 
 // ---- LayerNorm-prologue kernels: (BM, BN) in {(32, 32), (32, 64), (64, 64)}, KD = 128; a workgroup walks `group` column tiles ----
 struct QLnPlan { int bm, bn, group; };
-inline bool q_plan_ln(int M, int N, int d, int epi, int n_split, QLnPlan* out) {
+inline bool q_plan_ln(int M, int N, int d, int epi, int n_split, QLnPlan* out, int force = 0) {
     if (d % 128 || N % 32) return false;
     const int nk = d / 128;
     if (nk % 6 != 0 && nk % 4 != 0) return false;
     const int ncu = q_ncu();
     QLnPlan best{0, 0, 0}; long best_cost = 0;
     const int cands[3][2] = {{32, 32}, {32, 64}, {64, 64}};
-    for (const auto& c : cands) {
+    for (int ci = 0; ci < 3; ++ci) {
+        const int* c = cands[ci];
+        if (force > 0 && ci != force - 1) continue;
         const int bm = c[0], bn = c[1];
         if (N % bn || (epi == EPI_QKV && n_split % bn)) continue;
         if (bm > 32 && M <= 32) continue;
@@ -430,10 +436,10 @@ inline bool q_plan_ln(int M, int N, int d, int epi, int n_split, QLnPlan* out) {
         while ((long)mt * ((nt + gq - 1) / gq) > ncu) ++gq;      // ONE round of the chip (44 x 6 = 264 workgroups ran two)
         const long lds = (long)nk * bm * 256 + 2l * bn * 256 + (long)gq * bn * 4;
         if (lds > 160 * 1024) continue;
-        // per workgroup: bytes (its rows of x, fp32, + the weight rows of its column tiles, ~60 GB/s per CU) and the serial chain
-        // (one barrier-locked stage per 128 k-elements and column tile, ~0.2 us; a second LayerNorm batch at 64 rows ~1 us), in ns
-        const long bytes = (long)bm * d * 4 + (long)gq * bn * d * 2;
-        const long cost = bytes / 60 + (long)gq * nk * 200 + (bm > 32 ? 1000 : 0);
+        // launch time in ns, fitted to the tile sweep of scripts/micro/qgemm_probe.hip (profiles/r06_qgemm_tile_sweep.txt, d = 768):
+        // a fixed part (LayerNorm of the tile's rows + pipeline fill: 6.2 us at 32 rows, 9.4 at 64 -- two batches of rows) + the
+        // serial chain of barrier-locked stages, one per 128 k-elements and column tile (0.25 / 0.35 / 0.44 us by tile)
+        const long cost = (bm == 32 ? 6200 : 9400) + (long)gq * nk * (bn == 32 ? 250 : bm == 32 ? 350 : 440);
         if (best.bm == 0 || cost < best_cost) { best = QLnPlan{bm, bn, gq}; best_cost = cost; }
     }
     if (best.bm == 0) return false;
@@ -456,7 +462,7 @@ bool qgemm16(int epi, int out_dtype, const QGemmArgs& a, hipStream_t s) {
     if (a.x != nullptr) {           // LayerNorm prologue (K = d)
         const int d = a.g.K;
         QLnPlan pl;
-        if (!o16 || !q_plan_ln(a.g.M, a.g.N, d, epi, a.g.n_split, &pl)) return false;
+        if (!o16 || !q_plan_ln(a.g.M, a.g.N, d, epi, a.g.n_split, &pl, a.tile)) return false;
         const bool six = (d / 128) % 6 == 0;
 #define QLN(NVV)                                                                                                          \
         do {                                                                                                               \
