@@ -150,6 +150,9 @@ def hf_cpu_baseline(ocfg, ow, sample, repeats=3, mask=None, hf=None, slice_note=
         times.append(time.perf_counter() - t)
     dt = float(np.median(times))
     return emb.numpy(), {"value": round(len(sample) / dt, 2), "unit": "sentences/s", "cores": threads, "kind": "reference",
+                         "threads_note": "one torch thread per physical core, capped at 64: the 128-sentence sample is [16384, 768] x [768, 768..3072] "
+                                         "matmuls + 12-head attention at S = 128 -- on a 128-core host the second 64 threads add synchronisation, not rate "
+                                         "(bench.py::cpu_threads)",
                          "sample": f"{len(sample)} sentences x {ids.shape[1]} tokens{slice_note}: HF GPTNeoModel fp32 eager + raw weighted-mean "
                                    f"pooling + normalise (the reference's CPU path), torch CPU, median of {repeats} passes "
                                    f"({', '.join(f'{x:.1f}' for x in times)} s)"}, hf
@@ -203,6 +206,7 @@ def main():
     ap.add_argument("--no-varlen", action="store_true", help="skip the lengths ~U{16..128} leg")
     ap.add_argument("--equal-calls", action="store_true", help="A/B: round 4's equal token budgets per sgpt_encode call instead of the round-aware ones (variable-length leg)")
     ap.add_argument("--no-modes", action="store_true", help="skip the precision-mode leg (f16x3 and exact-fp32 encode rates beside the headline)")
+    ap.add_argument("--no-other-models", action="store_true", help="skip the short runs of BASELINE configs[2..4]'s shapes (SGPT-1.3B, 5.8B bf16, bloom-7b1 fp8 MFMA)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -312,6 +316,21 @@ def main():
     sentences = world * args.steps * args.chunk
     sent_per_s = sentences / dt
 
+    # ---- A/B of the measurement itself: the timed region above carries two hipEventRecord per projection launch
+    # (the live GEMM durations of `roofline`); the same steps again with the recording off ----
+    event_ab = None
+    if world == 1:
+        run2 = run
+        sync()
+        t1 = time.perf_counter()
+        for i in range(args.warmup, n_steps):
+            run2 = step(i, q, run2)
+        sync()
+        dt2 = time.perf_counter() - t1
+        event_ab = {"sentences_per_s_without_event_records": round(args.steps * args.chunk / dt2, 1), "ms_per_step_without": round(dt2 / args.steps * 1e3, 3),
+                    "event_records_in_timed_region": 2 * int(n_launch),
+                    "cost_of_recording": f"{(dt / dt2 - 1) * 100:+.2f} % on the step time (same process, second pass over the same steps)"}
+
     # ---- the same steps with the host side of the boundary inside the clock: every sgpt_encode call first packs its
     # token ids from host memory (numpy [call, S] int64 -> the int32 arena in pinned memory) and copies them over PCIe
     # (one non-blocking H2D per call, two pinned arenas alternating: the copy of call i+1 overlaps the encode of call i).
@@ -385,7 +404,7 @@ def main():
         return args.nq * reps / (time.perf_counter() - t)
 
     qps_job = time_search(corpus[args.warmup * args.chunk:])
-    qps_1m = qps_1m_enc = projected = k1001 = qps_1m_fp32 = None
+    qps_1m = qps_1m_enc = projected = k1001 = qps_1m_fp32 = scorer_breakdown = query_latency = None
     qps_enc_by_nq, qps_enc_ll = {}, {}
     if not args.no_1m:
         n1m = 1_000_000 // world                           # 1M-doc corpus sharded over the ranks
@@ -398,6 +417,24 @@ def main():
             big[s0:e0] = torch.nn.functional.normalize(noisy, dim=1).to(score_dt)
         del blk
         qps_1m = time_search(big, reps=3)
+        # where a 1 M pass goes (a box-to-box spread of the scorer cannot be read off one number): its GEMM launches
+        # (sample + filtered chunks; hipEvent pairs around each) against the whole enqueued pass
+        scorer_breakdown = None
+        if world == 1:
+            ctx.prof_read(reset=True); ctx.prof_enable(True)
+            sync()
+            t_ = time.perf_counter()
+            for _ in range(3):
+                search_once(big)
+            sync()
+            t_pass = (time.perf_counter() - t_) / 3
+            ctx.prof_enable(False)
+            nl_, gms_, gfl_ = ctx.prof_read(reset=True)
+            scorer_breakdown = {"ms_per_pass_with_event_records": round(t_pass * 1e3, 4), "gemm_launches_per_pass": nl_ // 3,
+                                "ms_in_gemm_launches": round(gms_ / 3, 4), "ms_select_merge_prologue_and_gaps": round(t_pass * 1e3 - gms_ / 3, 4),
+                                "algorithmic_tflop_per_pass": round(2.0 * args.nq * n1m * d / 1e12, 4),
+                                "tflops_of_the_gemm_launches": round(2.0 * args.nq * n1m * d / max(gms_ / 3, 1e-9) / 1e9, 1),
+                                "note": "launches = prologue-sampled threshold launch + filtered chunks + the predicated (no-op) fallback launches of every chunk"}
         # the same search with the query side included: token ids (host lists) -> pack -> one pinned async H2D ->
         # encode sharded over the ranks + one all-gather -> normalise -> search; nq = 16 / 128 / all
         def qps_incl_encode(nq_sub, reps=3):
@@ -516,6 +553,32 @@ def main():
         prev_ll = ctx.set_low_latency(True)
         qps_enc_ll = {n_: qps_incl_encode(n_) for n_ in (16, 128) if n_ <= args.nq}
         ctx.set_low_latency(prev_ll)
+        # ---- query-sized encodes on their own (round 6: csrc/qgemm.hip), next to the same layouts on the bulk path's small-tile
+        # kernels (sgpt_ctx_set_tile_policy(2): what rounds 1-5 ran) -- same box, same process, identical bits ----
+        if world == 1 and args.dtype in ("f16", "bf16"):
+            def enc_ms(pb_, reps=40):
+                for _ in range(5):
+                    model.encode_packed(pb_, normalize=True)
+                sync()
+                t_ = time.perf_counter()
+                for _ in range(reps):
+                    model.encode_packed(pb_, normalize=True)
+                sync()
+                return (time.perf_counter() - t_) / reps * 1e3
+            query_latency = {"unit": "ms per sgpt_encode call (packed ids resident), weighted-mean pool + normalise", "by_nq": {}}
+            for n_ in (1, 16, 125):
+                if n_ > args.nq:
+                    continue
+                pb_ = model.pack(queries[:n_])
+                new_ms = enc_ms(pb_)
+                prev_pol = ctx.set_tile_policy(2)
+                try:
+                    old_ms = enc_ms(pb_)
+                    same = bool(torch.equal(model.encode_packed(pb_, normalize=True), (ctx.set_tile_policy(0), model.encode_packed(pb_, normalize=True))[1]))
+                finally:
+                    ctx.set_tile_policy(prev_pol)
+                query_latency["by_nq"][str(n_)] = {"token_rows": int(pb_.T_pad), "ms": round(new_ms, 4), "ms_bulk_path_small_tiles": round(old_ms, 4),
+                                                   "identical_bits": same}
         if dist_on:
             keys, keys_ll = sorted(qps_enc_by_nq), sorted(qps_enc_ll)
             tq = torch.tensor([qps_1m] + [qps_enc_by_nq[k_] for k_ in keys] + [qps_enc_ll[k_] for k_ in keys_ll],
@@ -612,7 +675,7 @@ def main():
     # FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 corrections applied there); null if not collected
     traffic, traffic_source = None, None
     mfma_busy = eff_clock = None
-    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if args.dtype in ("bf16", "f16") and args.call * S == 131072 and os.path.exists(tpath):
             with open(tpath) as f:
@@ -727,6 +790,28 @@ def main():
         cpu["parity"] = parity
         cpu["cpu"] = cpu_info()
 
+    # ---- BASELINE configs[2..4]'s shapes, driver-timed (the sizes where >= 0.50 of the MFMA roofline IS reached
+    # had builder-run numbers only): three short runs of this script (3 steps of 1024 documents, encode + pool + score) in
+    # processes of their own, after this one has released the GPU memory it no longer needs ----
+    other_configs = None
+    if world == 1 and args.model == "125m" and not args.no_other_models and not args.no_1m:
+        del corpus, emb32
+        torch.cuda.empty_cache()
+        other_configs = {"note": "python bench.py --model M --dtype D --steps 3 --warmup 1 --chunk 1024 (1024-document steps, seq_len 128, same step "
+                                 "definition); frac = end-to-end fraction of the 16-bit dense MFMA peak (fp8mfma: of that SAME 2.5 PFLOP/s peak); "
+                                 "parity of each mode at its shape: profiles/r05_models.jsonl, tests/test_gpu_parity_large.py"}
+        for tag, mdl, dt_ in (("configs[2] SGPT-1.3B f16 (default precise_qk)", "1.3b", "f16"), ("configs[2] SGPT-1.3B bf16", "1.3b", "bf16"),
+                              ("configs[3] SGPT-5.8B bf16", "5.8b", "bf16"), ("configs[4] bloom-7b1 fp8 MFMA", "bloom-7b1", "fp8mfma")):
+            try:
+                r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--model", mdl, "--dtype", dt_, "--steps", "3", "--warmup", "1", "--chunk", "1024",
+                                     "--no-cpu-baseline", "--no-1m", "--no-varlen", "--no-modes", "--no-other-models"], capture_output=True, text=True, timeout=240)
+                ln_ = [x for x in r_.stdout.splitlines() if x.startswith("{")]
+                b_ = json.loads(ln_[-1])
+                other_configs[tag] = {"sentences_per_s": b_["value"], "ms_per_step": b_["ms_per_step"], "gemm_tflops_live": b_["roofline"]["achieved"],
+                                      "end_to_end_frac_of_mfma_roofline": b_["roofline"]["end_to_end_frac_of_mfma_roofline"]}
+            except Exception as e:  # noqa: BLE001
+                other_configs[tag] = {"error": str(e)[:200]}
+
     out = {"metric": "encoded sentences/sec (SGPT-125M, seq_len 128, encode + weighted-mean pool + cosine top-10 "
                      "chunk loop)",
            "value": round(sent_per_s, 1), "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
@@ -762,6 +847,8 @@ def main():
            "queries_per_sec_at_1M_corpus_incl_query_encode_low_latency_mode": {str(k_): round(v_, 1) for k_, v_ in qps_enc_ll.items()},
            "queries_per_sec_at_1M_corpus_k1001": k1001, "projected_8gpu": projected, "precision_modes": modes,
            "varlen": varlen, "shard_check": shard_check,
+           "query_encode_latency": query_latency, "scorer_breakdown_1M_pass": scorer_breakdown, "event_record_ab": event_ab,
+           "other_configs": other_configs,
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out))
     if dist_on:

@@ -443,6 +443,22 @@ sgpt_status sgpt_topk(sgpt_ctx* ctx, const float* scores, int32_t nq, int64_t n,
 sgpt_status sgpt_linear(sgpt_ctx* ctx, int32_t dtype, int32_t epi, int32_t out_dtype, const void* A, const void* W,
                         const float* bias, const float* resid, void* out, int32_t M, int32_t N, int32_t K, void* stream);
 
+/* The query- / mid-sized projection kernels of sgpt_encode, stand-alone (ABI v8; csrc/qgemm.hip: layouts of at most 4096 token rows --
+ * `SentenceTransformer.encode("one query")`, SentenceTransformer.py:143-146; USEB's 21-sentence batches,
+ * useb/useb/useb/evaluators/askubuntu.py:144-148), for kernel-level parity tests.  16-bit operands (dtype SGPT_BF16 | SGPT_F16),
+ * fp32 accumulation, W device [N, K] row-major.
+ *   A != NULL: A device [M, K] in `dtype`.
+ *   x != NULL: the LayerNorm prologue -- A = nn.LayerNorm(K, eps)(x) rounded to `dtype` (x device fp32 [M, K]: the residual stream;
+ *              HF:gpt_neo:317-319,385), computed by the projection itself; epi 7 and 1 only.
+ *   epi 0: out[M,N] = acc (+ bias if given)         epi 1: out[M,N] = gelu_new(acc + bias)        (out in `dtype`)
+ *   epi 2: out[M,N] = resid + acc + bias, fp32 (out may alias resid)
+ *   epi 7: the fused Q | K | V projection: columns [0, n_split) -> out[M, n_split] row-major, columns [n_split, N) -> out_vt[N - n_split, M]
+ *          (V^T, the attention kernel's P.V operand).
+ * Same bits as sgpt_linear (+ the LayerNorm kernel) on the same operands.  SGPT_ERR_INVALID if the shape is not served. */
+sgpt_status sgpt_linear_query(sgpt_ctx* ctx, int32_t dtype, int32_t epi, const void* A, const float* x, const float* ln_gamma,
+                              const float* ln_beta, float ln_eps, const void* W, const float* bias, const float* resid, void* out,
+                              void* out_vt, int32_t n_split, int32_t M, int32_t N, int32_t K, void* stream);
+
 /* The fp8-MFMA building blocks of SGPT_FP8M, stand-alone (kernel-level tests, custom blocks).
  * sgpt_layernorm_fp8: nn.LayerNorm(x)[T,d] -> e4m3fn codes + one power-of-two scale per row (true value = code * scale).
  * sgpt_linear_fp8:    acc = (A8 . W8^T)[m][n] * a_scale[m] * a_scalar * w_scale[n]   (A8 [M,K], W8 [N,K] e4m3fn codes, fp32

@@ -77,6 +77,8 @@ SIGNATURES = {
                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgpt_linear": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sgpt_linear_query": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sgpt_model_calibrate_begin": (C.c_int, [C.c_void_p]),
     "sgpt_model_calibrate_end": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "sgpt_model_set_act_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

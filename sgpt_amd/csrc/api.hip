@@ -1689,6 +1689,33 @@ sgpt_status sgpt_linear(sgpt_ctx* c, int32_t dtype, int32_t epi, int32_t out_dty
     return SGPT_OK;
 }
 
+sgpt_status sgpt_linear_query(sgpt_ctx* c, int32_t dtype, int32_t epi, const void* A, const float* x, const float* ln_gamma,
+                              const float* ln_beta, float ln_eps, const void* W, const float* bias, const float* resid, void* out,
+                              void* out_vt, int32_t n_split, int32_t M, int32_t N, int32_t K, void* stream) {
+    if (!c || !W || !out || M <= 0 || N <= 0 || K <= 0 || (!A && !x)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_query: bad arguments");
+    if (dtype != SGPT_BF16 && dtype != SGPT_F16) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_query: 16-bit operands (SGPT_BF16 | SGPT_F16)");
+    if (epi != EPI_STORE && epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID && epi != EPI_QKV)
+        return fail(c, SGPT_ERR_INVALID, "sgpt_linear_query: epi must be 0 (store), 1 (bias+gelu), 2 (bias+residual) or 7 (q | k | V^T)");
+    if (x && (!ln_gamma || !ln_beta || (epi != EPI_QKV && epi != EPI_BIAS_GELU)))
+        return fail(c, SGPT_ERR_INVALID, "sgpt_linear_query: the LayerNorm prologue feeds epi 7 (QKV) and 1 (fc1 + GELU) and needs gamma / beta");
+    if ((epi == EPI_BIAS_GELU || epi == EPI_BIAS_RESID) && !bias) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_query: bias required");
+    if (epi == EPI_BIAS_RESID && !resid) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_query: residual required");
+    if (epi == EPI_QKV && (!out_vt || n_split <= 0 || n_split >= N)) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_query: epi 7 needs out_vt and 0 < n_split < N");
+    HIPC(c, hipSetDevice(c->device));
+    QGemmArgs q{};
+    q.g.A = A; q.g.lda = K; q.g.W = W; q.g.ldw = K; q.g.M = M; q.g.m_valid = M; q.g.N = N; q.g.K = K; q.g.out = out;
+    q.g.ldo = epi == EPI_QKV ? n_split : N; q.g.out2 = out_vt; q.g.ldo2 = M; q.g.n_split = epi == EPI_QKV ? n_split : 0;
+    q.g.bias = bias; q.g.resid = resid;
+    const int out_dtype = epi == EPI_BIAS_RESID ? SGPT_F32 : dtype;
+    q.g.range_flag = out_dtype == SGPT_F16 ? c->range_flag : nullptr;
+    if (x) { q.x = x; q.ln_g = ln_gamma; q.ln_b = ln_beta; q.eps = ln_eps; q.g.A = nullptr; }
+    if (!qgemm(c, dtype, epi, out_dtype, q, (hipStream_t)stream))
+        return fail(c, SGPT_ERR_INVALID, "sgpt_linear_query: shape not served by the query-sized kernels (M % 32, M <= 4096; K / 128 a multiple of 4 or 6; "
+                                         "N % 16; LayerNorm prologue: K = 512 | 768 | 1024, N % 32)");
+    HIPC(c, hipGetLastError());
+    return SGPT_OK;
+}
+
 sgpt_status sgpt_linear_split(sgpt_ctx* c, int32_t dtype, int32_t epi, const void* A, const void* W, const float* bias, void* out,
                               int64_t ldo, int64_t lo_delta, int64_t hi2_delta, int32_t M, int32_t N, int32_t K, void* stream) {
     if (!c || !A || !W || !out || M <= 0 || N <= 0 || K <= 0 || lo_delta == 0) return fail(c, SGPT_ERR_INVALID, "sgpt_linear_split: bad arguments");

@@ -226,6 +226,26 @@ class Context:
                   "sgpt_linear")
         return out
 
+    def linear_query(self, w: torch.Tensor, a: Optional[torch.Tensor] = None, x: Optional[torch.Tensor] = None, ln=None,
+                     bias: Optional[torch.Tensor] = None, epi: str = "store", resid: Optional[torch.Tensor] = None, n_split: int = 0):
+        """The query- / mid-sized projection kernels stand-alone (include/sgpt_hip.h::sgpt_linear_query).  a: [M, K] 16-bit operand, or
+        x: fp32 [M, K] with ln = (gamma, beta, eps) -- the LayerNorm prologue.  epi 'store' | 'gelu' | 'resid' | 'qkv' (returns
+        (q|k [M, n_split], V^T [N - n_split, M]))."""
+        code = {"store": 0, "gelu": 1, "resid": 2, "qkv": 7}[epi]
+        N, K = w.shape
+        src = a if a is not None else x
+        M = src.shape[0]
+        odt = torch.float32 if epi == "resid" else w.dtype
+        out = torch.empty((M, n_split if epi == "qkv" else N), dtype=odt, device=self.device)
+        vt = torch.empty((N - n_split, M), dtype=odt, device=self.device) if epi == "qkv" else None
+        f32 = lambda t_: None if t_ is None else t_.to(device=self.device, dtype=torch.float32).contiguous()  # noqa: E731
+        g, b, eps = (f32(ln[0]), f32(ln[1]), float(ln[2])) if ln is not None else (None, None, 0.0)
+        b32, r32, x32 = f32(bias), f32(resid), f32(x)
+        self._chk(self.lib.sgpt_linear_query(self.handle, DT_CODE[w.dtype], code, _p(None if a is None else a.contiguous()), _p(x32), _p(g), _p(b), eps,
+                                             _p(w.contiguous()), _p(b32), _p(r32), _p(out), _p(vt), int(n_split), M, N, K,
+                                             _stream_ptr(self.device)), "sgpt_linear_query")
+        return (out, vt) if epi == "qkv" else out
+
     def linear_split(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: str = "store",
                      triple: bool = False) -> torch.Tensor:
         """The split store epilogues (include/sgpt_hip.h::sgpt_linear_split): epi 'store' | 'gelu' -> [M, 2 N] = [hi | lo], or

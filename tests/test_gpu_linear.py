@@ -174,3 +174,75 @@ def _k_group_checks(ctx, dt, M, N, K, a, w, bias, resid, acc, tol32, off):
             assert not torch.equal(x, ref), "the k-group path did not run (the test would be vacuous)"
         else:
             assert torch.equal(x, ref), "one group: the k-ascending sum, bit for bit"
+
+
+# ---------------------------------------------------------------- query- / mid-sized projections (csrc/qgemm.hip, round 6) -----
+QSHAPES = [(32, 768, 768), (32, 768, 3072), (96, 2304, 768), (352, 768, 3072), (512, 3072, 768), (1024, 768, 768), (2304, 768, 3072),
+           (2816, 2304, 768), (160, 1024, 1024), (64, 4096, 4096), (448, 2048, 8192)]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", QSHAPES)
+def test_query_projections_vs_torch_fp32_and_vs_the_bulk_kernels(ctx, dt, M, N, K):
+    """sgpt_linear_query (register-staged deep-prefetch tiles of 32 .. 128 rows) against the fp32 product of the same 16-bit
+    operands, every epilogue -- and bit for bit against sgpt_linear (the bulk path's kernels) on the same operands: every kernel
+    feeds an output element the k-ascending MFMA chain."""
+    a, w, bias, resid = operands(M, N, K, dt, seed=M + N + K + 1)
+    acc = a.float() @ w.float().T
+    scale = float(acc.abs().max())
+    tol32 = 1e-3 * math.sqrt(K / 64) * scale
+    tol16 = tol32 + ULP[dt] * scale
+    got = ctx.linear_query(w, a=a, bias=bias, epi="resid", resid=resid)
+    assert float((got - (resid + acc + bias)).abs().max()) < tol32 + 1e-6 * float((resid + acc + bias).abs().max())
+    assert torch.equal(got, ctx.linear(a, w, bias, "resid", resid))
+    got = ctx.linear_query(w, a=a, bias=bias, epi="gelu")
+    want = gelu_new(acc + bias)
+    assert float((got.float() - want).abs().max()) < tol16 + ULP[dt] * float(want.abs().max())
+    assert torch.equal(got, ctx.linear(a, w, bias, "gelu"))
+    got = ctx.linear_query(w, a=a, epi="store")
+    assert float((got.float() - acc).abs().max()) < tol16
+    assert torch.equal(got, ctx.linear(a, w, None, "store"))
+    if N % 96 == 0:                                                      # q | k | V^T in one launch (n_split = 2 N / 3)
+        ns = N // 3 * 2
+        qk, vt = ctx.linear_query(w, a=a, epi="qkv", n_split=ns)
+        assert float((qk.float() - acc[:, :ns]).abs().max()) < tol16 and float((vt.float() - acc[:, ns:].T).abs().max()) < tol16
+        assert torch.equal(qk, ctx.linear(a, w[:ns].contiguous(), None, "store"))
+        assert torch.equal(vt, ctx.linear(a, w[ns:].contiguous(), None, "store").T.contiguous())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,d", [(32, 768), (96, 768), (352, 768), (1024, 768), (2816, 768), (64, 1024), (640, 1024), (128, 512)])
+def test_query_projections_with_layernorm_prologue_vs_torch(ctx, dt, M, d):
+    """The LayerNorm prologue (LN1 -> QKV, LN2 -> fc1 + GELU inside the projection): against torch's fp32 LayerNorm rounded to the
+    operand format followed by the fp32 product.  The kernel's LayerNorm differs from torch's in the last fp32 bits, so a few
+    normalised values land on the other side of a 16-bit rounding boundary: tolerance = one operand ulp carried through the
+    product (sqrt(K) random-sign terms) on top of the accumulation-order noise."""
+    g = torch.Generator(device="cuda").manual_seed(M + d)
+    x = torch.randn((M, d), generator=g, device="cuda") * 3.0 + 0.5
+    gamma = 1.0 + 0.1 * torch.randn((d,), generator=g, device="cuda")
+    beta = 0.1 * torch.randn((d,), generator=g, device="cuda")
+    a = torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5).to(HALF[dt])
+    for epi, N in (("qkv", 3 * d), ("gelu", 4 * d)):
+        w = (torch.randn((N, d), generator=g, device="cuda") * (1.0 / math.sqrt(d))).to(HALF[dt])
+        bias = torch.randn((N,), generator=g, device="cuda") * 0.3
+        acc = a.float() @ w.float().T
+        scale = float(acc.abs().max())
+        tol = 1e-3 * math.sqrt(d / 64) * scale + 2 * ULP[dt] * scale + 4 * ULP[dt] * float(a.float().abs().max())
+        if epi == "qkv":
+            qk, vt = ctx.linear_query(w, x=x, ln=(gamma, beta, 1e-5), epi="qkv", n_split=2 * d)
+            assert torch.isfinite(qk.float()).all() and torch.isfinite(vt.float()).all()
+            assert float((qk.float() - acc[:, : 2 * d]).abs().max()) < tol and float((vt.float() - acc[:, 2 * d:].T).abs().max()) < tol
+        else:
+            got = ctx.linear_query(w, x=x, ln=(gamma, beta, 1e-5), bias=bias, epi="gelu")
+            want = gelu_new(acc + bias)
+            assert float((got.float() - want).abs().max()) < tol + ULP[dt] * float(want.abs().max())
+
+
+def test_query_projection_refuses_shapes_it_does_not_serve(ctx):
+    from sgpt_amd._lib import SgptHipError
+    a, w, bias, resid = operands(48, 768, 768, "f16", seed=1)          # M % 32 != 0
+    with pytest.raises(SgptHipError, match="not served"):
+        ctx.linear_query(w, a=a, epi="store")
+    a, w, bias, resid = operands(32, 768, 640, "f16", seed=2)          # K / 128 = 5
+    with pytest.raises(SgptHipError, match="not served"):
+        ctx.linear_query(w, a=a, epi="store")
