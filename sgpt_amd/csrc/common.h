@@ -165,6 +165,31 @@ __device__ __forceinline__ float wave_sum_valu(float v) {
     v += dpp_mov<0xB1>(v);                                                          // quad_perm [1,0,3,2] = lane ^ 1
     return v;
 }
+// R independent wave sums, the butterfly steps interleaved across the values (step k of every value before step k + 1 of any): each
+// value goes through exactly wave_sum_valu's operations -- same bits -- but the dependent DPP / permlane chain of one value (~12 ops
+// that each wait for the previous one) now overlaps with the others' (round 6: the LayerNorm prologue of a query-sized projection
+// normalised its four rows per wave one after the other, ~1 200 cycles each)
+template <int R>
+__device__ __forceinline__ void wave_sum_valu_multi(float (&v)[R]) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[u]), __float_as_uint(v[u]), false, false);
+        v[u] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[u]), __float_as_uint(v[u]), false, false);
+        v[u] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] += dpp_mov<0x128>(v[u]);
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] += dpp_mov<0x1B>(dpp_mov<0x141>(v[u]));
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] += dpp_mov<0x4E>(v[u]);
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] += dpp_mov<0xB1>(v[u]);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

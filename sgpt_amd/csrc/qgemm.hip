@@ -175,9 +175,12 @@ __global__ __launch_bounds__(QNT) void qgemm_kernel(const QGemmArgs q) {
 #pragma unroll
         for (int batch = 0; batch < RPW / RB; ++batch) {
             if (batch > 0) ln_rows_load(batch);
+            // (the rows' reduction chains interleaved: same bits.  What the prologue costs is VALU throughput, not latency: ~210
+            //  instructions per row, 4 rows per wave, two waves per SIMD -- 2.5 us of a 7.7 us launch at 32 rows, measured by compiling
+            //  the arithmetic out (5.2 us); the rows' loads are 0.4 us of it.  profiles/r06_qgemm_ln_ablation.txt)
+            rowln_normalize_rows<NV, RB, false>(rl, gg, bb, K, q.eps, lane);
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
-                rl[u].normalize_pre(gg, bb, K, q.eps, lane);
                 const int row = wave * RPW + batch * RB + u;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {

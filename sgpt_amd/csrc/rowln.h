@@ -73,3 +73,39 @@ struct RowLN {
     }
 };
 
+// R rows normalised together (gamma / beta in registers): RowLN::normalize_pre on each row, with the rows' reductions interleaved
+// (wave_sum_valu_multi) -- the same operations on every row, the same bits.
+template <int NV, int R, bool NT>
+__device__ __forceinline__ void rowln_normalize_rows(RowLN<NV, NT> (&r)[R], const float4* gg, const float4* bb, int d, float eps, int lane) {
+    float s[R], q[R], mean[R], rstd[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        s[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s[u] += (r[u].v[i].x + r[u].v[i].y) + (r[u].v[i].z + r[u].v[i].w);
+    }
+    wave_sum_valu_multi<R>(s);
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        mean[u] = s[u] / (float)d;
+        q[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < d) {
+                const float a0 = r[u].v[i].x - mean[u], a1 = r[u].v[i].y - mean[u], a2 = r[u].v[i].z - mean[u], a3 = r[u].v[i].w - mean[u];
+                q[u] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+    }
+    wave_sum_valu_multi<R>(q);
+#pragma unroll
+    for (int u = 0; u < R; ++u) rstd[u] = 1.0f / sqrtf(q[u] / (float)d + eps);
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < d) r[u].scale(i, mean[u], rstd[u], gg[i], bb[i]);
+        }
+}
