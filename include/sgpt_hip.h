@@ -159,7 +159,7 @@ sgpt_status sgpt_model_set_act_scales(sgpt_model* model, const float* scales, in
  * [seq_off[b], seq_off[b+1]) of the packed token axis; its seq_len[b] real tokens come
  * first.  seq_off[] are even (ABI <= v5 asked for multiples of 8; any such layout is still valid), seq_off[B] <= T_pad, T_pad is a multiple of 32
  * (ABI <= v7: 128; rows past seq_off[B] are filler: computed by the row-wise kernels, never attended to).  Layouts of at most
- * 512 rows take the query-sized kernels (csrc/qgemm.hip: 32-row tiles, LayerNorm inside the projections); same bits.
+ * 4096 rows take the query- / mid-sized kernels (csrc/qgemm.hip: tiles of 32 .. 128 rows, LayerNorm inside the projections); same bits.
  *   ids      device int32[T_pad]  token ids (filler rows: any valid id)
  *   pos      device int32[T_pad]  absolute position id = pad_left[b] + t  (HF:gpt_neo:451 uses
  *                                 the PADDED index arange(S); filler rows: 0)

@@ -531,9 +531,9 @@ static sgpt_status encode_impl(sgpt_model* m, const int32_t* ids, const int32_t*
             if (!(m->act_scale[li] > 0.f) || !(m->act_scale[m->d.n_layers + li] > 0.f))
                 return fail(c, SGPT_ERR_INVALID, "SGPT_FP8M: activation scales are not set (sgpt_model_calibrate_begin / _end, or sgpt_model_set_act_scales)");
     // Query-sized batches (round 6; qgemm.hip): at most QGEMM_MAX_ROWS token rows, plain 16-bit operands, no probe / calibration
-    // pass riding on the forward.  Every projection takes the LDS-DMA ring kernel; at d <= 1024 the two LayerNorms of a
-    // sequential block (GPT-Neo, BLOOM) run inside the prologues of the projections they feed: five launches per block instead
-    // of seven.  Same arithmetic per element as the bulk path (identical bits); sgpt_ctx_set_tile_policy(1) keeps the bulk kernels.
+    // pass riding on the forward.  Every projection takes the register-staged deep-prefetch kernel; at d = 512 / 768 / 1024 the two
+    // LayerNorms of a sequential block (GPT-Neo, BLOOM) run inside the prologues of the projections they feed: five launches per block
+    // instead of seven.  Same arithmetic per element as the bulk path (identical bits); sgpt_ctx_set_tile_policy(1 | 2) keeps the bulk kernels.
     const bool qpath = bf && !fp8 && !split && !(m->probing && m->crest_dev) && !m->calibrating && !c->force256 && !c->no_qpath && T <= QGEMM_MAX_ROWS &&
                        qgemm_shape_ok(T, 3 * dm, dm, EPI_QKV, 2 * dm) && qgemm_shape_ok(T, dm, dm, EPI_BIAS_RESID, 0) &&
                        qgemm_shape_ok(T, ffn, dm, EPI_BIAS_GELU, 0) && qgemm_shape_ok(T, dm, ffn, EPI_BIAS_RESID, 0);
