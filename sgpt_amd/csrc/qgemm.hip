@@ -362,12 +362,12 @@ inline int q_ncu() {
 // ---- tile choice (plain kernels): one launch = rounds x (BM + BN) K 2 bytes per workgroup; the fewest wins, ties to the larger tile ----
 struct QTile { int bm, bn, kd; };
 constexpr QTile Q_TILES[] = {{32, 16, 256}, {32, 32, 128}, {32, 64, 128}, {64, 32, 128}, {64, 64, 128}, {128, 64, 128}, {128, 128, 128}};
-// (measured and dropped: 512- / 256-element stages for the 32-row tiles -- fc2 at 32 rows 8.5 us against 8.1 -- and a software-pipelined
-//  k-loop, the MFMAs of stage s running under stage s + 1's LDS fill and barrier with their first fragments fetched a stage ahead
-//  (three LDS stages; commit "pipelined k-loop probe"): 8.0 against 8.1.  The serial chain of a small tile is the dependent MFMAs
-//  themselves: ~100 cycles per v_mfma_f32_16x16x32 whose C operand is the previous one's result, 96 of them for K = 3072 = 4.6 us,
-//  24 for K = 768 = 1.2 us -- on top of ~3 us of launch that is the 8.1 / 4.2 us these launches take.  A k-ascending sum per output
-//  element cannot go below it; profiles/r06_qgemm_tile_sweep.txt, r06_qgemm_pipe_probe.txt)
+// (measured and dropped for the 32-row tiles, fc2 at 32 rows = 8.1 us per launch: 512- / 256-element stages 8.5; a software-pipelined
+//  k-loop -- the MFMAs of stage s under stage s + 1's LDS fill and barrier, their first fragments fetched a stage ahead, three LDS
+//  stages -- 8.0; all twelve stages in flight from the start (D = 12, 288 KiB per workgroup) 9.2.  Stamps: the first stage is
+//  released 1.9 us after entry, then one 256-element stage (24 KiB) every 0.44 us = 55 GB/s per CU, half of what a free-running
+//  stream reaches -- whatever the depth, the stage length or the LDS schedule.  profiles/r06_qgemm_tile_sweep.txt,
+//  r06_qgemm_pipe_probe.txt, r06_qgemm_stage_stamps.txt)
 constexpr int Q_NTILES = sizeof(Q_TILES) / sizeof(Q_TILES[0]);
 
 // depth class of a tile at this K: 6 -> SIX kernels, 4 -> the others, 0 -> not served
