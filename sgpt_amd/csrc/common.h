@@ -311,7 +311,6 @@ struct QGemmArgs {
     const float* ln_g;
     const float* ln_b;
     float eps, ln_mul;     // ln_mul: power-of-two range shift of the normalised rows (0 is read as 1)
-    int ns;                // ring stages (set by the launcher)
     int group;             // LayerNorm prologue: column tiles per workgroup (set by the launcher)
     int tile;              // 0 = the launcher's choice; k > 0 = its k-th candidate tile (scripts/micro/qgemm_probe.hip: tile sweeps)
 };

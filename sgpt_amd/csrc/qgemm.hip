@@ -324,14 +324,14 @@ __global__ __launch_bounds__(QNT) void qgemm_kernel(const QGemmArgs q) {
     range.finish(p.range_flag, p.range_amax);
 }
 
-template <int BM, int BN, bool LN_A, int KD>
-constexpr int q_ch() { return ((LN_A ? 0 : BM) + BN) * KD * 2 / (QNT * 16); }
-// stages in flight: as many as 24 sixteen-byte chunks per thread allow -- 6 (or 3) when K / KD is a multiple of 6, else 4 (or 2)
+// 16-byte chunks per thread and ring stage of a tile
+constexpr int q_chunks(int bm, int bn, bool ln_a, int kd) { return ((ln_a ? 0 : bm) + bn) * kd * 2 / (QNT * 16); }
+// THE depth rule (used by the kernel instantiations and by the launcher's feasibility check alike): stages in flight, as many as the
+// registers allow -- 24 chunks per thread up to 4 chunks per stage, 18 / 16 above (128-row tiles carry 32-64 accumulators) -- in two
+// classes: SIX for K / KD a multiple of 6 (or 3), FOUR for a multiple of 4 (or 2)
+constexpr int q_depth_rule(int ch, bool six) { return ch >= 8 ? 2 : six ? (ch * 6 <= 24 ? 6 : 3) : (ch * 4 <= 16 ? 4 : 2); }
 template <int BM, int BN, bool LN_A, int KD, bool SIX>
-constexpr int q_depth() {
-    constexpr int ch = q_ch<BM, BN, LN_A, KD>();
-    return ch >= 8 ? 2 : SIX ? (ch * 6 <= 24 ? 6 : 3) : (ch * 4 <= 16 ? 4 : 2);      // (8 chunks per stage: 128 x 128 accumulators leave room for two)
-}
+constexpr int q_depth() { return q_depth_rule(q_chunks(BM, BN, LN_A, KD), SIX); }
 
 template <typename T, int EPI, typename OutT, int BM, int BN, bool LN_A, int NV, int KD, int D>
 void qlaunch(const QGemmArgs& a, int group, hipStream_t s) {
@@ -342,7 +342,7 @@ void qlaunch(const QGemmArgs& a, int group, hipStream_t s) {
     }();
     (void)attr_set;
     QGemmArgs b = a;
-    b.ns = 2; b.group = group;
+    b.group = group;
     const int nk = a.g.K / KD;
     const size_t lds = (size_t)(LN_A ? nk * BM * KD * 2 + group * BN * 4 : 0) + (size_t)2 * ((LN_A ? 0 : BM) + BN) * KD * 2;
     const int NT = a.g.N / BN, R = ((a.g.M + BM - 1) / BM) * ((NT + group - 1) / group);
@@ -374,8 +374,8 @@ constexpr int Q_NTILES = sizeof(Q_TILES) / sizeof(Q_TILES[0]);
 inline int q_class(const QTile& tl, bool ln_a, int K) {
     if (K % tl.kd) return 0;
     const int nk = K / tl.kd;
-    const int ch = ((ln_a ? 0 : tl.bm) + tl.bn) * tl.kd * 2 / (QNT * 16);
-    const int d6 = ch >= 8 ? 2 : ch * 6 <= 24 ? 6 : 3, d4 = ch >= 8 ? 2 : ch * 4 <= 16 ? 4 : 2;   // (q_depth<>: the depths of the two kernel classes)
+    const int ch = q_chunks(tl.bm, tl.bn, ln_a, tl.kd);
+    const int d6 = q_depth_rule(ch, true), d4 = q_depth_rule(ch, false);
     const bool ok6 = nk % d6 == 0, ok4 = nk % d4 == 0;
     if (ok6 && (!ok4 || d6 >= d4)) return 6;
     return ok4 ? 4 : 0;
