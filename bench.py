@@ -845,6 +845,8 @@ def main():
            "queries_per_sec_at_1M_corpus_incl_query_encode": None if qps_1m_enc is None else round(qps_1m_enc, 1),
            "queries_per_sec_at_1M_corpus_incl_query_encode_by_nq": {str(k_): round(v_, 1) for k_, v_ in qps_enc_by_nq.items()},
            "queries_per_sec_at_1M_corpus_incl_query_encode_low_latency_mode": {str(k_): round(v_, 1) for k_, v_ in qps_enc_ll.items()},
+           "low_latency_mode_note": "round 6: layouts of <= 4096 token rows run csrc/qgemm.hip, which keeps the k-ascending sum and ignores the opt-in "
+                                    "k-group mode (sgpt_ctx_set_low_latency): these figures equal the default mode's to within noise",
            "queries_per_sec_at_1M_corpus_k1001": k1001, "projected_8gpu": projected, "precision_modes": modes,
            "varlen": varlen, "shard_check": shard_check,
            "query_encode_latency": query_latency, "scorer_breakdown_1M_pass": scorer_breakdown, "event_record_ab": event_ab,
