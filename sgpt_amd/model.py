@@ -936,11 +936,11 @@ class EncodeGraph:
     (B, T_pad, max_alloc), or -- with bucket=(B_cap, T_cap, A_cap) -- of any batch that fits that capacity (padded with
     one-token filler sequences whose output rows are dropped, pack_layout).  Replay refills the captured token arena with
     one pinned copy.  The workspace is sized by a warm-up call before capture (hipMalloc is not capturable).
-    What it buys, measured on MI355X: host time only.  A 12-block forward is ~110 launches; eager, the host enqueues them
-    in ~0.5 ms while the GPU needs 0.9-1.5 ms for a 16-32 query batch (each small kernel is a serial load -> LDS -> MFMA
-    chain), so GPU time is unchanged by replay (32 queries: 1.579 ms eager, 1.586 ms replay).  Use it when the host
-    thread is the scarce resource (many models / streams driven from one Python thread); the GPU-side latency of small
-    batches is addressed in the kernels (k-groups in gemm.hip)."""
+    What it buys, measured on MI355X: host time only.  A 12-block forward is 63 launches on the query-sized kernels (round 6;
+    ~110 before); eager, the host enqueues them faster than the GPU retires them (one query: 0.42 ms of GPU time, launch gaps
+    of 0.04 us in the kernel trace), so GPU time is unchanged by replay (round 3, 32 queries: 1.579 ms eager, 1.586 ms replay).
+    Use it when the host thread is the scarce resource (many models / streams driven from one Python thread); the GPU-side
+    latency of small batches is addressed in the kernels (csrc/qgemm.hip)."""
 
     def __init__(self, model: "SGPTModel", seqs: Sequence[Sequence[int]], mode: str = "weightedmean",
                  normalize: bool = False, layer_idx: int = -1, pad_left: Optional[Sequence[int]] = None,
