@@ -112,6 +112,25 @@ def test_encode_f16_vs_golden(tag):
         assert maxabs(g2, fx[f"emb_{mode}"]) < TOL_F16_ABS * max(1.0, float(np.abs(fx[f"emb_{mode}"]).max())), mode
 
 
+@pytest.mark.parametrize("dtype", ["f16", "fp32"])
+def test_single_sentence_encodes_match_the_reference_rows(dtype):
+    """`SentenceTransformer.encode("one sentence")` (SentenceTransformer.py:143-146): every sentence of BASELINE configs[0]'s batch
+    encoded ALONE (a 32- / 64-row layout on the query-sized kernels of csrc/qgemm.hip) against the row the reference stack
+    (HF eager + Pooling.py, tests/golden) computed for it inside the padded batch of 32; the pairwise cosines of the 32
+    one-at-a-time embeddings at the north_star bar."""
+    fx, cfg_kw, seqs, pad_left, ids, mask = load_case("cfg1_125m_32x64")
+    m = build_model(cfg_kw, int(fx["seed"]), float(fx["std"]), dtype)
+    ref = fx["emb_weightedmean"]
+    got = np.concatenate([m.encode_ids([s], mode="weightedmean", pad_left=None if pad_left is None else [pad_left[i]]).cpu().numpy()
+                          for i, s in enumerate(seqs)])
+    err = maxabs(got, ref)
+    dev = maxabs(O.cos_sim(got, got), O.cos_sim(ref, ref))
+    print(f"cfg1 one-at-a-time {dtype}: max|emb - ref| = {err:.3e}, max|cos - cos_ref| = {dev:.3e}")
+    tol = TOL_FP32 if dtype == "fp32" else TOL_F16_ABS * max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(got).all() and err < tol and dev < (1e-4 if dtype == "fp32" else TOL_F16_DCOS)
+    assert np.array_equal(got, m.encode_ids(seqs, mode="weightedmean", pad_left=pad_left).cpu().numpy())   # and == the batch of 32, bit for bit
+
+
 def test_f16_range_shifts_cover_outliers_and_the_guard_stays_loud():
     """f16 has 5 exponent bits.  Operand classes that would leave the format are stored under a power-of-two down-shift
     which the consuming GEMM undoes on its fp32 accumulators (exact): a LayerNorm bound beyond the format is handled at
