@@ -26,6 +26,7 @@
 // groups of a ds_read_b128 fragment read (rows fr, chunks 4 ks + g) cover all 64 banks once (scripts/lds_layout_check.py).
 // The image is thread-linear (thread t writes bytes [16 t, 16 t + 16) of each 8-KiB slab), so the XOR is applied to each
 // thread's SOURCE chunk.
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -336,11 +337,15 @@ constexpr int q_depth() { return q_depth_rule(q_chunks(BM, BN, LN_A, KD), SIX); 
 template <typename T, int EPI, typename OutT, int BM, int BN, bool LN_A, int NV, int KD, int D>
 void qlaunch(const QGemmArgs& a, int group, hipStream_t s) {
     auto* kern = qgemm_kernel<T, EPI, OutT, BM, BN, LN_A, NV, KD, D>;
-    static const bool attr_set = [&] {
+    // more than 64 KiB of dynamic LDS is a per-function, per-DEVICE opt-in: once per device this process launches on
+    static std::atomic<unsigned> attr_done{0u};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)attr_set;
+        attr_done.fetch_or(bit, std::memory_order_relaxed);
+    }
     QGemmArgs b = a;
     b.group = group;
     const int nk = a.g.K / KD;
