@@ -799,7 +799,7 @@ def main():
         torch.cuda.empty_cache()
         other_configs = {"note": "python bench.py --model M --dtype D --steps 3 --warmup 1 --chunk 1024 (1024-document steps, seq_len 128, same step "
                                  "definition); frac = end-to-end fraction of the 16-bit dense MFMA peak (fp8mfma: of that SAME 2.5 PFLOP/s peak); "
-                                 "parity of each mode at its shape: profiles/r05_models.jsonl, tests/test_gpu_parity_large.py"}
+                                 "parity of each mode at its shape: profiles/r06_models.jsonl, tests/test_gpu_parity_large.py"}
         for tag, mdl, dt_ in (("configs[2] SGPT-1.3B f16 (default precise_qk)", "1.3b", "f16"), ("configs[2] SGPT-1.3B bf16", "1.3b", "bf16"),
                               ("configs[3] SGPT-5.8B bf16", "5.8b", "bf16"), ("configs[4] bloom-7b1 fp8 MFMA", "bloom-7b1", "fp8mfma")):
             try:
